@@ -1,0 +1,150 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself, run in the build container.
+
+    python oracle/make_golden.py            # needs /root/reference (never present on the GPU box)
+
+The reference modules are imported by path (oracle/ref_shim.py), loaded with the repo's seeded
+synthetic weights (tortoise_tts_amd/weights.py: the same numbers every test regenerates), and run on
+seeded inputs; only inputs and outputs are stored.  A fixture is data: no reference source text,
+bytecode or pickled module is written anywhere.
+
+Fixtures
+  ar_small.npz    UnifiedVoice(layers=2, dim=128, heads=2): prefill + 6 KV-cached decode steps (logits),
+                  forward(return_latent=True) latents                       (unified_voice.py:178-254, :544-599)
+  ar_full.npz     full-size UnifiedVoice(): prefill + 2 decode steps (logit slices), latents slice
+  diff_small.npz  DiffusionTTS(128 ch, 2 layers, 2 heads): timestep_independent, forward cond/uncond,
+                  DDIM 4 steps, p-sampler 4 steps                            (diffusion.py:1487-1574, :500-810)
+  diff_full.npz   full-size DiffusionTTS(): one forward (cond + uncond) at T=26
+  schedule.npz    get_diffuser(steps) tables for steps in 4, 30, 80, 200    (diffusion.py:1576-1590)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+from tortoise_tts_amd import weights as W  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def gen(seed):
+	g = torch.Generator(device="cpu")
+	g.manual_seed(seed)
+	return g
+
+
+def load_into(module, sd):
+	missing, unexpected = module.load_state_dict(sd, strict=False)
+	assert not unexpected, unexpected
+	return module.eval()
+
+
+def ar_case(uv_mod, cfg, seed, B, Tt, n_dec, M, full):
+	sd = W.synth_state_dict(W.ar_shapes(cfg), seed)
+	m = uv_mod.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, checkpointing=False)
+	load_into(m, sd)
+	text = torch.randint(1, 255, (1, Tt), generator=gen(seed + 1))
+	cond = torch.randn(1, cfg.model_dim, generator=gen(seed + 2))
+	dec_tokens = torch.randint(0, 8192, (B, n_dec), generator=gen(seed + 3))
+	codes = torch.randint(0, 8192, (B, M), generator=gen(seed + 4))
+	out = dict(text=text.numpy(), cond=cond.numpy(), dec_tokens=dec_tokens.numpy(), codes=codes.numpy(),
+				seed=np.int64(seed), B=np.int64(B))
+	with torch.inference_mode():
+		ids = m.compute_embeddings(cond, text)             # builds inference_model, stores prefix emb
+		ids = ids.repeat(B, 1)
+		im = m.inference_model
+		P1 = ids.shape[1]
+		r = im.forward(input_ids=ids, attention_mask=torch.ones(B, P1, dtype=torch.long), use_cache=True, return_dict=True)
+		pre = r.logits[:, -1].float()
+		past = r.past_key_values
+		dec = []
+		for k in range(1, n_dec + 1):
+			r = im.forward(input_ids=dec_tokens[:, k - 1:k], past_key_values=past,
+							attention_mask=torch.ones(B, P1 + k, dtype=torch.long), use_cache=True, return_dict=True)
+			past = r.past_key_values
+			dec.append(r.logits[:, -1].float())
+		dec = torch.stack(dec, 1)
+		lat = m.forward(cond.repeat(B, 1), text.repeat(B, 1), torch.tensor([Tt] * B, dtype=torch.int32), codes,
+						torch.tensor([M * cfg.mel_length_compression] * B), return_latent=True, clip_inputs=False)
+	if full:   # keep the fixture small: vocabulary slices + a latent slice
+		sel = torch.cat([torch.arange(0, 96), torch.arange(8100, 8194)])
+		out.update(logit_cols=sel.numpy(), prefill_logits=pre[:, sel].numpy(), decode_logits=dec[:, :, sel].numpy(),
+					latents=lat[:, :, :128].numpy())
+	else:
+		out.update(prefill_logits=pre.numpy(), decode_logits=dec.numpy(), latents=lat.numpy())
+	return out
+
+
+def diff_case(d_mod, cfg, seed, b, M, full):
+	sd = W.synth_state_dict(W.diffusion_shapes(cfg), seed)
+	m = d_mod.DiffusionTTS(model_channels=cfg.model_channels, num_layers=cfg.num_layers,
+							in_latent_channels=cfg.in_latent_channels, num_heads=cfg.num_heads)
+	load_into(m, sd)
+	T = M * 4 * 24000 // 22050
+	lat = torch.randn(b, M, cfg.in_latent_channels, generator=gen(seed + 1))
+	cond = torch.randn(b, 2 * cfg.model_channels, generator=gen(seed + 2))
+	x = torch.randn(b, 100, T, generator=gen(seed + 3))
+	t = torch.tensor([1333, 2666][:b])
+	out = dict(latents=lat.numpy(), cond=cond.numpy(), x=x.numpy(), t=t.numpy(), T=np.int64(T), seed=np.int64(seed))
+	with torch.inference_mode():
+		E = m.timestep_independent(lat, cond, T, False)
+		yc = m(x, t, precomputed_aligned_embeddings=E)
+		yu = m(x, t, precomputed_aligned_embeddings=E, conditioning_free=True)
+		out.update(E=E.numpy(), y_cond=yc.numpy(), y_uncond=yu.numpy())
+		if not full:
+			noise = torch.randn(1, 100, T, generator=gen(seed + 5))
+			for sampler in ("ddim", "p"):
+				for cf in (True, False):
+					diffuser = d_mod.get_diffuser(steps=4, cond_free=cf)
+					torch.manual_seed(seed + 6)
+					mel = diffuser.sample_loop(m, (1, 100, T), sampler=sampler, noise=noise,
+												model_kwargs={"precomputed_aligned_embeddings": E[:1]}, progress=False)
+					out[f"{sampler}_cf{int(cf)}"] = mel.numpy()
+			out["noise"] = noise.numpy()
+			out["sampler_seed"] = np.int64(seed + 6)
+	return out
+
+
+def schedule_case(d_mod):
+	out = {}
+	for steps in (4, 30, 80, 200):
+		df = d_mod.get_diffuser(steps=steps, cond_free=True)
+		out[f"map_{steps}"] = np.array(df.timestep_map, dtype=np.int64)
+		for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+					"sqrt_recipm1_alphas_cumprod", "posterior_log_variance_clipped", "posterior_mean_coef1",
+					"posterior_mean_coef2"):
+			out[f"{name}_{steps}"] = np.asarray(getattr(df, name), dtype=np.float64)
+	return out
+
+
+def main():
+	os.makedirs(OUT, exist_ok=True)
+	torch.set_num_threads(8)
+	d_mod, uv_mod = ref_shim.load()
+	jobs = [
+		("schedule", lambda: schedule_case(d_mod)),
+		("ar_small", lambda: ar_case(uv_mod, W.AR_SMALL, 11, B=2, Tt=12, n_dec=6, M=10, full=False)),
+		("diff_small", lambda: diff_case(d_mod, W.DIFF_SMALL, 21, b=2, M=10, full=False)),
+		("ar_full", lambda: ar_case(uv_mod, W.AR_FULL, 12, B=1, Tt=8, n_dec=2, M=6, full=True)),
+		("diff_full", lambda: diff_case(d_mod, W.DIFF_FULL, 22, b=1, M=6, full=True)),
+	]
+	only = set(sys.argv[1:])
+	for name, fn in jobs:
+		if only and name not in only:
+			continue
+		t0 = time.time()
+		data = fn()
+		path = os.path.join(OUT, name + ".npz")
+		np.savez_compressed(path, **data)
+		print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB in {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+	main()

@@ -1,0 +1,208 @@
+"""Weight tables of the two hot-path networks, in the reference's `state_dict` key names, and a
+seeded synthetic generator for them.
+
+The key names/shapes ARE the de-facto wire format of the reference checkpoints
+(`/root/reference/tortoise_tts/models/__init__.py:104-110,163-167` loads plain `state_dict`s of
+`UnifiedVoice` `models/unified_voice.py:334-451` and `DiffusionTTS` `models/diffusion.py:1389-1465`).
+No pretrained weights exist offline, so every test, fixture and bench run uses
+`synth_state_dict`: each tensor is drawn from its own CPU mt19937 stream keyed by (seed, crc32(name)),
+so any subset can be regenerated bit-identically on any machine without the reference.
+"""
+from __future__ import annotations
+
+import dataclasses
+import zlib
+from typing import Dict, Tuple
+
+import torch
+
+
+@dataclasses.dataclass(frozen=True)
+class ARConfig:
+	"""`UnifiedVoice.__init__` defaults, models/unified_voice.py:335-355."""
+	layers: int = 30
+	model_dim: int = 1024
+	heads: int = 16
+	max_text_tokens: int = 402
+	max_mel_tokens: int = 604
+	max_conditioning_inputs: int = 2
+	number_text_tokens: int = 255
+	start_text_token: int = 255
+	stop_text_token: int = 0
+	number_mel_codes: int = 8194
+	start_mel_token: int = 8192
+	stop_mel_token: int = 8193
+	mel_length_compression: int = 1024
+
+	@property
+	def head_dim(self):
+		return self.model_dim // self.heads
+
+	@property
+	def max_mel_seq_len(self):  # unified_voice.py:405
+		return self.max_mel_tokens + 2 + self.max_conditioning_inputs
+
+	@property
+	def max_text_seq_len(self):  # unified_voice.py:406
+		return self.max_text_tokens + 2
+
+
+@dataclasses.dataclass(frozen=True)
+class DiffusionConfig:
+	"""`DiffusionTTS.__init__` defaults, models/diffusion.py:1390-1404."""
+	model_channels: int = 1024
+	num_layers: int = 10
+	in_channels: int = 100
+	in_latent_channels: int = 1024
+	out_channels: int = 200
+	num_heads: int = 16
+
+	@property
+	def head_dim(self):
+		return self.model_channels // self.num_heads
+
+
+AR_SMALL = ARConfig(layers=2, model_dim=128, heads=2)
+AR_FULL = ARConfig()
+DIFF_SMALL = DiffusionConfig(model_channels=128, num_layers=2, in_latent_channels=128, num_heads=2)
+DIFF_FULL = DiffusionConfig()
+
+
+def ar_shapes(c: ARConfig) -> Dict[str, Tuple[int, ...]]:
+	"""Hot-path subset of `UnifiedVoice.state_dict()` (conditioning_encoder / text_head are off-path)."""
+	d = c.model_dim
+	s: Dict[str, Tuple[int, ...]] = {
+		"text_embedding.weight": (c.number_text_tokens + 1, d),
+		"mel_embedding.weight": (c.number_mel_codes, d),
+		"mel_pos_embedding.emb.weight": (c.max_mel_seq_len, d),
+		"text_pos_embedding.emb.weight": (c.max_text_seq_len, d),
+		"gpt.ln_f.weight": (d,), "gpt.ln_f.bias": (d,),
+		"final_norm.weight": (d,), "final_norm.bias": (d,),
+		"mel_head.weight": (c.number_mel_codes, d), "mel_head.bias": (c.number_mel_codes,),
+	}
+	for i in range(c.layers):
+		p = f"gpt.h.{i}."
+		s.update({
+			p + "ln_1.weight": (d,), p + "ln_1.bias": (d,),
+			p + "attn.c_attn.weight": (d, 3 * d), p + "attn.c_attn.bias": (3 * d,),   # HF Conv1D: [in, out]
+			p + "attn.c_proj.weight": (d, d), p + "attn.c_proj.bias": (d,),
+			p + "ln_2.weight": (d,), p + "ln_2.bias": (d,),
+			p + "mlp.c_fc.weight": (d, 4 * d), p + "mlp.c_fc.bias": (4 * d,),
+			p + "mlp.c_proj.weight": (4 * d, d), p + "mlp.c_proj.bias": (d,),
+		})
+	return s
+
+
+def _attn_shapes(p: str, ch: int, heads: int):
+	return {
+		p + "norm.weight": (ch,), p + "norm.bias": (ch,),
+		p + "qkv.weight": (3 * ch, ch, 1), p + "qkv.bias": (3 * ch,),
+		p + "proj_out.weight": (ch, ch, 1), p + "proj_out.bias": (ch,),
+		p + "relative_pos_embeddings.relative_attention_bias.weight": (32, heads),
+	}
+
+
+def _resblock_shapes(p: str, ch: int):
+	return {
+		p + "in_layers.0.weight": (ch,), p + "in_layers.0.bias": (ch,),
+		p + "in_layers.2.weight": (ch, ch, 1), p + "in_layers.2.bias": (ch,),
+		p + "emb_layers.1.weight": (2 * ch, ch), p + "emb_layers.1.bias": (2 * ch,),
+		p + "out_layers.0.weight": (ch,), p + "out_layers.0.bias": (ch,),
+		p + "out_layers.3.weight": (ch, ch, 3), p + "out_layers.3.bias": (ch,),
+	}
+
+
+def diffusion_shapes(c: DiffusionConfig) -> Dict[str, Tuple[int, ...]]:
+	"""Hot-path subset of `DiffusionTTS.state_dict()` (contextual_embedder / code_converter /
+	code_embedding / mel_head are off-path: conditioning latents come from the reference path and
+	aligned conditioning is always a latent at inference, inference.py:402)."""
+	ch = c.model_channels
+	s: Dict[str, Tuple[int, ...]] = {
+		"unconditioned_embedding": (1, ch, 1),
+		"inp_block.weight": (ch, c.in_channels, 3), "inp_block.bias": (ch,),
+		"time_embed.0.weight": (ch, ch), "time_embed.0.bias": (ch,),
+		"time_embed.2.weight": (ch, ch), "time_embed.2.bias": (ch,),
+		"code_norm.weight": (ch,), "code_norm.bias": (ch,),
+		"latent_conditioner.0.weight": (ch, c.in_latent_channels, 3), "latent_conditioner.0.bias": (ch,),
+		"integrating_conv.weight": (ch, 2 * ch, 1), "integrating_conv.bias": (ch,),
+		"out.0.weight": (ch,), "out.0.bias": (ch,),
+		"out.2.weight": (c.out_channels, ch, 3), "out.2.bias": (c.out_channels,),
+	}
+	for i in range(1, 5):
+		s.update(_attn_shapes(f"latent_conditioner.{i}.", ch, c.num_heads))
+	for i in range(3):
+		s.update(_resblock_shapes(f"conditioning_timestep_integrator.{i}.resblk.", ch))
+		s.update(_attn_shapes(f"conditioning_timestep_integrator.{i}.attn.", ch, c.num_heads))
+	for i in range(c.num_layers):
+		s.update(_resblock_shapes(f"layers.{i}.resblk.", ch))
+		s.update(_attn_shapes(f"layers.{i}.attn.", ch, c.num_heads))
+	for i in range(c.num_layers, c.num_layers + 3):
+		s.update(_resblock_shapes(f"layers.{i}.", ch))
+	return s
+
+
+def _gain_for(name: str, shape: Tuple[int, ...]) -> Tuple[str, float]:
+	"""(kind, std) of the synthetic draw for a key.  Chosen so that every op on the path is exercised
+	with O(1) activations: norm scales near 1, matrices fan-in scaled, residual-branch outputs damped.
+	The reference zero-initialises `proj_out` (models/arch_utils.py:172); a zero matrix would leave
+	the attention untested, so it is drawn like every other matrix."""
+	leaf = name.rsplit(".", 1)[-1]
+	if name == "unconditioned_embedding":
+		return "normal", 1.0
+	if "relative_attention_bias" in name:
+		return "normal", 0.2
+	if "embedding" in name:   # token / position tables
+		return "normal", 0.5
+	is_norm = (len(shape) == 1 and leaf == "weight")
+	if is_norm:
+		return "norm_scale", 0.1
+	if leaf == "bias":
+		return "normal", 0.05
+	fan_in = shape[0] if ("gpt.h." in name) else 1     # HF Conv1D is [in, out]
+	if fan_in == 1:
+		fan_in = 1
+		for s in shape[1:]:
+			fan_in *= s
+	gain = 1.0
+	if name.endswith("c_proj.weight") or "proj_out" in name or "out_layers.3" in name:
+		gain = 0.5
+	if "emb_layers" in name:
+		gain = 0.5
+	return "normal", gain / (fan_in ** 0.5)
+
+
+def synth_tensor(name: str, shape: Tuple[int, ...], seed: int) -> torch.Tensor:
+	g = torch.Generator(device="cpu")
+	g.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 63 - 1))
+	kind, std = _gain_for(name, shape)
+	t = torch.randn(shape, generator=g, dtype=torch.float32) * std
+	if kind == "norm_scale":
+		t = t + 1.0
+	return t
+
+
+def round_to_bf16(t: torch.Tensor) -> torch.Tensor:
+	"""f32 tensor whose values are exactly representable in bf16 (round-to-nearest-even)."""
+	return t.to(torch.bfloat16).to(torch.float32)
+
+
+def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, bf16_exact: bool = False) -> Dict[str, torch.Tensor]:
+	"""Seeded synthetic weights.  `bf16_exact` rounds every matrix (ndim >= 2) to a bf16-representable
+	value so an f32 oracle and a bf16-weight device path consume the same numbers."""
+	out = {}
+	for name, shape in shapes.items():
+		t = synth_tensor(name, shape, seed)
+		if bf16_exact and t.dim() >= 2:
+			t = round_to_bf16(t)
+		out[name] = t
+	return out
+
+
+def n_params(shapes: Dict[str, Tuple[int, ...]]) -> int:
+	n = 0
+	for s in shapes.values():
+		k = 1
+		for x in s:
+			k *= x
+		n += k
+	return n
