@@ -1,0 +1,123 @@
+/* libttk -- C ABI of the MI355X-native TorToiSe inference hot path.
+ *
+ * The reference (e-c-k-e-r/tortoise-tts) is pure Python and has no FFI of its own; its plugin idiom is replacing the
+ * module objects that `TTS.inference` calls (tortoise_tts/inference.py:185-202).  The entry points
+ * below are what a binding for those call sites needs; each cites the reference interface it stands in for.  The
+ * Python classes in tortoise_tts_amd/ wrap them under the reference's own method names.
+ *
+ * Conventions
+ *  - return 0 on success, a negative TTK_E_* code on failure; ttk_last_error() gives the text; nothing throws or aborts.
+ *  - every tensor argument is a raw DEVICE pointer to a contiguous row-major buffer in the reference's layout
+ *    (b x C x T channels-first for the diffusion net, B x S x D for the AR net); the caller owns them.
+ *  - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); calls only enqueue work and never
+ *    synchronise, allocate or free (except the create and destroy calls and the first call that grows a workspace), so a decode
+ *    step or a diffusion step can be captured into a HIP graph by the caller.
+ *  - a handle owns packed weights, KV cache and workspaces; one handle per (process, device); not re-entrant.
+ *  - weights are passed as f32 tensors (host or device memory) under the reference's state_dict key names and are copied.
+ */
+#ifndef TTK_H
+#define TTK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTK_VERSION 1
+
+enum { TTK_OK = 0, TTK_E_ARG = -1, TTK_E_HIP = -2, TTK_E_WEIGHT = -3, TTK_E_STATE = -4 };
+enum { TTK_F32 = 0, TTK_BF16 = 1 };   /* arithmetic mode: storage/MFMA operand type (accumulation is always f32) */
+
+typedef struct {
+	const char* name;     /* reference state_dict key, e.g. "gpt.h.0.attn.c_attn.weight" */
+	const float* data;    /* f32, contiguous, host or device */
+	int ndim;
+	int64_t shape[4];
+} ttk_weight_view;
+
+int ttk_version(void);
+const char* ttk_last_error(void);   /* thread-local text of the last failure */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Autoregressive model: UnifiedVoice + GPT2InferenceModel (tortoise_tts/models/unified_voice.py:98-254, 334-668).   */
+typedef struct ttk_ar ttk_ar;
+
+typedef struct {
+	int layers, model_dim, heads;             /* unified_voice.py:337-339 ; head_dim must be 64 */
+	int max_mel_seq_len, max_text_seq_len;    /* rows of the two learned position tables (:405-406) */
+	int number_text_tokens_p1, number_mel_codes;
+	int start_text_token, stop_text_token, start_mel_token, stop_mel_token;
+	int dtype;                                /* TTK_F32 | TTK_BF16 */
+	int max_batch;                            /* candidates decoded together (<= 64; <= 32 in TTK_F32) */
+	int max_ctx;                              /* KV-cache rows per sequence: prefix + generated tokens */
+} ttk_ar_config;
+
+/* Copies and packs the hot-path subset of UnifiedVoice.state_dict() (tortoise_tts_amd/weights.py: ar_shapes). */
+int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view* w, int n_w);
+int ttk_ar_destroy(ttk_ar* h);
+
+/* Prefill = first forward of `generate` (unified_voice.py:639-649 prefix build, :203-211 prefill branch, lm_head :239).
+ *   cond_latent [Bc, D] f32 (Bc == 1 or B), text [Tt] int64 raw token ids (start/stop are added here, :639-640)
+ *   logits_out  [B, number_mel_codes] f32 = logits of the last prefill row.  Resets the KV cache to P + 1 rows.   */
+int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, int B,
+				   float* logits_out, void* stream);
+
+/* One KV-cached decode step (unified_voice.py:212-214 + HF GPT2Model + lm_head): feeds back tok [B] int64, the k-th
+ * generated token (k = 1, 2, ... counted by the handle), with mel position k + 1 (the reference's indexing).
+ *   logits_out [B, number_mel_codes] f32;  hidden_out (optional, may be NULL) [B, D] f32 = final_norm(ln_f(h)) of the
+ *   new row, what `sample_stream` yields (stream_generator.py:1172).                                               */
+int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidden_out, void* stream);
+
+/* UnifiedVoice.forward(..., return_latent=True, clip_inputs=False) (unified_voice.py:544-599, get_logits :508-522):
+ *   cond [B, D] f32, text [B, Tt] int64, codes [B, M] int64  ->  latents_out [B, M, D] f32 (= mel_logits[:, :-2]).  */
+int ttk_ar_latents(ttk_ar* h, const float* cond, const int64_t* text, int Tt, const int64_t* codes, int M, int B,
+				   float* latents_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Diffusion decoder: DiffusionTTS + the DDIM / ancestral step (tortoise_tts/models/diffusion.py:1389-1574, 325-431,
+ * 646-694, 510-554) and AttentionBlock / GroupNorm32 / RelativePositionBias (arch_utils.py:24-190, xtransformers.py:148). */
+typedef struct ttk_diff ttk_diff;
+
+typedef struct {
+	int model_channels, num_layers, in_channels, in_latent_channels, out_channels, num_heads;   /* diffusion.py:1392-1400 */
+	int dtype;
+} ttk_diff_config;
+
+/* Besides the hot-path subset of DiffusionTTS.state_dict() (weights.py: diffusion_shapes) the caller passes two derived
+ * host tables: "__time_freqs" [C/2] (diffusion.py:1288-1290) and, per attention block, "<block>.__relbias" [H, 129] =
+ * scale * emb[bucket(d)] for d = -64..64 (xtransformers.py:157-188) -- built by tortoise_tts_amd/diffusion.py.       */
+int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight_view* w, int n_w);
+int ttk_diff_destroy(ttk_diff* h);
+
+/* DiffusionTTS.timestep_independent(latents, cond, T, False) (diffusion.py:1487-1510):
+ *   latents [b, M, Cl] f32, cond [b, 2C] f32, interp_idx [T] int32 device (nearest-neighbour source row of each output
+ *   frame, F.interpolate) -> E_out [b, C, T] f32.                                                                    */
+int ttk_diff_precompute(ttk_diff* h, const float* latents, const float* cond, const int32_t* interp_idx, int b, int M,
+						int T, float* E_out, void* stream);
+
+/* DiffusionTTS.forward(x, t, precomputed_aligned_embeddings=E[, conditioning_free=True]) (diffusion.py:1517-1574):
+ *   x [b, in, T] f32, t [b] int64 device, E [b, C, T] f32 or NULL (=> conditioning_free) -> out [b, out_channels, T].  */
+int ttk_diff_forward(ttk_diff* h, const float* x, const int64_t* t, const float* E, int b, int T, float* out, void* stream);
+
+typedef struct {
+	int64_t t;                 /* original-schedule timestep fed to the network (_WrappedModel map, diffusion.py:1232-1237) */
+	float sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_prev, sqrt_1m_ac_prev;   /* float64 tables -> f32 (:1264) */
+	float coef1, coef2, min_log, max_log;                                   /* ancestral sampler only */
+	float cfk;                 /* conditioning-free weight of this step (:391-393); < 0 disables the second evaluation */
+	int sampler;               /* 0 = ddim (eta 0), 1 = p */
+	int nonzero;               /* p sampler: add noise (i != 0) */
+} ttk_step;
+
+/* Stage E (as returned by ttk_diff_precompute, [b, C, T] f32) for a run of ttk_diff_step calls. */
+int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream);
+/* One sampler step: both network evaluations batched (cond + cond-free share every weight read), then the fused
+ * epilogue; x [b, in, T] f32 updated in place; noise [b, in, T] f32 for the p sampler (NULL for ddim).
+ * (GaussianDiffusion.p_mean_variance / ddim_sample / p_sample, diffusion.py:325-431, 646-694, 510-554)               */
+int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise, void* stream);
+/* Whole DDIM loop: steps[n-1], ..., steps[0] applied in that order (ddim_sample_loop_progressive :794-810). */
+int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,16 @@
+"""tortoise_tts_amd: MI355X-native (gfx950) inference hot path of e-c-k-e-r/tortoise-tts -- the UnifiedVoice KV-cached
+mel-token decode and the DiffusionTTS DDIM mel decoder -- as hand-written HIP kernels behind a C ABI (include/ttk.h),
+exposed under the reference's own method names.  See DESIGN.md and INTEGRATION.md."""
+from .weights import ARConfig, DiffusionConfig  # noqa: F401
+
+__all__ = ["ARConfig", "DiffusionConfig", "UnifiedVoice", "DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel"]
+
+
+def __getattr__(name):   # lazy: importing the package must not need the built library (CPU-side tools, oracle, weights)
+	if name == "UnifiedVoice":
+		from .autoregressive import UnifiedVoice
+		return UnifiedVoice
+	if name in ("DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel", "SpacedDiffusion"):
+		from . import diffusion
+		return getattr(diffusion, name)
+	raise AttributeError(name)

@@ -1,0 +1,278 @@
+"""Drop-in for the reference's autoregressive module object: same method names, arguments and return values as
+`UnifiedVoice` (/root/reference/tortoise_tts/models/unified_voice.py:334-679) for the calls `TTS.inference` makes
+(tortoise_tts/inference.py:266-285, 334-346, 371-379), backed by libttk (HIP, gfx950).  No torch fallback exists:
+every forward goes through the C ABI or raises.
+
+What runs where
+  * GPT-2 stack, embeddings, final norms, mel head, KV cache ........ libttk  (csrc/ar.hip and kernels)
+  * logit warpers + torch.multinomial + the stop/pad bookkeeping ..... torch ops on the same stream (sampling.py):
+    the generator stream is part of the reference's observable behaviour (seed 0 on every call).
+  * the per-token loop .............................................. here; one HIP-graph replay per token when the
+    logits pipeline needs no token history (the default), eager launches otherwise.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, Iterator, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .sampling import LogitsPipeline, setup_seed
+from .weights import ARConfig, ar_shapes
+
+
+class UnifiedVoice:
+	def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: ARConfig = ARConfig(), dtype: str = "bf16",
+				 device: str = "cuda:0", max_batch: int = 16, max_ctx: Optional[int] = None, use_graph: bool = True):
+		self.cfg = cfg
+		self.device = torch.device(device)
+		if self.device.type != "cuda":
+			raise _lib.TTKError("tortoise_tts_amd runs on an MI355X only (device must be cuda:N)")
+		self.lib = _lib.load()
+		self.dtype = _lib.DTYPES[dtype]
+		self.max_batch = max_batch
+		self.max_ctx = max_ctx or (cfg.max_text_seq_len + 2 + cfg.max_mel_seq_len)
+		self.use_graph = use_graph
+		# attributes TTS.inference reads (inference.py:354,368)
+		self.stop_mel_token, self.start_mel_token = cfg.stop_mel_token, cfg.start_mel_token
+		self.mel_length_compression = cfg.mel_length_compression
+		self.max_mel_tokens, self.max_text_tokens = cfg.max_mel_tokens, cfg.max_text_tokens
+		self.model_dim, self.layers, self.heads = cfg.model_dim, cfg.layers, cfg.heads
+		self.number_mel_codes = cfg.number_mel_codes
+
+		names = list(ar_shapes(cfg).keys())
+		missing = [n for n in names if n not in state_dict]
+		if missing:
+			raise _lib.TTKError(f"state_dict lacks {len(missing)} hot-path tensors, e.g. {missing[:3]}")
+		views, keep = _lib.weight_views(state_dict, names)
+		c = _lib.ARConfigC(cfg.layers, cfg.model_dim, cfg.heads, cfg.max_mel_seq_len, cfg.max_text_seq_len,
+						   cfg.number_text_tokens + 1, cfg.number_mel_codes, cfg.start_text_token, cfg.stop_text_token,
+						   cfg.start_mel_token, cfg.stop_mel_token, self.dtype, max_batch, self.max_ctx)
+		self._h = _lib.C.c_void_p()
+		with torch.cuda.device(self.device):
+			_lib.check(self.lib.ttk_ar_create(_lib.C.byref(self._h), _lib.C.byref(c), views, len(names)), "ttk_ar_create")
+		del keep
+		self._graph = None
+		self._graph_key = None
+		self._prefix = None
+
+	def __del__(self):
+		h = getattr(self, "_h", None)
+		if h:
+			self.lib.ttk_ar_destroy(h)
+			self._h = None
+
+	def parameters(self):
+		yield torch.empty(0, device=self.device)
+
+	def to(self, *a, **k):
+		return self
+
+	def eval(self):
+		return self
+
+	# ------------------------------------------------------------------ C-ABI calls
+	def _prefill(self, cond: torch.Tensor, text: torch.Tensor, B: int) -> torch.Tensor:
+		cond = cond.to(self.device, torch.float32).contiguous()
+		text = text.to(self.device, torch.int64).contiguous().view(-1)
+		_lib.require_cuda(cond, text)
+		logits = torch.empty((B, self.cfg.number_mel_codes), device=self.device, dtype=torch.float32)
+		_lib.check(self.lib.ttk_ar_prefill(self._h, cond.data_ptr(), cond.shape[0], text.data_ptr(), text.numel(), B,
+										   logits.data_ptr(), _lib.stream_ptr()), "ttk_ar_prefill")
+		return logits
+
+	def _decode(self, tok: torch.Tensor, logits: torch.Tensor, hidden: Optional[torch.Tensor] = None):
+		_lib.check(self.lib.ttk_ar_decode(self._h, tok.data_ptr(), logits.data_ptr(), _lib.ptr(hidden), _lib.stream_ptr()),
+				   "ttk_ar_decode")
+
+	# ------------------------------------------------------------------ reference surface
+	def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths, types=None,
+				text_first=True, raw_mels=None, return_attentions=False, return_latent=False, clip_inputs=True):
+		"""unified_voice.py:544-599 in the one mode inference uses: return_latent=True, clip_inputs=False
+		(inference.py:371-379).  Returns f32 [B, M, model_dim]."""
+		if not return_latent or clip_inputs or types is not None or raw_mels is not None or not text_first or return_attentions:
+			raise NotImplementedError("only forward(..., return_latent=True, clip_inputs=False) is on the inference hot path")
+		B, M = mel_codes.shape
+		cond = speech_conditioning_latent.to(self.device, torch.float32)
+		if cond.shape[0] != B:
+			cond = cond.expand(B, -1)
+		cond = cond.contiguous()
+		text = text_inputs.to(self.device, torch.int64)
+		if text.shape[0] != B:
+			text = text.expand(B, -1)
+		text = text.contiguous()
+		codes = mel_codes.to(self.device, torch.int64).contiguous()
+		# set_mel_padding (:494-506) rewrites codes past wav_lengths // compression + 1 with the stop token
+		mel_lengths = torch.div(torch.as_tensor(wav_lengths).view(-1).to("cpu"), self.mel_length_compression, rounding_mode="trunc")
+		if mel_lengths.numel() not in (1, B):
+			raise ValueError("wav_lengths must have 1 or B entries")
+		if int(mel_lengths.min()) + 1 < M:
+			codes = codes.clone()
+			for b in range(B):
+				end = int(mel_lengths[b if mel_lengths.numel() == B else 0]) + 1
+				if end < M:
+					codes[b, end:] = self.stop_mel_token
+		out = torch.empty((B, M, self.cfg.model_dim), device=self.device, dtype=torch.float32)
+		_lib.check(self.lib.ttk_ar_latents(self._h, cond.data_ptr(), text.data_ptr(), text.shape[1], codes.data_ptr(), M, B,
+										   out.data_ptr(), _lib.stream_ptr()), "ttk_ar_latents")
+		return out
+
+	__call__ = forward
+
+	def inference_speech(self, speech_conditioning_latent, text_inputs, input_tokens=None, num_return_sequences=1,
+						 max_generate_length=None, typical_sampling=False, typical_mass=.9, kv_cache=True, **hf_generate_kwargs):
+		"""unified_voice.py:632-668 + the sample branch of `generate` (stream_generator.py:213-639, HF `_sample`).
+		Returns int64 [B, L <= max_generate_length], rows padded with stop_mel_token after their EOS."""
+		if input_tokens is not None:
+			raise NotImplementedError("input_tokens (prompted continuation) is not on the inference hot path")
+		if text_inputs.shape[0] != 1:
+			raise NotImplementedError("one text line per call, as inference.py:244-246 does")
+		if hf_generate_kwargs.get("num_beams", 1) not in (None, 1) or not hf_generate_kwargs.get("do_sample", True):
+			raise NotImplementedError("only the sampling branch (do_sample=True, num_beams=1) is implemented")
+		gen, _ = self._generate(speech_conditioning_latent, text_inputs, num_return_sequences, max_generate_length,
+								typical_mass if typical_sampling else None, hf_generate_kwargs, stream=False)
+		return gen
+
+	def compute_embeddings(self, cond_latents, text_inputs, kv_cache=True):
+		"""unified_voice.py:614-630: remembers the prefix, returns the fake id row [b, P+1]."""
+		self._prefix = (cond_latents, text_inputs)
+		P1 = text_inputs.shape[1] + 4
+		ids = torch.ones((cond_latents.shape[0], P1), dtype=torch.long, device=self.device)
+		ids[:, -1] = self.start_mel_token
+		return ids
+
+	def get_generator(self, inputs, max_length=500, **hf_generate_kwargs) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+		"""unified_voice.py:670-679 / stream_generator.py:911-1190: yields (codes [B], latent [B, model_dim]) per token,
+		latent = final_norm(last hidden) (:1172)."""
+		if self._prefix is None:
+			raise _lib.TTKError("call compute_embeddings first")
+		cond, text = self._prefix
+		n_new = max_length - inputs.shape[1]
+		B = hf_generate_kwargs.pop("num_return_sequences", 1) or 1
+		return self._generate(cond, text, B, n_new, None, hf_generate_kwargs, stream=True)
+
+	# ------------------------------------------------------------------ the token loop
+	def _generate(self, cond, text, num_return_sequences, max_generate_length, typical_mass, kw, stream):
+		c = self.cfg
+		B = num_return_sequences * text.shape[0]
+		if B > self.max_batch:
+			raise _lib.TTKError(f"{B} candidates exceed max_batch={self.max_batch}")
+		Tt = text.shape[1]
+		trunc_index = Tt + 4
+		max_new = (c.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+		if trunc_index + max_new > self.max_ctx or max_new + 2 > c.max_mel_seq_len:
+			raise _lib.TTKError(f"prefix {trunc_index} + {max_new} new tokens exceed max_ctx={self.max_ctx} "
+								f"or the mel position table ({c.max_mel_seq_len})")
+		suppress = tuple(kw.get("suppress_tokens") or ())
+		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 0), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0),
+					suppress, typical_mass)
+		if stream:
+			pipe = LogitsPipeline(temperature=pipe_key[0], top_k=pipe_key[1], top_p=pipe_key[2], repetition_penalty=pipe_key[3],
+								  suppress_tokens=suppress, typical_mass=typical_mass, vocab=c.number_mel_codes, device=self.device)
+			return self._loop_stream(cond, text, B, max_new, pipe)
+		can_stop = c.stop_mel_token not in suppress
+		with torch.cuda.device(self.device):
+			st = self._gen_state(B, max_new, trunc_index, pipe_key)
+			setup_seed(kw.get("seed", 0))
+			st.reset(c)
+			st.logits.copy_(self._prefill(cond, text, B))
+			n = 0
+			if not (self.use_graph and not st.pipe.needs_history):
+				while True:
+					st.sample(n)
+					n += 1
+					if n >= max_new or (can_stop and int(st.unfinished.max()) == 0):
+						break
+					self._decode(st.tok, st.logits)
+			else:
+				# tokens 1 and 2 eagerly (the second pass also warms every kernel before a capture), then one HIP-graph
+				# replay per token: {ttk_ar_decode; warp; multinomial; bookkeeping}.  Every position-dependent quantity
+				# (cache length, mel position, output column) lives in device memory, so one graph serves all tokens.
+				st.sample(0)
+				n = 1
+				while n < max_new and not (can_stop and int(st.unfinished.max()) == 0):
+					if st.graph is None:
+						self._decode(st.tok, st.logits)
+						st.sample(n)
+						n += 1
+						if n < max_new:
+							torch.cuda.synchronize(self.device)
+							g = torch.cuda.CUDAGraph()
+							with torch.cuda.graph(g):
+								self._decode(st.tok, st.logits)
+								st.sample(0)
+							st.graph = g
+						continue
+					st.graph.replay()
+					n += 1
+			return st.ids[:, :n].clone(), None
+
+	def _gen_state(self, B, max_new, trunc_index, pipe_key):
+		key = (B, max_new, trunc_index, pipe_key)
+		if self._graph_key != key:
+			self._graph = _GenState(self, B, max_new, trunc_index, pipe_key)
+			self._graph_key = key
+		return self._graph
+
+	def _loop_stream(self, cond, text, B, max_new, pipe):
+		c = self.cfg
+		with torch.cuda.device(self.device):
+			setup_seed(0)
+			logits = self._prefill(cond, text, B)
+			hidden = torch.empty((B, c.model_dim), device=self.device, dtype=torch.float32)
+			unfinished = torch.ones(B, dtype=torch.long, device=self.device)
+			hist = torch.ones((B, text.shape[1] + 4), dtype=torch.long, device=self.device)
+			hist[:, -1] = c.start_mel_token
+			for n in range(max_new):
+				scores = pipe(hist if pipe.needs_history else None, logits)
+				nxt = torch.multinomial(torch.nn.functional.softmax(scores, dim=-1), num_samples=1).squeeze(1)
+				nxt = nxt * unfinished + c.stop_mel_token * (1 - unfinished)
+				unfinished = unfinished * (nxt != c.stop_mel_token).long()
+				if pipe.needs_history:
+					hist = torch.cat([hist, nxt[:, None]], dim=-1)
+				if n + 1 >= max_new or int(unfinished.max()) == 0:
+					# the reference yields (tokens, final_norm(hidden of the row that produced them)); the last row needs no decode
+					return
+				self._decode(nxt, logits, hidden)
+				yield nxt, hidden.clone()
+
+
+class _GenState:
+	"""Persistent device buffers of one generation shape, so a captured token step can be replayed across calls."""
+
+	def __init__(self, model: UnifiedVoice, B, max_new, trunc_index, pipe_key):
+		c, dev = model.cfg, model.device
+		self.B, self.max_new, self.trunc_index = B, max_new, trunc_index
+		self.pipe = LogitsPipeline(temperature=pipe_key[0], top_k=pipe_key[1], top_p=pipe_key[2], repetition_penalty=pipe_key[3],
+								   suppress_tokens=pipe_key[4], typical_mass=pipe_key[5], vocab=c.number_mel_codes, device=dev)
+		self.stop = c.stop_mel_token
+		self.logits = torch.empty((B, c.number_mel_codes), device=dev, dtype=torch.float32)
+		self.ids = torch.empty((B, max_new), dtype=torch.long, device=dev)
+		self.tok = torch.empty(B, dtype=torch.long, device=dev)
+		self.unfinished = torch.ones(B, dtype=torch.long, device=dev)
+		self.col = torch.zeros(1, dtype=torch.long, device=dev)
+		self.history = torch.ones((B, trunc_index + max_new), dtype=torch.long, device=dev) if self.pipe.needs_history else None
+		self.graph = None
+
+	def reset(self, c):
+		self.ids.fill_(self.stop)
+		self.unfinished.fill_(1)
+		self.col.zero_()
+		if self.history is not None:
+			self.history.fill_(1)
+			self.history[:, self.trunc_index - 1] = c.start_mel_token
+
+	def sample(self, n):
+		"""one token from self.logits: warp, sample, pad finished rows, record      (HF:generation/utils.py:2894-2937)"""
+		hist = None if self.history is None else self.history[:, :self.trunc_index + n]
+		scores = self.pipe(hist, self.logits)
+		probs = torch.nn.functional.softmax(scores, dim=-1)
+		nxt = torch.multinomial(probs, num_samples=1).squeeze(1)
+		nxt = nxt * self.unfinished + self.stop * (1 - self.unfinished)
+		self.tok.copy_(nxt)
+		self.ids.index_copy_(1, self.col, nxt[:, None])
+		self.col.add_(1)
+		self.unfinished.mul_((nxt != self.stop).long())
+		if self.history is not None:
+			self.history[:, self.trunc_index + n] = nxt

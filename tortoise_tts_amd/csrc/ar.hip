@@ -1,0 +1,302 @@
+// ttk_ar: the autoregressive half of the hot path -- UnifiedVoice's GPT-2 stack behind the C ABI of include/ttk.h.
+//   prefill / latent pass : token-major dense pipeline (LayerNorm -> MFMA GEMM -> causal flash attention ...)
+//   decode step           : 5 fused weight-streaming launches per layer + head, all position-dependent state read
+//                           from a device scalar so the step is HIP-graph capturable
+// Reference: /root/reference/tortoise_tts/models/unified_voice.py:98-254 (GPT2InferenceModel), :334-668 (UnifiedVoice),
+//            HF:models/gpt2/modeling_gpt2.py:144-310,514-634 (GPT-2 block math).
+#include "ttk_common.h"
+#include "ttk_host.h"
+
+using namespace ttk;
+
+namespace {
+
+struct ARLayer {
+	float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+	Mat attn, proj, fc, proj2;
+};
+
+// rows of the prefill input: [cond | start_text, text.., stop_text | start_mel]      (unified_voice.py:639-649, :203-211)
+__global__ void k_build_prefill_emb(const float* cond, int Bc, const int64_t* text, int Tt, int B, int d,
+									const float* text_emb, const float* text_pos, const float* mel_emb, const float* mel_pos,
+									int start_text, int stop_text, int start_mel, float* out) {
+	const int S = Tt + 4;
+	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int d4 = d / 4;
+	if (idx >= (int64_t)B * S * d4) return;
+	const int c = (int)(idx % d4) * 4;
+	const int64_t row = idx / d4;
+	const int b = (int)(row / S), s = (int)(row - (int64_t)b * S);
+	float4 v;
+	if (s == 0) {
+		v = *(const float4*)(cond + (int64_t)(Bc == 1 ? 0 : b) * d + c);
+	} else if (s == S - 1) {
+		const float4 e = *(const float4*)(mel_emb + (int64_t)start_mel * d + c), w = *(const float4*)(mel_pos + c);
+		v = make_float4(e.x + w.x, e.y + w.y, e.z + w.z, e.w + w.w);
+	} else {
+		const int j = s - 1;   // position in [start, text.., stop]
+		const int64_t tok = j == 0 ? start_text : (j == Tt + 1 ? stop_text : text[j - 1]);
+		const float4 e = *(const float4*)(text_emb + tok * d + c), w = *(const float4*)(text_pos + (int64_t)j * d + c);
+		v = make_float4(e.x + w.x, e.y + w.y, e.z + w.z, e.w + w.w);
+	}
+	*(float4*)(out + row * d + c) = v;
+}
+
+// rows of the latent pass: [cond | start_text, text.., stop_text | start_mel, codes.., stop_mel]   (unified_voice.py:576-593)
+__global__ void k_build_latent_emb(const float* cond, const int64_t* text, int Tt, const int64_t* codes, int M, int B, int d,
+								   const float* text_emb, const float* text_pos, const float* mel_emb, const float* mel_pos,
+								   int start_text, int stop_text, int start_mel, int stop_mel, float* out) {
+	const int S = Tt + M + 5;
+	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int d4 = d / 4;
+	if (idx >= (int64_t)B * S * d4) return;
+	const int c = (int)(idx % d4) * 4;
+	const int64_t row = idx / d4;
+	const int b = (int)(row / S), s = (int)(row - (int64_t)b * S);
+	float4 v;
+	if (s == 0) {
+		v = *(const float4*)(cond + (int64_t)b * d + c);
+	} else if (s < Tt + 3) {
+		const int j = s - 1;
+		const int64_t tok = j == 0 ? start_text : (j == Tt + 1 ? stop_text : text[(int64_t)b * Tt + j - 1]);
+		const float4 e = *(const float4*)(text_emb + tok * d + c), w = *(const float4*)(text_pos + (int64_t)j * d + c);
+		v = make_float4(e.x + w.x, e.y + w.y, e.z + w.z, e.w + w.w);
+	} else {
+		const int j = s - (Tt + 3);   // position in [start, codes.., stop]
+		const int64_t tok = j == 0 ? start_mel : (j == M + 1 ? stop_mel : codes[(int64_t)b * M + j - 1]);
+		const float4 e = *(const float4*)(mel_emb + tok * d + c), w = *(const float4*)(mel_pos + (int64_t)j * d + c);
+		v = make_float4(e.x + w.x, e.y + w.y, e.z + w.z, e.w + w.w);
+	}
+	*(float4*)(out + row * d + c) = v;
+}
+
+}  // namespace
+
+struct ttk_ar {
+	ttk_ar_config cfg;
+	int dt;
+	size_t es;
+	Arena arena;
+	std::vector<ARLayer> L;
+	float *lnf_g, *lnf_b, *fn_g, *fn_b;
+	Mat head;
+	float *text_emb, *mel_emb, *mel_pos, *text_pos;
+	void *kc, *vc;          // [layers][max_batch][H][max_ctx][64]
+	size_t kv_layer_stride; // elements
+	int* d_pos;             // device scalar: number of valid cache rows
+	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
+	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
+	WsBuf ws_x, ws_a, ws_qkv, ws_ao, ws_h;
+	int B = 0, P = 0, k = 0, ready = 0;
+};
+
+static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipStream_t s) {
+	const int d = h->cfg.model_dim, H = h->cfg.heads, dt = h->dt;
+	const int rows = B * S;
+	TTK_TRY(h->ws_a.reserve((size_t)rows * d * h->es));
+	TTK_TRY(h->ws_qkv.reserve((size_t)rows * 3 * d * h->es));
+	TTK_TRY(h->ws_ao.reserve((size_t)rows * d * h->es));
+	TTK_TRY(h->ws_h.reserve((size_t)rows * 4 * d * h->es));
+	for (int l = 0; l < h->cfg.layers; ++l) {
+		const ARLayer& L = h->L[l];
+		launch_layernorm(dt, x, d, rows, d, L.ln1_g, L.ln1_b, nullptr, nullptr, h->ws_a.p, d, 0, s);
+		GemmParams g = {};
+		g.nseg = 1; g.seg[0] = {h->ws_a.p, d, 0, 0};
+		g.W = L.attn.w; g.ldw = L.attn.Kpad; g.M = rows; g.N = 3 * d; g.K = d; g.bias = L.attn.bias;
+		g.C = h->ws_qkv.p; g.ldc = 3 * d;
+		launch_gemm(dt, g, s);
+		if (write_kv) {
+			char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * h->es;
+			char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * h->es;
+			launch_kv_scatter(dt, h->ws_qkv.p, B, S, H, kc, vc, h->cfg.max_ctx, s);
+		}
+		AttnParams a = {};
+		a.qkv = h->ws_qkv.p; a.ld = 3 * d; a.q_off = 0; a.k_off = d; a.v_off = 2 * d; a.head_stride = 64;
+		a.out = h->ws_ao.p; a.ldo = d; a.nb = B; a.T = S; a.H = H; a.causal = 1; a.bias = nullptr; a.scale = 0.125f;
+		launch_attn_fwd(dt, a, s);
+		g = {};
+		g.nseg = 1; g.seg[0] = {h->ws_ao.p, d, 0, 0};
+		g.W = L.proj.w; g.ldw = L.proj.Kpad; g.M = rows; g.N = d; g.K = d; g.bias = L.proj.bias;
+		g.residual = x; g.ldr = d; g.C = x; g.ldc = d; g.out_f32 = 1;
+		launch_gemm(dt, g, s);
+		launch_layernorm(dt, x, d, rows, d, L.ln2_g, L.ln2_b, nullptr, nullptr, h->ws_a.p, d, 0, s);
+		g = {};
+		g.nseg = 1; g.seg[0] = {h->ws_a.p, d, 0, 0};
+		g.W = L.fc.w; g.ldw = L.fc.Kpad; g.M = rows; g.N = 4 * d; g.K = d; g.bias = L.fc.bias; g.act = ACT_GELU_NEW;
+		g.C = h->ws_h.p; g.ldc = 4 * d;
+		launch_gemm(dt, g, s);
+		g = {};
+		g.nseg = 1; g.seg[0] = {h->ws_h.p, 4 * d, 0, 0};
+		g.W = L.proj2.w; g.ldw = L.proj2.Kpad; g.M = rows; g.N = d; g.K = 4 * d; g.bias = L.proj2.bias;
+		g.residual = x; g.ldr = d; g.C = x; g.ldc = d; g.out_f32 = 1;
+		launch_gemm(dt, g, s);
+	}
+	return TTK_OK;
+}
+
+// ln_f + final_norm + mel_head on the decode rows h->x [B][d]
+static void head_launch(ttk_ar* h, int B, float* logits, float* hidden_out, hipStream_t s) {
+	SkinnyParams p = {};
+	p.Wp = h->head.wfrag; p.N = h->cfg.number_mel_codes; p.K = h->cfg.model_dim; p.M = B; p.bias = h->head.bias;
+	p.ln_count = 2; p.x = h->x; p.ldx = h->cfg.model_dim;
+	p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hidden_out;
+	p.mode = SK_STORE_F32; p.out_f32 = logits; p.ldc = h->cfg.number_mel_codes;
+	launch_skinny(h->dt, p, 4, s);
+}
+
+extern "C" {
+
+int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view* w, int n_w) {
+	TTK_REQUIRE(out && cfg && w, TTK_E_ARG, "ttk_ar_create: null argument");
+	TTK_REQUIRE(cfg->model_dim % 64 == 0 && cfg->heads * 64 == cfg->model_dim, TTK_E_ARG,
+				"ttk_ar_create: head_dim must be 64 (model_dim %d, heads %d)", cfg->model_dim, cfg->heads);
+	TTK_REQUIRE(cfg->model_dim <= 2048, TTK_E_ARG, "ttk_ar_create: model_dim %d > 2048 unsupported", cfg->model_dim);
+	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16, TTK_E_ARG, "ttk_ar_create: bad dtype %d", cfg->dtype);
+	TTK_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= (cfg->dtype == TTK_F32 ? 32 : 64), TTK_E_ARG,
+				"ttk_ar_create: max_batch %d out of range", cfg->max_batch);
+	TTK_REQUIRE(cfg->max_ctx >= 8, TTK_E_ARG, "ttk_ar_create: max_ctx %d too small", cfg->max_ctx);
+	ttk_ar* h = new ttk_ar();
+	h->cfg = *cfg;
+	h->dt = cfg->dtype;
+	h->es = dtype_size(h->dt);
+	WeightMap wm(w, n_w);
+	const int d = cfg->model_dim;
+	int rc = TTK_OK;
+	auto fail = [&](int code) { h->arena.release(); delete h; return code; };
+#define AR_TRY(expr) do { rc = (expr); if (rc != TTK_OK) return fail(rc); } while (0)
+	h->L.resize(cfg->layers);
+	for (int l = 0; l < cfg->layers; ++l) {
+		const std::string p = "gpt.h." + std::to_string(l) + ".";
+		ARLayer& L = h->L[l];
+		AR_TRY(upload_f32(h->arena, wm, p + "ln_1.weight", d, &L.ln1_g));
+		AR_TRY(upload_f32(h->arena, wm, p + "ln_1.bias", d, &L.ln1_b));
+		AR_TRY(upload_f32(h->arena, wm, p + "ln_2.weight", d, &L.ln2_g));
+		AR_TRY(upload_f32(h->arena, wm, p + "ln_2.bias", d, &L.ln2_b));
+		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "attn.c_attn.weight", p + "attn.c_attn.bias", PK_KN, 3 * d, d, true, &L.attn));
+		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "attn.c_proj.weight", p + "attn.c_proj.bias", PK_KN, d, d, true, &L.proj));
+		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", PK_KN, 4 * d, d, true, &L.fc));
+		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", PK_KN, d, 4 * d, true, &L.proj2));
+	}
+	AR_TRY(upload_f32(h->arena, wm, "gpt.ln_f.weight", d, &h->lnf_g));
+	AR_TRY(upload_f32(h->arena, wm, "gpt.ln_f.bias", d, &h->lnf_b));
+	AR_TRY(upload_f32(h->arena, wm, "final_norm.weight", d, &h->fn_g));
+	AR_TRY(upload_f32(h->arena, wm, "final_norm.bias", d, &h->fn_b));
+	AR_TRY(upload_mat(h->arena, wm, h->dt, "mel_head.weight", "mel_head.bias", PK_NK, cfg->number_mel_codes, d, true, &h->head));
+	AR_TRY(upload_f32(h->arena, wm, "text_embedding.weight", (int64_t)cfg->number_text_tokens_p1 * d, &h->text_emb));
+	AR_TRY(upload_f32(h->arena, wm, "mel_embedding.weight", (int64_t)cfg->number_mel_codes * d, &h->mel_emb));
+	AR_TRY(upload_f32(h->arena, wm, "mel_pos_embedding.emb.weight", (int64_t)cfg->max_mel_seq_len * d, &h->mel_pos));
+	AR_TRY(upload_f32(h->arena, wm, "text_pos_embedding.emb.weight", (int64_t)cfg->max_text_seq_len * d, &h->text_pos));
+	h->kv_layer_stride = (size_t)cfg->max_batch * cfg->heads * cfg->max_ctx * 64;
+	AR_TRY(h->arena.alloc(&h->kc, h->kv_layer_stride * cfg->layers * h->es));
+	AR_TRY(h->arena.alloc(&h->vc, h->kv_layer_stride * cfg->layers * h->es));
+	AR_TRY(h->arena.alloc((void**)&h->d_pos, 16));
+	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
+	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
+	AR_TRY(h->arena.alloc(&h->attn_out, (size_t)cfg->max_batch * d * h->es));
+	AR_TRY(h->arena.alloc(&h->hbuf, (size_t)cfg->max_batch * 4 * d * h->es));
+#undef AR_TRY
+	hipError_t e = hipDeviceSynchronize();
+	if (e != hipSuccess) { set_error("ttk_ar_create: %s", hipGetErrorString(e)); return fail(TTK_E_HIP); }
+	*out = h;
+	return TTK_OK;
+}
+
+int ttk_ar_destroy(ttk_ar* h) {
+	if (!h) return TTK_OK;
+	(void)hipDeviceSynchronize();
+	h->ws_x.release(); h->ws_a.release(); h->ws_qkv.release(); h->ws_ao.release(); h->ws_h.release();
+	h->arena.release();
+	delete h;
+	return TTK_OK;
+}
+
+int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, int B, float* logits_out, void* stream) {
+	TTK_REQUIRE(h && cond_latent && text && logits_out, TTK_E_ARG, "ttk_ar_prefill: null argument");
+	const ttk_ar_config& c = h->cfg;
+	TTK_REQUIRE(B >= 1 && B <= c.max_batch, TTK_E_ARG, "ttk_ar_prefill: B=%d exceeds max_batch=%d", B, c.max_batch);
+	TTK_REQUIRE(Bc == 1 || Bc == B, TTK_E_ARG, "ttk_ar_prefill: cond batch %d must be 1 or B=%d", Bc, B);
+	TTK_REQUIRE(Tt >= 1 && Tt + 2 <= c.max_text_seq_len, TTK_E_ARG, "ttk_ar_prefill: %d text tokens exceed the position table (%d)", Tt, c.max_text_seq_len - 2);
+	const int S = Tt + 4, d = c.model_dim;
+	TTK_REQUIRE(S + 1 <= c.max_ctx, TTK_E_ARG, "ttk_ar_prefill: prefix of %d rows does not fit max_ctx=%d", S, c.max_ctx);
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(h->ws_x.reserve((size_t)B * S * d * sizeof(float)));
+	float* x = (float*)h->ws_x.p;
+	const int64_t total = (int64_t)B * S * (d / 4);
+	hipLaunchKernelGGL(k_build_prefill_emb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cond_latent, Bc, text, Tt, B, d,
+					   h->text_emb, h->text_pos, h->mel_emb, h->mel_pos, c.start_text_token, c.stop_text_token, c.start_mel_token, x);
+	TTK_TRY(dense_forward(h, x, B, S, true, s));
+	launch_copy_rows(x + (size_t)(S - 1) * d, (int64_t)S * d, h->x, d, B, d, s);
+	head_launch(h, B, logits_out, nullptr, s);
+	launch_set_int(h->d_pos, S, s);
+	h->B = B; h->P = Tt + 3; h->k = 0; h->ready = 1;
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidden_out, void* stream) {
+	TTK_REQUIRE(h && tok && logits_out, TTK_E_ARG, "ttk_ar_decode: null argument");
+	TTK_REQUIRE(h->ready, TTK_E_STATE, "ttk_ar_decode: call ttk_ar_prefill first");
+	const ttk_ar_config& c = h->cfg;
+	const int B = h->B, d = c.model_dim, H = c.heads, dt = h->dt;
+	TTK_REQUIRE(h->P + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "ttk_ar_decode: KV cache full (max_ctx=%d)", c.max_ctx);
+	TTK_REQUIRE(h->k + 2 < c.max_mel_seq_len, TTK_E_STATE, "ttk_ar_decode: mel position table exhausted (%d rows)", c.max_mel_seq_len);
+	hipStream_t s = (hipStream_t)stream;
+	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)
+	launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s);
+	const int wv_small = d >= 1024 ? 4 : 4;
+	for (int l = 0; l < c.layers; ++l) {
+		const ARLayer& L = h->L[l];
+		char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * h->es;
+		char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * h->es;
+		SkinnyParams p = {};
+		p.Wp = L.attn.wfrag; p.N = 3 * d; p.K = d; p.M = B; p.bias = L.attn.bias;
+		p.ln_count = 1; p.x = h->x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b;
+		p.mode = SK_QKV; p.qbuf = h->qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
+		launch_skinny(dt, p, wv_small, s);
+		AttnDecodeParams a = {};
+		a.qbuf = h->qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = B; a.H = H; a.max_ctx = c.max_ctx; a.out = h->attn_out;
+		launch_attn_decode(dt, a, s);
+		p = {};
+		p.Wp = L.proj.wfrag; p.N = d; p.K = d; p.M = B; p.bias = L.proj.bias; p.a = h->attn_out; p.lda = d;
+		p.mode = SK_RESIDUAL; p.out_f32 = h->x; p.ldc = d;
+		launch_skinny(dt, p, wv_small, s);
+		p = {};
+		p.Wp = L.fc.wfrag; p.N = 4 * d; p.K = d; p.M = B; p.bias = L.fc.bias;
+		p.ln_count = 1; p.x = h->x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b;
+		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = h->hbuf;
+		launch_skinny(dt, p, wv_small, s);
+		p = {};
+		p.Wp = L.proj2.wfrag; p.N = d; p.K = 4 * d; p.M = B; p.bias = L.proj2.bias; p.a = h->hbuf; p.lda = 4 * d;
+		p.mode = SK_RESIDUAL; p.out_f32 = h->x; p.ldc = d;
+		launch_skinny(dt, p, d >= 1024 ? 16 : 4, s);
+	}
+	head_launch(h, B, logits_out, hidden_out, s);
+	launch_add_int(h->d_pos, 1, s);
+	h->k += 1;
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+int ttk_ar_latents(ttk_ar* h, const float* cond, const int64_t* text, int Tt, const int64_t* codes, int M, int B, float* latents_out, void* stream) {
+	TTK_REQUIRE(h && cond && text && codes && latents_out, TTK_E_ARG, "ttk_ar_latents: null argument");
+	const ttk_ar_config& c = h->cfg;
+	TTK_REQUIRE(B >= 1 && Tt >= 1 && M >= 1, TTK_E_ARG, "ttk_ar_latents: empty input (B=%d Tt=%d M=%d)", B, Tt, M);
+	TTK_REQUIRE(Tt + 2 <= c.max_text_seq_len, TTK_E_ARG, "ttk_ar_latents: %d text tokens exceed the position table", Tt);
+	TTK_REQUIRE(M + 2 <= c.max_mel_seq_len, TTK_E_ARG, "ttk_ar_latents: %d mel codes exceed the position table (%d)", M, c.max_mel_seq_len - 2);
+	const int S = Tt + M + 5, d = c.model_dim;
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(h->ws_x.reserve((size_t)B * S * d * sizeof(float)));
+	float* x = (float*)h->ws_x.p;
+	const int64_t total = (int64_t)B * S * (d / 4);
+	hipLaunchKernelGGL(k_build_latent_emb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cond, text, Tt, codes, M, B, d,
+					   h->text_emb, h->text_pos, h->mel_emb, h->mel_pos, c.start_text_token, c.stop_text_token, c.start_mel_token, c.stop_mel_token, x);
+	TTK_TRY(dense_forward(h, x, B, S, false, s));
+	// enc = final_norm(ln_f(h)); mel rows start at 1 + (Tt + 2); keep the first M of the M + 2   (unified_voice.py:518-522,595)
+	for (int b = 0; b < B; ++b)
+		launch_layernorm(h->dt, x + ((size_t)b * S + Tt + 3) * d, d, M, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b,
+						 latents_out + (size_t)b * M * d, d, 1, s);
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,349 @@
+// Attention kernels (head_dim 64) for gfx950.
+//
+// k_attn_fwd: tiled flash-style forward on MFMA, never materialising the [T,T] score matrix that the reference
+//   builds (`QKVAttentionLegacy` /root/reference/tortoise_tts/models/arch_utils.py:59-94 einsum + softmax; GPT-2
+//   eager/sdpa attention HF:models/gpt2/modeling_gpt2.py:144-226).  Two uses:
+//     * DiffusionTTS AttentionBlock: non-causal, T5 relative-position bias added before the softmax
+//       (xtransformers.py:148-188; bias depends on clamp(k-q, -64, 64) only, so a 129-entry per-head table).
+//     * GPT-2 prefill / latent pass: causal, no bias.
+//   Formulation: S^T = K Q^T (keys on MFMA rows, queries on lanes) so each lane owns one query column: the online
+//   softmax reduces over registers + 2 cross-lane steps, and P^T in accumulator layout is directly the B operand
+//   of O^T = V^T P^T with a permuted key order that the V^T fragment reads match (ds_read_b64_tr_b16 for bf16).
+//   4 waves x 32 queries per workgroup, 64-key K/V tiles staged through LDS, f32 softmax/accumulators.
+//
+// k_attn_decode: single-query KV-cached attention for the AR decode step (HBM-bound: streams the K/V cache once).
+#include "ttk_common.h"
+#include "ttk_kernels.h"
+
+namespace ttk {
+
+constexpr int HD = 64;
+constexpr float NEG_BIG = -1e30f;
+
+template <typename T> struct VT;   // V^T fragment loader from an LDS tile [64 keys][64 d] with swizzled 16-byte chunks
+template <> struct VT<bf16> {
+	// lane (i = lane & 15, g = lane >> 4): elements j<4: V[kb + 4g + j][d0 + i], j>=4: V[kb + 16 + 4g + (j-4)][d0 + i]
+	static __device__ __forceinline__ bf16x8 load(const char* Vs, int kb, int d0, int lane) {
+		const int i = lane & 15, g = lane >> 4;
+		const int q = i >> 2, p = i & 3;            // this lane supplies row q, columns 4p..4p+3 of the 4x16 block
+		const int col = d0 + 4 * p;
+		const int r0 = kb + 4 * g + q, r1 = r0 + 16;
+		const int ch = col >> 3, sub = (col & 7) * 2;
+		typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+		const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(Vs + r0 * 128 + ((ch ^ (r0 & 7)) << 4) + sub));
+		const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(Vs + r1 * 128 + ((ch ^ (r1 & 7)) << 4) + sub));
+		return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+	}
+};
+template <> struct VT<float> {
+	static __device__ __forceinline__ f32x8 load(const char* Vs, int kb, int d0, int lane) {
+		const int i = lane & 15, g = lane >> 4;
+		const int col = d0 + i;
+		f32x8 r;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int row = kb + 4 * g + (j & 3) + (j >> 2) * 16;
+			r[j] = *(const float*)(Vs + row * 256 + (((col >> 2) ^ (row & 15)) << 4) + (col & 3) * 4);
+		}
+		return r;
+	}
+};
+
+template <typename T, bool CAUSAL, bool BIAS>
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
+	typedef typename Frag<T>::type FragT;
+	constexpr int ES = sizeof(T);
+	constexpr int ROWB = HD * ES;             // LDS row bytes (128 bf16 / 256 f32)
+	constexpr int NCH = ROWB / 16;            // 16-byte chunks per row (8 / 16)
+	constexpr int SWM = NCH - 1;              // swizzle mask on the row index
+	constexpr int FCH = 8 * ES / 16;          // chunks per fragment
+	constexpr int TILE_CH = 64 * NCH;         // chunks per K (or V) tile
+	constexpr int CPT = TILE_CH / 256;        // chunks per thread (2 / 4)
+	__shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
+	__shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
+	__shared__ float bias_s[132];
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int h = blockIdx.y, b = blockIdx.z;
+	const int q0 = blockIdx.x * 128 + wave * 32;      // first query row of this wave
+	const int li = lane & 15, g = lane >> 4;
+	const T* base = (const T*)p.qkv + (int64_t)b * p.T * p.ld;
+	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
+
+	if (BIAS) {
+		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid];
+	}
+
+	// Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32ks + 8g .. +8], scaled
+	FragT qf[2][2];
+#pragma unroll
+	for (int qt = 0; qt < 2; ++qt) {
+		int row = q0 + 16 * qt + li;
+		row = row < p.T ? row : p.T - 1;
+#pragma unroll
+		for (int ks = 0; ks < 2; ++ks) {
+			FragT f = *(const FragT*)(base + (int64_t)row * p.ld + qc + 32 * ks + 8 * g);
+#pragma unroll
+			for (int j = 0; j < 8; ++j) f[j] = cvt<T>((float)f[j] * p.scale);
+			qf[qt][ks] = f;
+		}
+	}
+
+	f32x4 o[2][4];
+	float m_run[2], l_run[2];
+#pragma unroll
+	for (int qt = 0; qt < 2; ++qt) {
+		m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
+#pragma unroll
+		for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+	}
+
+	int nkt = (p.T + 63) / 64;
+	if (CAUSAL) { const int last_q = min(blockIdx.x * 128 + 127, p.T - 1); nkt = min(nkt, last_q / 64 + 1); }
+
+	uint4 rk[CPT], rv[CPT];
+	auto load_kv = [&](int kt) {
+#pragma unroll
+		for (int i = 0; i < CPT; ++i) {
+			const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
+			int key = kt * 64 + row;
+			key = key < p.T ? key : p.T - 1;
+			const T* src = base + (int64_t)key * p.ld + c * (16 / ES);
+			rk[i] = *(const uint4*)(src + kc);
+			rv[i] = *(const uint4*)(src + vc);
+		}
+	};
+	auto store_kv = [&]() {
+#pragma unroll
+		for (int i = 0; i < CPT; ++i) {
+			const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
+			const int off = row * ROWB + ((c ^ (row & SWM)) << 4);
+			*(uint4*)(Ks + off) = rk[i];
+			*(uint4*)(Vs + off) = rv[i];
+		}
+	};
+
+	load_kv(0);
+	for (int kt = 0; kt < nkt; ++kt) {
+		__syncthreads();            // previous tile's readers are done
+		store_kv();
+		__syncthreads();
+		if (kt + 1 < nkt) load_kv(kt + 1);
+
+		const int k0 = kt * 64;
+		const bool wave_active = !CAUSAL || k0 <= q0 + 31;
+		if (wave_active) {
+			// ---- S^T tile: 4 key sub-tiles x 2 query tiles
+			f32x4 s[2][4];
+#pragma unroll
+			for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) s[qt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt) {
+					union { FragT v; uint4 q[FCH]; } kf;
+					const int row = 16 * nt + li;
+					const int c0 = (32 * ks + 8 * g) * ES / 16;
+#pragma unroll
+					for (int f = 0; f < FCH; ++f) kf.q[f] = *(const uint4*)(Ks + row * ROWB + (((c0 + f) ^ (row & SWM)) << 4));
+#pragma unroll
+					for (int qt = 0; qt < 2; ++qt) s[qt][nt] = mma16<T>(kf.v, qf[qt][ks], s[qt][nt]);
+				}
+			}
+			// ---- bias, masks, online softmax (lane owns query column li of each q tile; keys 16nt + 4g + r)
+#pragma unroll
+			for (int qt = 0; qt < 2; ++qt) {
+				const int qi = q0 + 16 * qt + li;
+				float tmax = NEG_BIG;
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const int key = k0 + 16 * nt + 4 * g + r;
+						float v = s[qt][nt][r];
+						if (BIAS) { int rel = key - qi; rel = rel < -64 ? -64 : (rel > 64 ? 64 : rel); v += bias_s[rel + 64]; }
+						if (key >= p.T || (CAUSAL && key > qi)) v = NEG_BIG;
+						s[qt][nt][r] = v;
+						tmax = fmaxf(tmax, v);
+					}
+				tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+				tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+				const float m_new = fmaxf(m_run[qt], tmax);
+				const float alpha = __expf(m_run[qt] - m_new);
+				m_run[qt] = m_new;
+				float psum = 0.f;
+#pragma unroll
+				for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const float pv = __expf(s[qt][nt][r] - m_new);
+						s[qt][nt][r] = pv;
+						psum += pv;
+					}
+				l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+				for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+			}
+			// ---- O^T += V^T P^T
+#pragma unroll
+			for (int sidx = 0; sidx < 2; ++sidx) {
+				FragT pf[2];
+#pragma unroll
+				for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+					for (int j = 0; j < 8; ++j) pf[qt][j] = cvt<T>(s[qt][2 * sidx + (j >> 2)][j & 3]);
+#pragma unroll
+				for (int dt = 0; dt < 4; ++dt) {
+					const FragT vf = VT<T>::load(Vs, 32 * sidx, 16 * dt, lane);
+#pragma unroll
+					for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mma16<T>(vf, pf[qt], o[qt][dt]);
+				}
+			}
+		}
+	}
+
+	// ---- normalise and store: lane holds d = 16dt + 4g + r of query column li
+#pragma unroll
+	for (int qt = 0; qt < 2; ++qt) {
+		float l = l_run[qt];
+		l += __shfl_xor(l, 16);
+		l += __shfl_xor(l, 32);
+		const float inv = 1.0f / l;
+		const int qi = q0 + 16 * qt + li;
+		if (qi < p.T) {
+			T* dst = (T*)p.out + ((int64_t)b * p.T + qi) * p.ldo + h * HD;
+#pragma unroll
+			for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) dst[16 * dt + 4 * g + r] = cvt<T>(o[qt][dt][r] * inv);
+		}
+	}
+}
+
+template <typename T>
+static void launch_attn_fwd_t(const AttnParams& p, hipStream_t s) {
+	dim3 grid((p.T + 127) / 128, p.H, p.nb);
+	if (p.causal) hipLaunchKernelGGL((k_attn_fwd<T, true, false>), grid, dim3(256), 0, s, p);
+	else if (p.bias) hipLaunchKernelGGL((k_attn_fwd<T, false, true>), grid, dim3(256), 0, s, p);
+	else hipLaunchKernelGGL((k_attn_fwd<T, false, false>), grid, dim3(256), 0, s, p);
+}
+void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s) {
+	if (dt == DT_BF16) launch_attn_fwd_t<bf16>(p, s);
+	else launch_attn_fwd_t<float>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------ decode
+// grid (H, B), 256 threads.  Lane (slot = lane>>3, dg = lane&7) owns 8 head dims of every 8th key of its wave's
+// key range: one wave instruction reads 8 consecutive cache rows = 1 KiB (bf16).  Online softmax per slot, then
+// slots (shuffles) and waves (LDS) are merged.  Algorithmic bytes: 2 * (pos+1) * 64 * sizeof(T) per (b, h).
+template <typename T>
+__global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
+	typedef typename Frag<T>::type FragT;
+	const int h = blockIdx.x, b = blockIdx.y;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int slot = lane >> 3, dg = lane & 7;
+	const int n = min(*p.d_pos + 1, p.max_ctx);
+	const T* Kc = (const T*)p.kcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
+	const T* Vc = (const T*)p.vcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
+	float q[8];
+	{
+		const float* qp = p.qbuf + ((int64_t)b * p.H + h) * HD + 8 * dg;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) q[j] = qp[j];
+	}
+	// this wave's contiguous key range, in groups of 8 keys
+	const int groups = (n + 7) / 8;
+	const int g0 = (groups * wave) / 4, g1 = (groups * (wave + 1)) / 4;
+	float m = NEG_BIG, l = 0.f, acc[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+	constexpr int UN = 4;
+	for (int gb = g0; gb < g1; gb += UN) {
+		FragT kf[UN], vf[UN];
+#pragma unroll
+		for (int u = 0; u < UN; ++u) {
+			int key = (gb + u) * 8 + slot;
+			key = key < n ? key : n - 1;
+			kf[u] = *(const FragT*)(Kc + (int64_t)key * HD + 8 * dg);
+			vf[u] = *(const FragT*)(Vc + (int64_t)key * HD + 8 * dg);
+		}
+#pragma unroll
+		for (int u = 0; u < UN; ++u) {
+			const int key = (gb + u) * 8 + slot;
+			float sdot = 0.f;
+#pragma unroll
+			for (int j = 0; j < 8; ++j) sdot += q[j] * (float)kf[u][j];
+			sdot += __shfl_xor(sdot, 1);
+			sdot += __shfl_xor(sdot, 2);
+			sdot += __shfl_xor(sdot, 4);
+			const bool valid = (gb + u) < g1 && key < n;
+			if (valid) {
+				const float m_new = fmaxf(m, sdot);
+				const float alpha = __expf(m - m_new), pv = __expf(sdot - m_new);
+				l = l * alpha + pv;
+#pragma unroll
+				for (int j = 0; j < 8; ++j) acc[j] = acc[j] * alpha + pv * (float)vf[u][j];
+				m = m_new;
+			}
+		}
+	}
+	// merge the 8 key slots of the wave (lanes differing in bits 3..5)
+#pragma unroll
+	for (int off = 8; off < 64; off <<= 1) {
+		const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+		const float mn = fmaxf(m, m2);
+		const float a1 = __expf(m - mn), a2 = __expf(m2 - mn);
+		l = l * a1 + l2 * a2;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) { const float o2 = __shfl_xor(acc[j], off); acc[j] = acc[j] * a1 + o2 * a2; }
+		m = mn;
+	}
+	__shared__ float sm[4], sl[4], sacc[4][HD];
+	if (slot == 0) {
+		if (dg == 0) { sm[wave] = m; sl[wave] = l; }
+#pragma unroll
+		for (int j = 0; j < 8; ++j) sacc[wave][8 * dg + j] = acc[j];
+	}
+	__syncthreads();
+	if (tid < HD) {
+		const float mn = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+		float lt = 0.f, ot = 0.f;
+#pragma unroll
+		for (int w = 0; w < 4; ++w) { const float a = __expf(sm[w] - mn); lt += sl[w] * a; ot += sacc[w][tid] * a; }
+		((T*)p.out)[((int64_t)b * p.H + h) * HD + tid] = cvt<T>(ot / lt);
+	}
+}
+
+void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {
+	dim3 grid(p.H, p.B);
+	if (dt == DT_BF16) hipLaunchKernelGGL((k_attn_decode<bf16>), grid, dim3(256), 0, s, p);
+	else hipLaunchKernelGGL((k_attn_decode<float>), grid, dim3(256), 0, s, p);
+}
+
+// ------------------------------------------------------------------------------------------------ prefill KV -> cache
+template <typename T>
+__global__ void k_kv_scatter(const T* qkv, int B, int S, int H, T* kc, T* vc, int max_ctx) {
+	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 8 elements
+	const int d = H * HD;
+	const int64_t total = (int64_t)B * S * (d / 8);
+	if (idx >= total) return;
+	const int c8 = (int)(idx % (d / 8));
+	const int64_t row = idx / (d / 8);
+	const int b = (int)(row / S), t = (int)(row - (int64_t)b * S);
+	const int c = c8 * 8, h = c >> 6, dd = c & 63;
+	typedef typename Frag<T>::type FragT;
+	const T* src = qkv + row * (3 * d);
+	const int64_t dst = (((int64_t)b * H + h) * max_ctx + t) * HD + dd;
+	*(FragT*)(kc + dst) = *(const FragT*)(src + d + c);
+	*(FragT*)(vc + dst) = *(const FragT*)(src + 2 * d + c);
+}
+void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcache, void* vcache, int max_ctx, hipStream_t s) {
+	const int64_t total = (int64_t)B * S * (H * HD / 8);
+	const int grid = (int)((total + 255) / 256);
+	if (dt == DT_BF16) hipLaunchKernelGGL((k_kv_scatter<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)qkv, B, S, H, (bf16*)kcache, (bf16*)vcache, max_ctx);
+	else hipLaunchKernelGGL((k_kv_scatter<float>), dim3(grid), dim3(256), 0, s, (const float*)qkv, B, S, H, (float*)kcache, (float*)vcache, max_ctx);
+}
+
+}  // namespace ttk

@@ -1,0 +1,325 @@
+// ttk_diff: the diffusion half of the hot path -- DiffusionTTS and the per-step sampler behind the C ABI of include/ttk.h.
+// Internal layout is channels-last ([b*T rows][C]) so every 1x1 conv is an NT GEMM on the conv weight as stored and the
+// k=3 convs are 3 row-shifted GEMM segments; the boundary stays the reference's [b, C, T].
+// The conditioned and the conditioning-free evaluation of a sampler step run as ONE batch of 2b sequences (same x, same t,
+// different code embedding) so each weight is read once per step.
+// Reference: /root/reference/tortoise_tts/models/diffusion.py:1316-1574 (ResBlock, DiffusionLayer, DiffusionTTS),
+//            :325-431,646-694,510-554 (p_mean_variance, ddim_sample, p_sample); arch_utils.py:136-190 (AttentionBlock).
+#include "ttk_common.h"
+#include "ttk_host.h"
+
+using namespace ttk;
+
+namespace {
+struct AttnBlk { float *gn_g, *gn_b; Mat qkv, proj; float* relbias; };
+struct ResBlk { float *gn1_g, *gn1_b, *gn2_g, *gn2_b; Mat in, out3; int emb_slot; };
+struct DLayer { ResBlk res; AttnBlk attn; };
+}  // namespace
+
+struct ttk_diff {
+	ttk_diff_config cfg;
+	int dt;
+	size_t es;
+	Arena arena;
+	AttnBlk lat_attn[4];
+	Mat lat_conv, inp_block, integ, out_conv, time0, time2, emb_cat;
+	float *code_g, *code_b, *out_g, *out_b, *uncond, *time_freqs;
+	DLayer integrator[3];
+	std::vector<DLayer> layers;
+	ResBlk tail[3];
+	int n_emb;               // number of ResBlocks = rows of emb_cat / 2C
+	int in_pad;              // in_channels rounded up to 64
+	// workspaces
+	WsBuf cs, xs, hf, a, qkv, ao, h0, csT, xcl, outb, ecl, ms, temb, e1, e2, se, emb_all, lat_T;
+	int cur_b = 0, cur_T = 0, staged = 0;
+};
+
+static void gemm1(ttk_diff* h, const void* A, int64_t lda, const Mat& m, int M, void* C, int64_t ldc, int out_f32, int act,
+				  const float* residual, hipStream_t s) {
+	GemmParams g = {};
+	g.nseg = 1; g.seg[0] = {A, lda, 0, 0};
+	g.W = m.w; g.ldw = m.Kpad; g.M = M; g.N = m.N; g.K = m.Kpad; g.bias = m.bias;
+	g.residual = residual; g.ldr = ldc; g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.act = act;
+	launch_gemm(h->dt, g, s);
+}
+
+// k=3 'same' conv over rows inside each batch element: tap j multiplies row t + j - 1
+static void gemm_conv3(ttk_diff* h, const void* A, int64_t lda, const Mat& m, int M, int Tper, void* C, int64_t ldc, int out_f32,
+					   const float* residual, int transpose_out, hipStream_t s) {
+	GemmParams g = {};
+	g.nseg = 3;
+	for (int j = 0; j < 3; ++j) g.seg[j] = {A, lda, j - 1, (int64_t)j * m.Npad * m.Kpad};
+	g.W = m.w; g.ldw = m.Kpad; g.M = M; g.N = m.N; g.K = m.Kpad; g.rows_per_batch = Tper; g.bias = m.bias;
+	g.residual = residual; g.ldr = ldc; g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.transpose_out = transpose_out;
+	launch_gemm(h->dt, g, s);
+}
+
+static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, const float* beta, const float* scale, const float* shift,
+			   int64_t ss_stride, int act, void* out, int out_f32, const int* row_idx, int Tout, hipStream_t s) {
+	const int C = h->cfg.model_channels;
+	launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);
+	GnApplyParams p = {};
+	p.x = x; p.ms = (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
+	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.act = act; p.out = out; p.out_f32 = out_f32;
+	launch_gn_apply(h->dt, p, s);
+}
+
+// x (f32 stream, in place) = x + proj_out(attention(qkv(GN(x))))         arch_utils.py:183-190
+static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, hipStream_t s) {
+	const int C = h->cfg.model_channels, rows = nb * T;
+	gn(h, x, nb, T, A.gn_g, A.gn_b, nullptr, nullptr, 0, ACT_NONE, h->a.p, 0, nullptr, T, s);
+	gemm1(h, h->a.p, C, A.qkv, rows, h->qkv.p, 3 * C, 0, ACT_NONE, nullptr, s);
+	AttnParams a = {};
+	a.qkv = h->qkv.p; a.ld = 3 * C; a.q_off = 0; a.k_off = 64; a.v_off = 128; a.head_stride = 192;   // head-major [H][3][64], arch_utils.py:79
+	a.out = h->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f;
+	launch_attn_fwd(h->dt, a, s);
+	gemm1(h, h->ao.p, C, A.proj, rows, x, C, 1, ACT_NONE, x, s);
+}
+
+// x = x + conv3(SiLU(GN(conv1(SiLU(GN(x)))) * (1 + scale) + shift))        diffusion.py:1363-1376
+static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, const float* emb_all, int64_t emb_stride, hipStream_t s) {
+	const int C = h->cfg.model_channels, rows = nb * T;
+	gn(h, x, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s);
+	gemm1(h, h->a.p, C, R.in, rows, h->hf.p, C, 1, ACT_NONE, nullptr, s);
+	const float* sc = emb_all + (int64_t)R.emb_slot * 2 * C;
+	gn(h, (const float*)h->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->a.p, 0, nullptr, T, s);
+	gemm_conv3(h, h->a.p, C, R.out3, rows, T, x, C, 1, x, 0, s);
+}
+
+static int reserve_ws(ttk_diff* h, int nb, int T) {
+	const size_t rows = (size_t)nb * T, C = h->cfg.model_channels, es = h->es;
+	TTK_TRY(h->cs.reserve(rows * C * 4)); TTK_TRY(h->xs.reserve(rows * C * 4)); TTK_TRY(h->hf.reserve(rows * C * 4));
+	TTK_TRY(h->a.reserve(rows * C * es)); TTK_TRY(h->qkv.reserve(rows * 3 * C * es)); TTK_TRY(h->ao.reserve(rows * C * es));
+	TTK_TRY(h->h0.reserve(rows * C * es)); TTK_TRY(h->csT.reserve(rows * C * es)); TTK_TRY(h->xcl.reserve(rows * h->in_pad * es));
+	TTK_TRY(h->outb.reserve(rows * h->cfg.out_channels * 4)); TTK_TRY(h->ecl.reserve(rows * C * 4));
+	TTK_TRY(h->ms.reserve((size_t)nb * 64 * 4));
+	return TTK_OK;
+}
+
+// time_embed MLP + every ResBlock's emb_layers for n timestep rows -> emb_all f32 [n][n_emb * 2C]    diffusion.py:1549, :1365
+static int time_path(ttk_diff* h, const int64_t* t_dev, const int64_t* t_host, int n, hipStream_t s) {
+	const int C = h->cfg.model_channels;
+	const size_t es = h->es;
+	TTK_TRY(h->temb.reserve((size_t)n * C * es)); TTK_TRY(h->e1.reserve((size_t)n * C * es)); TTK_TRY(h->e2.reserve((size_t)n * C * 4));
+	TTK_TRY(h->se.reserve((size_t)n * C * es)); TTK_TRY(h->emb_all.reserve((size_t)n * h->n_emb * 2 * C * 4));
+	if (t_dev) launch_timestep_embedding(h->dt, t_dev, 0, n, C, h->time_freqs, h->temb.p, s);
+	else for (int i = 0; i < n; ++i) launch_timestep_embedding(h->dt, nullptr, t_host[i], 1, C, h->time_freqs, (char*)h->temb.p + (size_t)i * C * es, s);
+	gemm1(h, h->temb.p, C, h->time0, n, h->e1.p, C, 0, ACT_SILU, nullptr, s);
+	gemm1(h, h->e1.p, C, h->time2, n, h->e2.p, C, 1, ACT_NONE, nullptr, s);
+	launch_silu_cast(h->dt, (const float*)h->e2.p, h->se.p, (int64_t)n * C, s);
+	gemm1(h, h->se.p, C, h->emb_cat, n, h->emb_all.p, (int64_t)h->n_emb * 2 * C, 1, ACT_NONE, nullptr, s);
+	return TTK_OK;
+}
+
+// The network body on nb sequences of T frames.  Inputs: h->xcl (T-typed [nb*T][in_pad]) and h->cs (f32 code embedding stream
+// [nb*T][C], consumed); emb rows at emb_all + b * emb_stride.  Output: out f32 [nb][out_channels][T].     diffusion.py:1549-1564
+static void network(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, float* out, hipStream_t s) {
+	const int C = h->cfg.model_channels, rows = nb * T;
+	float* cs = (float*)h->cs.p;
+	float* x = (float*)h->xs.p;
+	for (int i = 0; i < 3; ++i) {
+		res_block(h, h->integrator[i].res, cs, nb, T, emb_all, emb_stride, s);
+		attn_block(h, h->integrator[i].attn, cs, nb, T, s);
+	}
+	gemm_conv3(h, h->xcl.p, h->in_pad, h->inp_block, rows, T, h->h0.p, C, 0, nullptr, 0, s);
+	launch_cast(h->dt, cs, h->csT.p, (int64_t)rows * C, s);
+	{   // integrating_conv over cat([h0, code_emb], channels): two K segments of one [C][2C] matrix
+		GemmParams g = {};
+		g.nseg = 2;
+		g.seg[0] = {h->h0.p, C, 0, 0};
+		g.seg[1] = {h->csT.p, C, 0, C};
+		g.W = h->integ.w; g.ldw = h->integ.Kpad; g.M = rows; g.N = C; g.K = C; g.bias = h->integ.bias;
+		g.C = x; g.ldc = C; g.out_f32 = 1;
+		launch_gemm(h->dt, g, s);
+	}
+	for (size_t i = 0; i < h->layers.size(); ++i) {
+		res_block(h, h->layers[i].res, x, nb, T, emb_all, emb_stride, s);
+		attn_block(h, h->layers[i].attn, x, nb, T, s);
+	}
+	for (int i = 0; i < 3; ++i) res_block(h, h->tail[i], x, nb, T, emb_all, emb_stride, s);
+	gn(h, x, nb, T, h->out_g, h->out_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s);
+	gemm_conv3(h, h->a.p, C, h->out_conv, rows, T, out, 0, 1, nullptr, 1, s);
+}
+
+static int load_attn(ttk_diff* h, const WeightMap& wm, const std::string& p, AttnBlk* A) {
+	const int C = h->cfg.model_channels;
+	TTK_TRY(upload_f32(h->arena, wm, p + "norm.weight", C, &A->gn_g));
+	TTK_TRY(upload_f32(h->arena, wm, p + "norm.bias", C, &A->gn_b));
+	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "qkv.weight", p + "qkv.bias", PK_NK, 3 * C, C, false, &A->qkv));
+	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "proj_out.weight", p + "proj_out.bias", PK_NK, C, C, false, &A->proj));
+	TTK_TRY(upload_f32(h->arena, wm, p + "__relbias", (int64_t)h->cfg.num_heads * 129, &A->relbias));
+	return TTK_OK;
+}
+static int load_res(ttk_diff* h, const WeightMap& wm, const std::string& p, ResBlk* R, int slot) {
+	const int C = h->cfg.model_channels;
+	TTK_TRY(upload_f32(h->arena, wm, p + "in_layers.0.weight", C, &R->gn1_g));
+	TTK_TRY(upload_f32(h->arena, wm, p + "in_layers.0.bias", C, &R->gn1_b));
+	TTK_TRY(upload_f32(h->arena, wm, p + "out_layers.0.weight", C, &R->gn2_g));
+	TTK_TRY(upload_f32(h->arena, wm, p + "out_layers.0.bias", C, &R->gn2_b));
+	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "in_layers.2.weight", p + "in_layers.2.bias", PK_NK, C, C, false, &R->in));
+	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "out_layers.3.weight", p + "out_layers.3.bias", PK_CONV3, C, C, false, &R->out3));
+	R->emb_slot = slot;
+	return TTK_OK;
+}
+
+extern "C" {
+
+int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight_view* w, int n_w) {
+	TTK_REQUIRE(out && cfg && w, TTK_E_ARG, "ttk_diff_create: null argument");
+	TTK_REQUIRE(cfg->model_channels % 64 == 0 && cfg->num_heads * 64 == cfg->model_channels, TTK_E_ARG,
+				"ttk_diff_create: head_dim must be 64 (channels %d, heads %d)", cfg->model_channels, cfg->num_heads);
+	TTK_REQUIRE(cfg->in_latent_channels % 64 == 0, TTK_E_ARG, "ttk_diff_create: in_latent_channels %% 64 != 0");
+	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
+	ttk_diff* h = new ttk_diff();
+	h->cfg = *cfg;
+	h->dt = cfg->dtype;
+	h->es = dtype_size(h->dt);
+	h->in_pad = round_up(cfg->in_channels, 64);
+	const int C = cfg->model_channels;
+	WeightMap wm(w, n_w);
+	int rc = TTK_OK;
+	auto fail = [&](int code) { h->arena.release(); delete h; return code; };
+#define D_TRY(expr) do { rc = (expr); if (rc != TTK_OK) return fail(rc); } while (0)
+	D_TRY(upload_f32(h->arena, wm, "unconditioned_embedding", C, &h->uncond));
+	D_TRY(upload_f32(h->arena, wm, "__time_freqs", C / 2, &h->time_freqs));
+	D_TRY(upload_mat(h->arena, wm, h->dt, "inp_block.weight", "inp_block.bias", PK_CONV3, C, cfg->in_channels, false, &h->inp_block));
+	D_TRY(upload_mat(h->arena, wm, h->dt, "time_embed.0.weight", "time_embed.0.bias", PK_NK, C, C, false, &h->time0));
+	D_TRY(upload_mat(h->arena, wm, h->dt, "time_embed.2.weight", "time_embed.2.bias", PK_NK, C, C, false, &h->time2));
+	D_TRY(upload_f32(h->arena, wm, "code_norm.weight", C, &h->code_g));
+	D_TRY(upload_f32(h->arena, wm, "code_norm.bias", C, &h->code_b));
+	D_TRY(upload_mat(h->arena, wm, h->dt, "latent_conditioner.0.weight", "latent_conditioner.0.bias", PK_CONV3, C, cfg->in_latent_channels, false, &h->lat_conv));
+	for (int i = 0; i < 4; ++i) D_TRY(load_attn(h, wm, "latent_conditioner." + std::to_string(i + 1) + ".", &h->lat_attn[i]));
+	D_TRY(upload_mat(h->arena, wm, h->dt, "integrating_conv.weight", "integrating_conv.bias", PK_NK, C, 2 * C, false, &h->integ));
+	D_TRY(upload_f32(h->arena, wm, "out.0.weight", C, &h->out_g));
+	D_TRY(upload_f32(h->arena, wm, "out.0.bias", C, &h->out_b));
+	D_TRY(upload_mat(h->arena, wm, h->dt, "out.2.weight", "out.2.bias", PK_CONV3, cfg->out_channels, C, false, &h->out_conv));
+	int slot = 0;
+	for (int i = 0; i < 3; ++i) {
+		const std::string p = "conditioning_timestep_integrator." + std::to_string(i) + ".";
+		D_TRY(load_res(h, wm, p + "resblk.", &h->integrator[i].res, slot++));
+		D_TRY(load_attn(h, wm, p + "attn.", &h->integrator[i].attn));
+	}
+	h->layers.resize(cfg->num_layers);
+	for (int i = 0; i < cfg->num_layers; ++i) {
+		const std::string p = "layers." + std::to_string(i) + ".";
+		D_TRY(load_res(h, wm, p + "resblk.", &h->layers[i].res, slot++));
+		D_TRY(load_attn(h, wm, p + "attn.", &h->layers[i].attn));
+	}
+	for (int i = 0; i < 3; ++i) D_TRY(load_res(h, wm, "layers." + std::to_string(cfg->num_layers + i) + ".", &h->tail[i], slot++));
+	h->n_emb = slot;
+	// all emb_layers.1 linears stacked into one [n_emb * 2C][C] matrix ("__emb_cat.*", built by the Python packer)
+	D_TRY(upload_mat(h->arena, wm, h->dt, "__emb_cat.weight", "__emb_cat.bias", PK_NK, h->n_emb * 2 * C, C, false, &h->emb_cat));
+#undef D_TRY
+	hipError_t e = hipDeviceSynchronize();
+	if (e != hipSuccess) { set_error("ttk_diff_create: %s", hipGetErrorString(e)); return fail(TTK_E_HIP); }
+	*out = h;
+	return TTK_OK;
+}
+
+int ttk_diff_destroy(ttk_diff* h) {
+	if (!h) return TTK_OK;
+	(void)hipDeviceSynchronize();
+	WsBuf* all[] = {&h->cs, &h->xs, &h->hf, &h->a, &h->qkv, &h->ao, &h->h0, &h->csT, &h->xcl, &h->outb, &h->ecl, &h->ms,
+					&h->temb, &h->e1, &h->e2, &h->se, &h->emb_all, &h->lat_T};
+	for (WsBuf* b : all) b->release();
+	h->arena.release();
+	delete h;
+	return TTK_OK;
+}
+
+int ttk_diff_precompute(ttk_diff* h, const float* latents, const float* cond, const int32_t* interp_idx, int b, int M, int T,
+						float* E_out, void* stream) {
+	TTK_REQUIRE(h && latents && cond && interp_idx && E_out, TTK_E_ARG, "ttk_diff_precompute: null argument");
+	TTK_REQUIRE(b >= 1 && M >= 1 && T >= 1, TTK_E_ARG, "ttk_diff_precompute: empty input (b=%d M=%d T=%d)", b, M, T);
+	const int C = h->cfg.model_channels, Cl = h->cfg.in_latent_channels;
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(reserve_ws(h, b, M > T ? M : T));
+	h->staged = 0;   // ecl is reused below
+	TTK_TRY(h->lat_T.reserve((size_t)b * M * Cl * h->es));
+	float* x = (float*)h->xs.p;
+	launch_cast(h->dt, latents, h->lat_T.p, (int64_t)b * M * Cl, s);   // latents are already [b][M][Cl] = channels-last
+	gemm_conv3(h, h->lat_T.p, Cl, h->lat_conv, b * M, M, x, C, 1, nullptr, 0, s);
+	for (int i = 0; i < 4; ++i) attn_block(h, h->lat_attn[i], x, b, M, s);
+	// code_norm(x) * (1 + scale) + shift, then nearest-neighbour expansion M -> T      diffusion.py:1492,1498,1507
+	gn(h, x, b, M, h->code_g, h->code_b, cond, cond + C, 2 * C, ACT_NONE, h->ecl.p, 1, interp_idx, T, s);
+	launch_cl_to_cf((const float*)h->ecl.p, b, C, T, E_out, s);
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+int ttk_diff_forward(ttk_diff* h, const float* x, const int64_t* t, const float* E, int b, int T, float* out, void* stream) {
+	TTK_REQUIRE(h && x && t && out, TTK_E_ARG, "ttk_diff_forward: null argument");
+	TTK_REQUIRE(b >= 1 && T >= 1, TTK_E_ARG, "ttk_diff_forward: empty input");
+	const int C = h->cfg.model_channels;
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(reserve_ws(h, b, T));
+	h->staged = 0;
+	if (E) launch_cf_to_cl(DT_F32, E, b, C, T, h->cs.p, C, 1, s);
+	else launch_bcast_rows(DT_F32, h->uncond, b * T, C, h->cs.p, s);            // diffusion.py:1534
+	launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, 1, s);
+	TTK_TRY(time_path(h, t, nullptr, b, s));
+	network(h, b, T, (const float*)h->emb_all.p, (int64_t)h->n_emb * 2 * C, out, s);
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream) {
+	TTK_REQUIRE(h && E, TTK_E_ARG, "ttk_diff_begin: null argument");
+	TTK_REQUIRE(b >= 1 && T >= 1, TTK_E_ARG, "ttk_diff_begin: empty input");
+	const int C = h->cfg.model_channels;
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(reserve_ws(h, 2 * b, T));
+	float* ecl = (float*)h->ecl.p;
+	launch_cf_to_cl(DT_F32, E, b, C, T, ecl, C, 1, s);
+	launch_bcast_rows(DT_F32, h->uncond, b * T, C, ecl + (size_t)b * T * C, s);
+	h->cur_b = b; h->cur_T = T; h->staged = 1;
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+static int step_impl(ttk_diff* h, float* x, const ttk_step* st, const float* noise, const float* emb_row, hipStream_t s) {
+	const int C = h->cfg.model_channels, b = h->cur_b, T = h->cur_T;
+	const bool cf = st->cfk >= 0.f;
+	const int nb = cf ? 2 * b : b;
+	TTK_HIP(hipMemcpyAsync(h->cs.p, h->ecl.p, (size_t)nb * T * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+	launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, cf ? 2 : 1, s);
+	float* out = (float*)h->outb.p;
+	network(h, nb, T, emb_row, 0, out, s);
+	StepCoefs k = {};
+	k.sqrt_recip_ac = st->sqrt_recip_ac; k.sqrt_recipm1_ac = st->sqrt_recipm1_ac; k.sqrt_ac_prev = st->sqrt_ac_prev;
+	k.sqrt_1m_ac_prev = st->sqrt_1m_ac_prev; k.cfk = st->cfk; k.coef1 = st->coef1; k.coef2 = st->coef2;
+	k.min_log = st->min_log; k.max_log = st->max_log; k.sampler = st->sampler; k.nonzero = st->nonzero;
+	const int Cin = h->cfg.in_channels;
+	launch_diffusion_step(out, out + (size_t)b * h->cfg.out_channels * T, x, noise, b, Cin, T, k, s);
+	return TTK_OK;
+}
+
+int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise, void* stream) {
+	TTK_REQUIRE(h && x && st, TTK_E_ARG, "ttk_diff_step: null argument");
+	TTK_REQUIRE(h->staged, TTK_E_STATE, "ttk_diff_step: call ttk_diff_begin first");
+	TTK_REQUIRE(st->sampler == 0 || noise, TTK_E_ARG, "ttk_diff_step: the p sampler needs noise");
+	TTK_REQUIRE(h->cfg.out_channels == 2 * h->cfg.in_channels, TTK_E_ARG, "ttk_diff_step: learned-range output needs out = 2 * in channels");
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(time_path(h, nullptr, &st->t, 1, s));
+	TTK_TRY(step_impl(h, x, st, noise, (const float*)h->emb_all.p, s));
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream) {
+	TTK_REQUIRE(h && x && E && steps && n_steps >= 1, TTK_E_ARG, "ttk_diff_sample_ddim: bad argument");
+	TTK_REQUIRE(h->cfg.out_channels == 2 * h->cfg.in_channels, TTK_E_ARG, "ttk_diff_sample_ddim: learned-range output needs out = 2 * in channels");
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(ttk_diff_begin(h, E, b, T, stream));
+	// the timestep-only work of ALL steps in one pass: [n_steps] rows through time_embed + every emb_layers (weights read once)
+	std::vector<int64_t> ts(n_steps);
+	for (int i = 0; i < n_steps; ++i) { ts[i] = steps[i].t; TTK_REQUIRE(steps[i].sampler == 0, TTK_E_ARG, "ttk_diff_sample_ddim: step %d is not a ddim step", i); }
+	TTK_TRY(time_path(h, nullptr, ts.data(), n_steps, s));
+	const int64_t stride = (int64_t)h->n_emb * 2 * h->cfg.model_channels;
+	for (int i = n_steps - 1; i >= 0; --i)
+		TTK_TRY(step_impl(h, x, &steps[i], nullptr, (const float*)h->emb_all.p + i * stride, s));
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+}  // extern "C"

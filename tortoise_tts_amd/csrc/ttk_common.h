@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libttk.
+// One arithmetic template parameter T in {float, __bf16}: T is the storage/MFMA-operand type of weights and
+// of GEMM/attention input activations; accumulators, residual streams, norm statistics and softmax are f32.
+//   T = __bf16 : v_mfma_f32_16x16x32_bf16              (performance mode, BASELINE config 2)
+//   T = float  : 8 x v_mfma_f32_16x16x4_f32 per k-step (exact-f32 parity mode; same tiling, same code)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+namespace ttk {
+
+// A "fragment" is 8 consecutive-k elements of T held by one lane: for the 16x16 MFMA tile, lane l holds
+// row/col (l & 15) and k-group g = l >> 4, i.e. k = 32*ks + 8*g + j, j = 0..7.
+template <typename T> struct Frag;
+template <> struct Frag<float> { typedef f32x8 type; };
+template <> struct Frag<bf16> { typedef bf16x8 type; };
+
+template <typename T>
+__device__ __forceinline__ f32x4 mma16(typename Frag<T>::type a, typename Frag<T>::type b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mma16<bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
+	return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// f32: instruction j contracts k = {8g + j : g = 0..3}; the eight instructions together cover the same 32 k as
+// the bf16 form with the same per-lane addressing (exact f32 fma chain, MI355X_MICROARCH "FP32-input MFMA").
+template <>
+__device__ __forceinline__ f32x4 mma16<float>(f32x8 a, f32x8 b, f32x4 c) {
+#pragma unroll
+	for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+	return c;
+}
+
+template <typename T> __device__ __forceinline__ T cvt(float x);
+template <> __device__ __forceinline__ float cvt<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 cvt<bf16>(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+	return v;
+}
+
+__device__ __forceinline__ float gelu_new_f(float x) {   // HF:activations.py:59-66
+	const float k = 0.7978845608028654f;
+	return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
+
+enum Act { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_SILU = 2 };
+__device__ __forceinline__ float apply_act(float v, int act) {
+	if (act == ACT_GELU_NEW) return gelu_new_f(v);
+	if (act == ACT_SILU) return silu_precise(v);
+	return v;
+}
+
+}  // namespace ttk

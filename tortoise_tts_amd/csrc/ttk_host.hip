@@ -1,0 +1,63 @@
+#include "ttk_host.h"
+
+#include <stdarg.h>
+
+namespace ttk {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+int upload_f32(Arena& ar, const WeightMap& wm, const std::string& name, int64_t expect_numel, float** out) {
+	const ttk_weight_view* v = wm.find(name);
+	TTK_REQUIRE(v != nullptr, TTK_E_WEIGHT, "missing weight '%s'", name.c_str());
+	TTK_REQUIRE(numel(v) == expect_numel, TTK_E_WEIGHT, "weight '%s' has %lld elements, expected %lld", name.c_str(),
+				(long long)numel(v), (long long)expect_numel);
+	TTK_TRY(ar.alloc((void**)out, (size_t)expect_numel * sizeof(float)));
+	TTK_HIP(hipMemcpy(*out, v->data, (size_t)expect_numel * sizeof(float), hipMemcpyDefault));
+	return TTK_OK;
+}
+
+int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, int layout,
+			   int N, int K, bool frag, Mat* out) {
+	const ttk_weight_view* v = wm.find(wname);
+	TTK_REQUIRE(v != nullptr, TTK_E_WEIGHT, "missing weight '%s'", wname.c_str());
+	const int ntap = layout == PK_CONV3 ? 3 : 1;
+	TTK_REQUIRE(numel(v) == (int64_t)N * K * ntap, TTK_E_WEIGHT, "weight '%s' has %lld elements, expected %lld", wname.c_str(),
+				(long long)numel(v), (long long)N * K * ntap);
+	out->N = N; out->K = K; out->ntap = ntap;
+	out->Npad = round_up(N, 128);
+	out->Kpad = round_up(K, 64);
+	const size_t es = dtype_size(dt);
+	float* tmp = nullptr;
+	TTK_HIP(hipMalloc((void**)&tmp, (size_t)numel(v) * sizeof(float)));
+	hipError_t e = hipMemcpy(tmp, v->data, (size_t)numel(v) * sizeof(float), hipMemcpyDefault);
+	if (e != hipSuccess) { (void)hipFree(tmp); set_error("hipMemcpy of '%s' failed: %s", wname.c_str(), hipGetErrorString(e)); return TTK_E_HIP; }
+	const size_t wbytes = (size_t)ntap * out->Npad * out->Kpad * es;
+	int rc = ar.alloc(&out->w, wbytes);
+	if (rc == TTK_OK) {
+		launch_pack_nk(dt, tmp, layout, N, K, out->Npad, out->Kpad, out->w, 0);
+		if (frag && ntap == 1) {
+			rc = ar.alloc(&out->wfrag, wbytes);
+			if (rc == TTK_OK) launch_pack_frag(dt, out->w, out->Npad, out->Kpad, out->wfrag, 0);
+		}
+	}
+	e = hipDeviceSynchronize();
+	(void)hipFree(tmp);
+	if (rc != TTK_OK) return rc;
+	if (e != hipSuccess) { set_error("weight packing of '%s' failed: %s", wname.c_str(), hipGetErrorString(e)); return TTK_E_HIP; }
+	if (!bname.empty()) TTK_TRY(upload_f32(ar, wm, bname, N, &out->bias));
+	return TTK_OK;
+}
+
+}  // namespace ttk
+
+extern "C" {
+int ttk_version(void) { return TTK_VERSION; }
+const char* ttk_last_error(void) { return ttk::get_error(); }
+}

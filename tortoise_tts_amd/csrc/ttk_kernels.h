@@ -1,0 +1,136 @@
+// Host-side launchers of the libttk kernels (internal C++ interface between the handles in ar.hip / diff.hip
+// and the kernel files).  All pointers are device pointers; every launcher only enqueues work on `stream`
+// (no allocation, no synchronisation: graph-capture safe).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ttk {
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+inline size_t dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+
+// ---------------------------------------------------------------- dense GEMM (gemm.hip)
+// C[M,N] = epilogue( sum_seg  shift(A_seg)[M,K] * W_seg[N,K]^T )      ("NT": both operands K-contiguous)
+// Segments express (a) the 3 taps of a k=3 'same' convolution over rows (row shift -1,0,+1 inside each
+// batch element of `rows_per_batch` rows, zero outside) and (b) channel concatenation (two A sources).
+struct GemmSeg {
+	const void* A;      // T [M][lda]
+	int64_t lda;
+	int shift;          // source row = m + shift (valid iff it stays inside m's batch element)
+	int64_t w_off;      // element offset of this segment's [Npad][K] matrix inside W
+};
+struct GemmParams {
+	GemmSeg seg[3];
+	int nseg;
+	const void* W;      // T, each segment matrix [Npad][ldw] row-major (first K columns used), Npad % 128 == 0
+	int64_t ldw;
+	int M, N, K;        // K (per segment) % 64 == 0
+	int rows_per_batch; // >0 when any shift != 0 or transpose_out
+	const float* bias;  // [N] or null
+	const float* residual;  // f32 [M][ldr] or null (may alias C when out_f32)
+	int64_t ldr;
+	void* C;
+	int64_t ldc;
+	int act;            // ttk::Act
+	int out_f32;        // C is f32 (else T)
+	int transpose_out;  // C is f32 [M / rows_per_batch][N][rows_per_batch]
+};
+void launch_gemm(int dt, const GemmParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- skinny GEMM for decode (skinny.hip)
+// out[M<=16*MT, N] = epilogue( LN?(x)[M,K] * W[N,K]^T + bias ), weights streamed once from HBM in MFMA-fragment
+// order: Wp[n_tile][k_step][lane][8].
+enum SkinnyMode { SK_STORE_F32 = 0, SK_RESIDUAL = 1, SK_ACT_T = 2, SK_QKV = 3 };
+struct SkinnyParams {
+	const void* Wp;
+	int N, K, M;
+	const float* bias;
+	// A source: LN mode (ln_count 1|2) reads f32 rows and normalises; plain mode reads T rows
+	int ln_count;
+	const float* x;  int64_t ldx;
+	const float *g1, *b1, *g2, *b2;
+	float* ln_out;              // optional f32 [M][K]: the normalised rows (block 0 writes), else null
+	const void* a;   int64_t lda;
+	int mode, act;
+	float* out_f32;  int64_t ldc;   // SK_STORE_F32 / SK_RESIDUAL (in place +=)
+	void* out_T;                    // SK_ACT_T, [M][N]
+	// SK_QKV: n in [0,3d): q -> qbuf[m][n] f32 (pre-scaled), k/v -> cache[m][h][*pos][64]
+	float* qbuf; void* kcache; void* vcache; const int* d_pos; int max_ctx, H; float q_scale;
+};
+void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s);
+
+// ---------------------------------------------------------------- norms (norm.hip)
+// y = LN2?(LN1(x)) per row; out is T or f32
+void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
+					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s);
+// GroupNorm32 over channels-last x f32 [nb][T][C], 32 groups: stats -> ms[nb][32][2] (mean, rstd)
+void launch_gn_stats(const float* x, int nb, int T, int C, float* ms, hipStream_t s);
+// y[nb][Tout][C] (T-typed or f32) = act( gn(x)*gamma+beta [ *(1+scale[b][c]) + shift[b][c] ] ), optional nearest
+// row gather (row_idx[Tout] into [0,T)) used by timestep_independent's F.interpolate.
+struct GnApplyParams {
+	const float* x; const float* ms; const float* gamma; const float* beta;
+	const float* scale; const float* shift; int64_t ss_stride;   // per-batch stride of scale/shift rows (0 = shared)
+	const int* row_idx; int nb, T, Tout, C; int act; void* out; int out_f32;
+};
+void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (attn.hip)
+struct AttnParams {
+	const void* qkv; int64_t ld;          // T [nb*T][ld]
+	int q_off, k_off, v_off, head_stride; // column of (h, d) = off + h*head_stride + d ; head_dim is 64
+	void* out; int64_t ldo;               // T [nb*T][ldo], column h*64 + d
+	int nb, T, H, causal;
+	const float* bias;                    // [H][129] relative-position bias (already scaled) or null
+	float scale;                          // multiplies q.k
+};
+void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s);
+
+struct AttnDecodeParams {
+	const float* qbuf;        // f32 [B][H*64], already scaled
+	const void* kcache; const void* vcache;   // T [B][H][max_ctx][64]
+	const int* d_pos;         // keys valid = *d_pos + 1
+	int B, H, max_ctx;
+	void* out;                // T [B][H*64]
+};
+void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s);
+
+// copy k/v of a dense qkv buffer [B*S][3d] (GPT-2 order q|k|v, head h at h*64) into the cache rows [0,S)
+void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcache, void* vcache, int max_ctx, hipStream_t s);
+
+// ---------------------------------------------------------------- elementwise (elementwise.hip)
+void launch_set_int(int* p, int v, hipStream_t s);
+void launch_add_int(int* p, int v, hipStream_t s);
+// out[r][:] = A[ia[r]][:] + Bt[ib[r]][:]   (f32 tables, f32 out); ia/ib int32 device arrays; Bt may be null
+void launch_gather_add(const float* A, const int* ia, const float* Bt, const int* ib, float* out, int rows, int d, hipStream_t s);
+// decode-time embedding: out[b] = mel_emb[tok[b]] + mel_pos[*d_pos - pos_bias]
+void launch_decode_embed(const float* emb, const int64_t* tok, const float* pos, const int* d_pos, int pos_off, int pos_rows,
+						 float* out, int B, int d, hipStream_t s);
+void launch_copy_rows(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int d, hipStream_t s);
+void launch_cast(int dt, const float* src, void* dst, int64_t n, hipStream_t s);
+// [nb][C][T] f32  ->  [rep*nb*T][ldo] T, zero padded to ldo columns; the nb*T block is written `rep` times
+void launch_cf_to_cl(int dt, const float* src, int nb, int C, int T, void* dst, int64_t ldo, int rep, hipStream_t s);
+// [nb*T][C] f32 -> [nb][C][T] f32
+void launch_cl_to_cf(const float* src, int nb, int C, int T, float* dst, hipStream_t s);
+// rows of a [1][C] f32 vector broadcast to T-typed [rows][C]
+void launch_bcast_rows(int dt, const float* vec, int rows, int C, void* dst, hipStream_t s);
+// sinusoidal timestep embedding (diffusion.py:1277-1295): t int64 device [n] (or host value when t == null) -> T [n][C]
+void launch_timestep_embedding(int dt, const int64_t* t, int64_t t_host, int n, int C, const float* freqs, void* out, hipStream_t s);
+// y = T(silu(x)) elementwise (f32 in)
+void launch_silu_cast(int dt, const float* x, void* y, int64_t n, hipStream_t s);
+// fused DDIM/p epilogue on channel-first f32 buffers; see elementwise.hip
+struct StepCoefs {
+	float sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac_prev, sqrt_1m_ac_prev, cfk;   // cfk < 0: no cond-free mix
+	float coef1, coef2, min_log, max_log; int sampler; int nonzero;            // sampler 0 ddim, 1 p
+};
+void launch_diffusion_step(const float* out_c, const float* out_u, float* x, const float* noise, int nb, int C, int T,
+						   StepCoefs c, hipStream_t s);
+
+// ---------------------------------------------------------------- packing (pack.hip)
+enum PackLayout { PK_NK = 0, PK_KN = 1, PK_CONV3 = 2 };
+// src f32 -> dst T [ntap][Npad][Kpad] (zero padded)
+void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s);
+// T [Npad][K] -> fragment order [Npad/16][K/32][64][8]
+void launch_pack_frag(int dt, const void* src, int Npad, int K, void* dst, hipStream_t s);
+
+}  // namespace ttk
