@@ -1,0 +1,102 @@
+"""CPU tests of the host-side logic of the product (no GPU, no compute calls into libttk)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import tortoise_oracle as O
+from tortoise_tts_amd import _lib, diffusion as D, sampling, weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+	_lib.build()
+	lib = ctypes.CDLL(_lib.LIB_PATH)
+	header = open(os.path.join(ROOT, "include", "ttk.h")).read()
+	declared = set(re.findall(r"\b(ttk_[a-z_]+)\s*\(", header))
+	assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+	for name in declared:
+		assert hasattr(lib, name), name
+	assert _lib.load().ttk_version() == 1
+
+
+def test_struct_layouts_match_header_sizes():
+	assert ctypes.sizeof(_lib.ARConfigC) == 14 * 4
+	assert ctypes.sizeof(_lib.DiffConfigC) == 7 * 4
+	assert ctypes.sizeof(_lib.StepC) == 8 + 9 * 4 + 2 * 4 + 4      # int64 + 9 floats + 2 ints, padded to 8
+	assert ctypes.sizeof(_lib.WeightView) == 8 + 8 + 8 + 32
+
+
+@pytest.mark.parametrize("steps", [4, 30, 80, 200])
+def test_product_schedule_equals_golden(golden, steps):
+	g = golden("schedule")
+	s = D.get_diffuser(steps=steps)
+	assert s.timestep_map == g[f"map_{steps}"].tolist()
+	for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+				"posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+		assert np.array_equal(getattr(s, name), g[f"{name}_{steps}"]), name
+
+
+def test_step_coefs_follow_reference_float_conversions():
+	s = D.get_diffuser(steps=80, cond_free=True)
+	o = O.SpacedSchedule(steps=80, cond_free=True)
+	for i in (0, 1, 40, 79):
+		c = s.step_coefs(i, "ddim")
+		assert c.t == o.timestep_map[i]
+		assert c.sqrt_recip_ac == float(o._f(o.sqrt_recip_alphas_cumprod, i))
+		assert c.sqrt_ac_prev == float(torch.sqrt(o._f(o.alphas_cumprod_prev, i)))
+		assert c.sqrt_1m_ac_prev == float(torch.sqrt(1 - o._f(o.alphas_cumprod_prev, i)))
+		assert abs(c.cfk - 2 * (1 - i / 80)) < 1e-7
+	assert D.get_diffuser(steps=8, cond_free=False).step_coefs(3, "p").cfk < 0
+
+
+@pytest.mark.parametrize("M,T", [(10, 43), (250, 1088), (48, 208), (7, 7), (5, 10), (500, 2176), (1, 4), (13, 5)])
+def test_nearest_index_equals_f_interpolate(M, T):
+	src = torch.arange(M, dtype=torch.float32).view(1, 1, M)
+	ref = F.interpolate(src, size=T, mode="nearest").view(-1).long()
+	assert torch.equal(D.nearest_index(M, T).long(), ref)
+
+
+def test_relbias_table_equals_relative_position_bias():
+	emb = torch.randn(32, 4, generator=torch.Generator().manual_seed(0))
+	tab = D.relbias_table(emb, 64)                       # [H, 129]
+	full = O.rel_pos_bias(emb, 300, 300, 8.0)            # [H, q, k]
+	q = torch.arange(300)[:, None]
+	k = torch.arange(300)[None, :]
+	idx = (k - q).clamp(-64, 64) + 64
+	assert torch.equal(tab[:, idx], full)
+
+
+def test_logits_pipeline_equals_oracle_processing():
+	g = torch.Generator().manual_seed(5)
+	scores = torch.randn(3, 8194, generator=g) * 3
+	ids = torch.randint(0, 8194, (3, 20), generator=g)
+	kw = dict(temperature=0.7, top_k=16, top_p=0.8, repetition_penalty=2.0, suppress_tokens=[8193])
+	pipe = sampling.LogitsPipeline(vocab=8194, device="cpu", **kw)
+	assert torch.equal(pipe(ids, scores), O.process_logits(ids, scores, **kw))
+	pipe = sampling.LogitsPipeline(vocab=8194, device="cpu", temperature=0.8)
+	assert not pipe.needs_history and torch.equal(pipe(None, scores), O.process_logits(ids, scores, temperature=0.8))
+
+
+def test_synthetic_weights_are_deterministic_and_complete():
+	a = W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 3)
+	b = W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 3)
+	assert all(torch.equal(a[k], b[k]) for k in a)
+	assert W.n_params(W.ar_shapes(W.AR_FULL)) == 395978754 and W.n_params(W.diffusion_shapes(W.DIFF_FULL)) > 150e6
+	r = W.synth_state_dict(W.diffusion_shapes(W.DIFF_SMALL), 3, bf16_exact=True)
+	assert torch.equal(r["layers.0.attn.qkv.weight"], r["layers.0.attn.qkv.weight"].bfloat16().float())
+	assert r["layers.0.attn.proj_out.weight"].abs().max() > 0     # the reference's zero init would hide the attention
+
+
+def test_product_path_has_no_cpu_fallback():
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	sd = W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 3)
+	with pytest.raises(_lib.TTKError):
+		UnifiedVoice(sd, W.AR_SMALL, device="cpu")
+	src = "".join(open(os.path.join(ROOT, "tortoise_tts_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "tortoise_tts_amd")) if f.endswith(".py"))
+	assert "tortoise_oracle" not in src and "import oracle" not in src
