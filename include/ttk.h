@@ -38,6 +38,15 @@ typedef struct {
 int ttk_version(void);
 const char* ttk_last_error(void);   /* thread-local text of the last failure */
 
+/* Per-kernel timing for the roofline report (no reference counterpart: the reference has no profiling of its own,
+ * SURVEY.md section 5).  Between begin and end every libttk kernel launch is bracketed by HIP events on its own stream and
+ * tallied per kernel kind together with its algorithmic work.  Do not capture graphs while enabled.
+ * kinds: 0 gemm (flop), 1 skinny gemm (bytes), 2 attention fwd (flop), 3 decode attention (bytes), 4 groupnorm stats (bytes),
+ *        5 groupnorm apply (bytes), 6 layernorm (bytes)                                                                 */
+typedef struct { double ms; int64_t launches; double work; } ttk_prof_result;
+int ttk_prof_begin(void);
+int ttk_prof_end(ttk_prof_result* out, int n_kinds);   /* n_kinds >= 7; synchronises the device */
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Autoregressive model: UnifiedVoice + GPT2InferenceModel (tortoise_tts/models/unified_voice.py:98-254, 334-668).   */
 typedef struct ttk_ar ttk_ar;

@@ -41,11 +41,17 @@ class StepC(C.Structure):
 		("sampler", C.c_int), ("nonzero", C.c_int)]
 
 
+class ProfResult(C.Structure):
+	_fields_ = [("ms", C.c_double), ("launches", C.c_int64), ("work", C.c_double)]
+
+
 # every symbol include/ttk.h declares: (restype, argtypes)
 _P, _I, _L = C.c_void_p, C.c_int, C.c_int64
 SYMBOLS = {
 	"ttk_version": (_I, []),
 	"ttk_last_error": (C.c_char_p, []),
+	"ttk_prof_begin": (_I, []),
+	"ttk_prof_end": (_I, [C.POINTER(ProfResult), _I]),
 	"ttk_ar_create": (_I, [C.POINTER(_P), C.POINTER(ARConfigC), C.POINTER(WeightView), _I]),
 	"ttk_ar_destroy": (_I, [_P]),
 	"ttk_ar_prefill": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),

@@ -254,7 +254,7 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
 		p.mode = SK_QKV; p.qbuf = h->qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
 		launch_skinny(dt, p, wv_small, s);
 		AttnDecodeParams a = {};
-		a.qbuf = h->qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = B; a.H = H; a.max_ctx = c.max_ctx; a.out = h->attn_out;
+		a.qbuf = h->qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = B; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = h->attn_out;
 		launch_attn_decode(dt, a, s);
 		p = {};
 		p.Wp = L.proj.wfrag; p.N = d; p.K = d; p.M = B; p.bias = L.proj.bias; p.a = h->attn_out; p.lda = d;

@@ -230,6 +230,7 @@ static void launch_attn_fwd_t(const AttnParams& p, hipStream_t s) {
 	else hipLaunchKernelGGL((k_attn_fwd<T, false, false>), grid, dim3(256), 0, s, p);
 }
 void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s) {
+	ProfScope prof(PROF_ATTN_FWD, 4.0 * p.nb * p.H * (double)p.T * p.T * HD * (p.causal ? 0.5 : 1.0), s);
 	if (dt == DT_BF16) launch_attn_fwd_t<bf16>(p, s);
 	else launch_attn_fwd_t<float>(p, s);
 }
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
 }
 
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {
+	ProfScope prof(PROF_ATTN_DECODE, 2.0 * p.B * p.H * (double)p.ctx_hint * HD * dtype_size(dt), s);
 	dim3 grid(p.H, p.B);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_attn_decode<bf16>), grid, dim3(256), 0, s, p);
 	else hipLaunchKernelGGL((k_attn_decode<float>), grid, dim3(256), 0, s, p);

@@ -60,7 +60,7 @@ static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, c
 	launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);
 	GnApplyParams p = {};
 	p.x = x; p.ms = (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
-	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.act = act; p.out = out; p.out_f32 = out_f32;
+	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.nchunks = gn_num_chunks(T, C); p.act = act; p.out = out; p.out_f32 = out_f32;
 	launch_gn_apply(h->dt, p, s);
 }
 
@@ -92,7 +92,7 @@ static int reserve_ws(ttk_diff* h, int nb, int T) {
 	TTK_TRY(h->a.reserve(rows * C * es)); TTK_TRY(h->qkv.reserve(rows * 3 * C * es)); TTK_TRY(h->ao.reserve(rows * C * es));
 	TTK_TRY(h->h0.reserve(rows * C * es)); TTK_TRY(h->csT.reserve(rows * C * es)); TTK_TRY(h->xcl.reserve(rows * h->in_pad * es));
 	TTK_TRY(h->outb.reserve(rows * h->cfg.out_channels * 4)); TTK_TRY(h->ecl.reserve(rows * C * 4));
-	TTK_TRY(h->ms.reserve((size_t)nb * 64 * 4));
+	TTK_TRY(h->ms.reserve((size_t)nb * 32 * gn_num_chunks(T, (int)C) * 3 * 4));
 	return TTK_OK;
 }
 

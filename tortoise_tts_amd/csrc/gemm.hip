@@ -162,6 +162,7 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
 }
 
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
+	ProfScope prof(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, s);
 	if (dt == DT_BF16) launch_gemm_t<bf16>(p, s);
 	else launch_gemm_t<float>(p, s);
 }

@@ -62,6 +62,7 @@ __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const 
 
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
 					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s) {
+	ProfScope prof(PROF_LAYERNORM, (double)rows * d * (4.0 + (out_f32 ? 4.0 : dtype_size(dt))), s);
 	const int grid = (rows + 3) / 4;
 	if (out_f32 || dt == DT_F32)
 		hipLaunchKernelGGL((k_layernorm<float>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (float*)out, ldo);
@@ -70,33 +71,49 @@ void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, cons
 }
 
 // ---------------------------------------------------------------- GroupNorm32
-// stats: grid (32, nb), 256 threads; two passes over the (T x cpg) slab (mean, then centred sum of squares).
-__global__ void k_gn_stats(const float* x, int T, int C, float* ms) {
-	const int g = blockIdx.x, b = blockIdx.y, cpg = C / 32;
-	const float* base = x + (int64_t)b * T * C + g * cpg;
-	const int n = T * cpg;
+// stats: grid (32 groups, nb, nchunks).  Each workgroup holds its (rows x cpg) chunk (<= 2048 values) in registers, computes the
+// chunk's (count, mean, M2) with an exact two-pass, and writes the triple; the consumer merges the chunk triples with Chan's
+// parallel-variance formula (k_gn_apply), so no second reduction launch and no atomics (bitwise reproducible).
+__global__ __launch_bounds__(256) void k_gn_stats(const float* x, int T, int C, int rows_per_chunk, float* part) {
+	const int g = blockIdx.x, b = blockIdx.y, ch = blockIdx.z, cpg = C / 32;
+	const int t0 = ch * rows_per_chunk;
+	const int rows = min(rows_per_chunk, T - t0);
+	const float* base = x + ((int64_t)b * T + t0) * C + g * cpg;
+	const int n = rows * cpg;
 	__shared__ float sh[4];
+	float v[8];
 	float sum = 0.f;
-	for (int i = threadIdx.x; i < n; i += 256) { const int t = i / cpg, c = i - t * cpg; sum += base[(int64_t)t * C + c]; }
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const int e = threadIdx.x + 256 * i;
+		const int t = e / cpg, c = e - t * cpg;
+		v[i] = e < n ? base[(int64_t)t * C + c] : 0.f;
+		sum += v[i];
+	}
 	sum = wave_sum(sum);
 	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
 	__syncthreads();
 	const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)n;
 	__syncthreads();
 	float sq = 0.f;
-	for (int i = threadIdx.x; i < n; i += 256) { const int t = i / cpg, c = i - t * cpg; const float d = base[(int64_t)t * C + c] - mean; sq += d * d; }
+#pragma unroll
+	for (int i = 0; i < 8; ++i)
+		if (threadIdx.x + 256 * i < n) { const float d = v[i] - mean; sq += d * d; }
 	sq = wave_sum(sq);
 	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		const float var = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)n;
-		ms[(b * 32 + g) * 2 + 0] = mean;
-		ms[(b * 32 + g) * 2 + 1] = rsqrtf(var + 1e-5f);
+		float* o = part + (((int64_t)b * 32 + g) * gridDim.z + ch) * 3;
+		o[0] = (float)n; o[1] = mean; o[2] = sh[0] + sh[1] + sh[2] + sh[3];
 	}
 }
 
-void launch_gn_stats(const float* x, int nb, int T, int C, float* ms, hipStream_t s) {
-	hipLaunchKernelGGL(k_gn_stats, dim3(32, nb), dim3(256), 0, s, x, T, C, ms);
+int gn_rows_per_chunk(int C) { const int r = 2048 / (C / 32); return r < 1 ? 1 : r; }
+int gn_num_chunks(int T, int C) { const int r = gn_rows_per_chunk(C); return (T + r - 1) / r; }
+
+void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStream_t s) {
+	ProfScope prof(PROF_GN_STATS, 4.0 * nb * T * C, s);
+	hipLaunchKernelGGL(k_gn_stats, dim3(32, nb, gn_num_chunks(T, C)), dim3(256), 0, s, x, T, C, gn_rows_per_chunk(C), part);
 }
 
 // apply: one thread per 4 channels of one output row
@@ -111,12 +128,19 @@ __global__ void k_gn_apply(GnApplyParams p) {
 	const int b = (int)(orow / p.Tout), to = (int)(orow - (int64_t)b * p.Tout);
 	const int ti = p.row_idx ? p.row_idx[to] : to;
 	const float4 xv = *(const float4*)(p.x + ((int64_t)b * p.T + ti) * p.C + c);
-	const int cpg = p.C / 32;
+	// merge this group's chunk statistics (Chan et al.): cpg % 4 == 0, so the 4 channels share one group
+	const int g = c / (p.C / 32);
+	const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
+	float nt = 0.f, mean = 0.f;
+	for (int k = 0; k < p.nchunks; ++k) { nt += part[3 * k]; mean += part[3 * k] * part[3 * k + 1]; }
+	mean /= nt;
+	float m2 = 0.f;
+	for (int k = 0; k < p.nchunks; ++k) { const float d = part[3 * k + 1] - mean; m2 += part[3 * k + 2] + part[3 * k] * d * d; }
+	const float rstd = rsqrtf(m2 / nt + 1e-5f);
 	float in[4] = {xv.x, xv.y, xv.z, xv.w}, o[4];
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {
-		const int cc = c + j, g = cc / cpg;
-		const float mean = p.ms[(b * 32 + g) * 2], rstd = p.ms[(b * 32 + g) * 2 + 1];
+		const int cc = c + j;
 		float v = (in[j] - mean) * rstd * p.gamma[cc] + p.beta[cc];
 		if (p.scale) v = v * (1.0f + p.scale[(int64_t)b * p.ss_stride + cc]) + p.shift[(int64_t)b * p.ss_stride + cc];
 		o[j] = apply_act(v, p.act);
@@ -126,6 +150,7 @@ __global__ void k_gn_apply(GnApplyParams p) {
 }
 
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
+	ProfScope prof(PROF_GN_APPLY, (double)p.nb * p.Tout * p.C * (4.0 + (p.out_f32 ? 4.0 : dtype_size(dt))), s);
 	const int64_t total = (int64_t)p.nb * p.Tout * (p.C / 4);
 	const int grid = (int)((total + 255) / 256);
 	if (p.out_f32 || dt == DT_F32) hipLaunchKernelGGL((k_gn_apply<float>), dim3(grid), dim3(256), 0, s, p);

@@ -186,6 +186,8 @@ static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s) {
 
 void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s) {
 	if (waves < 4) waves = 4;
+	// algorithmic bytes: the weight matrix once + bias + the M activation rows in and out
+	ProfScope prof(PROF_SKINNY, (double)p.N * p.K * dtype_size(dt) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, s);
 	if (dt == DT_BF16) launch_skinny_t<bf16>(p, waves, s);
 	else launch_skinny_t<float>(p, waves, s);
 }

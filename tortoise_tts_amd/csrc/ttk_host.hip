@@ -55,9 +55,46 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 	return TTK_OK;
 }
 
+bool g_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double work; };
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_used = 0;
+hipEvent_t pool_get() {
+	if (g_pool_used == g_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); g_pool.push_back(e); }
+	return g_pool[g_pool_used++];
+}
+}  // namespace
+void prof_start(int kind, double work, hipStream_t s) {
+	ProfRec r; r.a = pool_get(); r.b = pool_get(); r.kind = kind; r.work = work;
+	(void)hipEventRecord(r.a, s);
+	g_recs.push_back(r);
+}
+void prof_stop(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); }
+
 }  // namespace ttk
 
 extern "C" {
+int ttk_prof_begin(void) {
+	ttk::g_recs.clear();
+	ttk::g_pool_used = 0;
+	ttk::g_prof_on = true;
+	return TTK_OK;
+}
+int ttk_prof_end(ttk_prof_result* out, int n_kinds) {
+	ttk::g_prof_on = false;
+	TTK_REQUIRE(out && n_kinds >= ttk::PROF_KINDS, TTK_E_ARG, "ttk_prof_end: need room for %d kinds", (int)ttk::PROF_KINDS);
+	TTK_HIP(hipDeviceSynchronize());
+	for (int i = 0; i < n_kinds; ++i) { out[i].ms = 0; out[i].launches = 0; out[i].work = 0; }
+	for (const auto& r : ttk::g_recs) {
+		float ms = 0.f;
+		TTK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+		out[r.kind].ms += ms; out[r.kind].launches += 1; out[r.kind].work += r.work;
+	}
+	ttk::g_recs.clear();
+	return TTK_OK;
+}
 int ttk_version(void) { return TTK_VERSION; }
 const char* ttk_last_error(void) { return ttk::get_error(); }
 }

@@ -10,6 +10,21 @@ namespace ttk {
 enum DType { DT_F32 = 0, DT_BF16 = 1 };
 inline size_t dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
 
+// ---------------------------------------------------------------- per-kernel timing (ttk_host.hip)
+// When enabled (ttk_prof_begin) every launcher brackets its launch with two HIP events on the launch stream and adds its
+// ALGORITHMIC work (flop for MFMA-bound kernels, bytes for HBM-bound ones) to its kind's tally; bench.py turns the
+// tallies into the `roofline` object.  Off by default: zero cost and graph-capture safe.
+enum ProfKind { PROF_GEMM = 0, PROF_SKINNY = 1, PROF_ATTN_FWD = 2, PROF_ATTN_DECODE = 3, PROF_GN_STATS = 4, PROF_GN_APPLY = 5,
+				PROF_LAYERNORM = 6, PROF_KINDS = 7 };
+extern bool g_prof_on;
+void prof_start(int kind, double work, hipStream_t s);
+void prof_stop(hipStream_t s);
+struct ProfScope {
+	hipStream_t s; bool on;
+	ProfScope(int kind, double work, hipStream_t s_) : s(s_), on(g_prof_on) { if (on) prof_start(kind, work, s); }
+	~ProfScope() { if (on) prof_stop(s); }
+};
+
 // ---------------------------------------------------------------- dense GEMM (gemm.hip)
 // C[M,N] = epilogue( sum_seg  shift(A_seg)[M,K] * W_seg[N,K]^T )      ("NT": both operands K-contiguous)
 // Segments express (a) the 3 taps of a k=3 'same' convolution over rows (row shift -1,0,+1 inside each
@@ -64,14 +79,15 @@ void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s);
 // y = LN2?(LN1(x)) per row; out is T or f32
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
 					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s);
-// GroupNorm32 over channels-last x f32 [nb][T][C], 32 groups: stats -> ms[nb][32][2] (mean, rstd)
-void launch_gn_stats(const float* x, int nb, int T, int C, float* ms, hipStream_t s);
+// GroupNorm32 over channels-last x f32 [nb][T][C], 32 groups: per-chunk statistics part[nb][32][nchunks][3] = (count, mean, M2)
+int gn_num_chunks(int T, int C);
+void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStream_t s);
 // y[nb][Tout][C] (T-typed or f32) = act( gn(x)*gamma+beta [ *(1+scale[b][c]) + shift[b][c] ] ), optional nearest
 // row gather (row_idx[Tout] into [0,T)) used by timestep_independent's F.interpolate.
 struct GnApplyParams {
 	const float* x; const float* ms; const float* gamma; const float* beta;
 	const float* scale; const float* shift; int64_t ss_stride;   // per-batch stride of scale/shift rows (0 = shared)
-	const int* row_idx; int nb, T, Tout, C; int act; void* out; int out_f32;
+	const int* row_idx; int nb, T, Tout, C; int nchunks; int act; void* out; int out_f32;
 };
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s);
 
@@ -91,6 +107,7 @@ struct AttnDecodeParams {
 	const void* kcache; const void* vcache;   // T [B][H][max_ctx][64]
 	const int* d_pos;         // keys valid = *d_pos + 1
 	int B, H, max_ctx;
+	int ctx_hint;             // host-side copy of the key count (profiling only; stale under graph replay)
 	void* out;                // T [B][H*64]
 };
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s);

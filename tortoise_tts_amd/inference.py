@@ -1,0 +1,87 @@
+"""The hot-path section of `TTS.inference` (/root/reference/tortoise_tts/inference.py:331-413) over the libttk-backed
+modules: AR sampling -> stop-token fix-up -> latent pass -> calm-token trim -> [candidate pick] -> timestep-independent
+conditioning -> DDIM loop -> mel denormalisation.  Everything before (tokenizer, conditioning latents) and after (CLVP,
+vocoder) stays on the reference path and is represented here by its inputs/outputs.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .autoregressive import UnifiedVoice
+from .diffusion import DiffusionTTS, denormalize_tacotron_mel, get_diffuser
+
+CALM_TOKEN = 83
+SAMPLE_RATE = 24_000
+HOP = 256   # BigVGAN 24 kHz / 100-band hop (assumed: its config JSON is download-only)
+
+
+def fix_stop_tokens(codes: torch.Tensor, stop_mel_token: int) -> torch.Tensor:
+	"""inference.py:353-366.  The reference takes `.min()` of the stop positions before checking that any exist (:355 vs
+	:357) and raises on a row without a stop token; such rows are left untouched here (what the check intends)."""
+	codes = codes.clone()
+	is_stop = codes == stop_mel_token
+	has = is_stop.any(dim=1)
+	if not bool(has.any()):
+		return codes
+	L = codes.shape[1]
+	first = torch.where(has, is_stop.float().argmax(dim=1), torch.full_like(has, L, dtype=torch.long))
+	pos = torch.arange(L, device=codes.device)[None, :]
+	codes = torch.where((pos >= first[:, None]) & has[:, None], torch.full_like(codes, 83), codes)
+	tail = torch.tensor([45, 45, 248], device=codes.device, dtype=codes.dtype)
+	codes[has, -3:] = tail
+	return codes
+
+
+def trim_calm_tokens(codes: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
+	"""inference.py:381-389 on row 0: cut the latents at the position where the 9th consecutive calm token sits."""
+	row = codes[0].tolist()            # one host copy instead of a sync per position
+	calm = 0
+	for k, c in enumerate(row):
+		calm = calm + 1 if c == CALM_TOKEN else 0
+		if calm > 8:
+			return latents[:, :k]
+	return latents
+
+
+class TTSHotPath:
+	def __init__(self, autoregressive: UnifiedVoice, diffusion: DiffusionTTS):
+		self.autoregressive, self.diffusion = autoregressive, diffusion
+
+	@torch.inference_mode()
+	def inference(self, text_tokens: torch.Tensor, autoregressive_latents: torch.Tensor, diffusion_latents: torch.Tensor, *,
+				  max_ar_steps=500, max_diffusion_steps=80, ar_temp=0.8, diffusion_temp=1.0, top_p=1.0, top_k=0,
+				  repetition_penalty=1.0, length_penalty=1.0, diffusion_sampler="ddim", cond_free=True, candidates=1,
+				  suppress_tokens=None, return_all=False):
+		"""text_tokens [1, Tt] int64; latents from the reference's conditioning encoders ([1,1024], [1,2048]).
+		Returns the denormalised mel [1, 100, T] (input of the vocoder) and the audio seconds it represents."""
+		ar, diff = self.autoregressive, self.diffusion
+		dev = ar.device
+		text_tokens = text_tokens.to(dev)
+		diffuser = get_diffuser(steps=max_diffusion_steps, cond_free=cond_free)
+		extra = {"suppress_tokens": suppress_tokens} if suppress_tokens else {}
+		codes = ar.inference_speech(autoregressive_latents, text_tokens, do_sample=True, top_k=top_k, top_p=top_p,
+									temperature=ar_temp, num_return_sequences=candidates, num_beams=1,
+									length_penalty=length_penalty, repetition_penalty=repetition_penalty,
+									max_generate_length=max_ar_steps, **extra)
+		codes = fix_stop_tokens(codes, ar.stop_mel_token)
+		B, M = codes.shape
+		wav_lengths = torch.tensor([M * ar.mel_length_compression])
+		text_lengths = torch.tensor([text_tokens.shape[1]], dtype=torch.int32)
+		latents = ar.forward(autoregressive_latents.expand(B, -1) if autoregressive_latents.shape[0] != B else autoregressive_latents,
+							 text_tokens.expand(B, -1), text_lengths.expand(B), codes, wav_lengths.expand(B),
+							 return_latent=True, clip_inputs=False)
+		latents = trim_calm_tokens(codes, latents)
+		# CLVP scoring (reference path) would reorder candidates here (inference.py:392-396); off-path: candidate 0
+		latents = latents[:1]
+		T = latents.shape[1] * 4 * 24000 // 22050
+		E = diff.timestep_independent(latents, diffusion_latents, T, False)
+		noise = torch.randn((1, 100, T), device=dev) * diffusion_temp
+		mel = diffuser.sample_loop(diff, (1, 100, T), sampler=diffusion_sampler, noise=noise,
+								   model_kwargs={"precomputed_aligned_embeddings": E}, progress=False)
+		mels = denormalize_tacotron_mel(mel)[:, :, :T]
+		seconds = T * HOP / SAMPLE_RATE
+		if return_all:
+			return mels, seconds, dict(codes=codes, latents=latents, E=E, noise=noise, mel=mel)
+		return mels, seconds

@@ -1,0 +1,52 @@
+"""Roofline bookkeeping for bench.py: per-kernel-kind HIP-event timing collected inside libttk (ttk_prof_begin / ttk_prof_end)
+over one instrumented pass of the benchmark step, reduced to the `roofline` object of the dominant kernel.
+
+Peaks (MI355X_MICROARCH.md, chip-level parameters): HBM3E 8.0 TB/s spec; dense MFMA 2.5 PFLOP/s bf16, 157.3 TFLOP/s f32.
+`achieved` = algorithmic work of the kind (flop or bytes, summed over its launches) / summed launch duration, i.e. the
+duration-weighted average over the launches of that kernel in one benchmark step.
+"""
+from __future__ import annotations
+
+from . import _lib
+
+KINDS = ["gemm", "skinny_gemm", "attn_fwd", "attn_decode", "groupnorm_stats", "groupnorm_apply", "layernorm"]
+KERNEL_NAMES = {"gemm": "ttk::k_gemm", "skinny_gemm": "ttk::k_skinny", "attn_fwd": "ttk::k_attn_fwd", "attn_decode": "ttk::k_attn_decode",
+				"groupnorm_stats": "ttk::k_gn_stats", "groupnorm_apply": "ttk::k_gn_apply", "layernorm": "ttk::k_layernorm"}
+MFMA_BOUND = {"gemm", "attn_fwd"}
+PEAK_TFLOPS = {_lib.TTK_BF16: 2500.0, _lib.TTK_F32: 157.3}
+PEAK_HBM_GBS = 8000.0
+
+
+def collect(step_fn, ar=None):
+	"""Run step_fn once with per-launch timing on; returns {kind: dict(ms, launches, work)}."""
+	import torch
+	lib = _lib.load()
+	saved = None
+	if ar is not None:
+		saved, ar.use_graph = ar.use_graph, False      # events cannot be recorded inside a captured graph
+	torch.cuda.synchronize()
+	_lib.check(lib.ttk_prof_begin(), "ttk_prof_begin")
+	try:
+		step_fn()
+	finally:
+		res = (_lib.ProfResult * len(KINDS))()
+		rc = lib.ttk_prof_end(res, len(KINDS))
+		if ar is not None:
+			ar.use_graph = saved
+	_lib.check(rc, "ttk_prof_end")
+	return {k: dict(ms=res[i].ms, launches=int(res[i].launches), work=res[i].work) for i, k in enumerate(KINDS)}
+
+
+def dominant_kernel_roofline(step_fn, ar, df):
+	table = collect(step_fn, ar)
+	kind = max(table, key=lambda k: table[k]["ms"])
+	r = table[kind]
+	sec = r["ms"] * 1e-3
+	breakdown = {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in table.items()}
+	if kind in MFMA_BOUND:
+		achieved, peak, unit, bound = r["work"] / sec / 1e12, PEAK_TFLOPS[df.dtype], "TFLOP/s", "mfma"
+	else:
+		achieved, peak, unit, bound = r["work"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+	return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": None,
+			"kernel": KERNEL_NAMES[kind], "launches_per_step": r["launches"], "avg_launch_us": 1e3 * r["ms"] / max(r["launches"], 1),
+			"algorithmic_work_per_launch": r["work"] / max(r["launches"], 1), "per_kernel_ms": breakdown}
