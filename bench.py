@@ -48,7 +48,12 @@ def cpu_baseline(seed):
 	sys.path.insert(0, os.path.join(ROOT, "oracle"))
 	import tortoise_oracle as O
 	from tortoise_tts_amd import weights as W
-	cores = os.cpu_count() or 1
+	# the GPU box gives a 1-GPU job a 16-core share whatever os.cpu_count() says; oversubscribing it is pathologically slow
+	try:
+		cores = len(os.sched_getaffinity(0))
+	except AttributeError:
+		cores = os.cpu_count() or 1
+	cores = max(1, min(cores, 16))
 	torch.set_num_threads(cores)
 	g = torch.Generator().manual_seed(seed)
 	with torch.inference_mode():
@@ -81,6 +86,10 @@ def cpu_baseline(seed):
 	return {"value": audio / est, "unit": "audio-sec/wall-sec", "cores": cores, "kind": "port",
 			"sample": f"prefill + 2 decode steps at B=16 (x125) + 1 DDIM step at T={Ts} scaled by F(T) to T={T} x80; "
 					  f"measured {t_prefill:.2f}s + {t_dec * 1e3:.0f} ms/decode-step + {t_step:.2f} s/DDIM-step; latent pass not included"}
+
+
+def log(msg):
+	print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -127,9 +136,11 @@ def main():
 			dist.barrier()
 		torch.cuda.synchronize()
 
+	log("models built; warmup")
 	for _ in range(a.warmup):
 		step()
 	fence()
+	log("timed region")
 	t0 = time.perf_counter()
 	audio = 0.0
 	for _ in range(a.steps):
@@ -141,10 +152,12 @@ def main():
 		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 	dt = float(tmax.item())
 
+	log(f"timed {a.steps} steps in {dt:.3f}s")
 	roof = None
 	if rank == 0 and not a.no_roofline:
 		from tortoise_tts_amd import profiling
 		roof = profiling.dominant_kernel_roofline(lambda: step(), ar, df)
+	log("roofline pass done; cpu baseline")
 	cpu = None
 	if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:
 		cpu = cpu_baseline(1234)
