@@ -141,7 +141,7 @@ static void head_launch(ttk_ar* h, int B, float* logits, float* hidden_out, hipS
 	p.ln_count = 2; p.x = h->x; p.ldx = h->cfg.model_dim;
 	p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hidden_out;
 	p.mode = SK_STORE_F32; p.out_f32 = logits; p.ldc = h->cfg.number_mel_codes;
-	launch_skinny(h->dt, p, 4, s);
+	launch_skinny(h->dt, p, h->cfg.model_dim >= 1024 ? 8 : 4, s);
 }
 
 extern "C" {
@@ -243,7 +243,7 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)
 	launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s);
-	const int wv_small = d >= 1024 ? 4 : 4;
+	const int wv_small = d >= 1024 ? 8 : 4;   // waves per workgroup that split K = d
 	for (int l = 0; l < c.layers; ++l) {
 		const ARLayer& L = h->L[l];
 		char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * h->es;

@@ -6,14 +6,107 @@
 //   k=3 convs (inp_block, latent_conditioner.0, out_layers.3, out.2 = 3 row-shifted segments, zero padded at the
 //   edges of each batch element), emb_layers / time_embed linears.   (/root/reference/tortoise_tts/models/diffusion.py:1316-1376,1517-1574)
 //
-// Tiling: 256 threads = 4 waves (2x2), BMxBN block tile, 128-byte-row LDS tiles (64 bf16 / 32 f32 of K),
-// XOR-swizzled 16-byte chunks, double-buffered LDS with register-staged prefetch (global loads of tile k+1 in
-// flight under the MFMAs of tile k; one barrier per tile), 16x16 MFMA sub-tiles, f32 accumulate.
+// Tiling: 256 threads = 4 waves (2x2), BMxBN block tile, 128-byte-row LDS tiles (64 bf16 / 32 f32 of K) with XOR-swizzled
+// 16-byte chunks, 16x16 MFMA sub-tiles, f32 accumulate.  Operand staging is direct-to-LDS (`global_load_lds_dwordx4`, one
+// 1-KiB piece = 8 tile rows per wave instruction) into a 3-stage ring: tile k+2 is requested while tile k is multiplied, a
+// counted `s_waitcnt vmcnt(N)` leaves one tile in flight across the single raw `s_barrier` of each k-step
+// (cdna_hip_programming.md section 5 "Pipelining across barriers").  The swizzle lives on the per-lane SOURCE address (LDS
+// destination of a glds is lane-linear); rows outside M or outside a conv tap's batch element read a zero page instead.
 // Roofline: MFMA-bound for the diffusion shapes (M = b*T ~ 2k rows, N,K in 1k..3k); bytes/flop is tiny.
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
 namespace ttk {
+
+__device__ uint4 g_zero_page[16];   // 256 B of zeros: source of out-of-range tile rows
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024).
+// Issued from inline asm on purpose: hipcc's waitcnt pass would otherwise put `s_waitcnt vmcnt(0)` in front of the first ds_read
+// of every k-step (it cannot prove that the ring stage being read is not the one being filled) and serialise the ring; hidden
+// from it, the only vmcnt waits in the k-loop are the counted ones below (cdna_hip_programming.md section 5.7, items 1-2).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+				 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+	return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Accumulator (i, j) register r is row row0 + 16i + 4*(lane>>4) + r, column col0 + 16j + (lane&15).
+// MODE 0: T-typed C; 1: f32 C (+ f32 residual, which may alias C); 2: f32 C transposed to [batch][N][rows_per_batch].
+// All residual/bias loads are issued before the first store: with C aliasing the residual a load-store-load-store order would
+// serialise 64 dependent L2 round trips per lane.  GUARD = tile crosses the M or N edge.
+template <typename T, int MODE, bool GUARD, int MI, int NI>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int row0, int col0, int lane) {
+	const int lr = 4 * (lane >> 4), lc = lane & 15;
+	float bj[NI];
+#pragma unroll
+	for (int j = 0; j < NI; ++j) {
+		const int gn = col0 + 16 * j + lc;
+		bj[j] = (p.bias && (!GUARD || gn < p.N)) ? p.bias[gn] : 0.f;
+	}
+	// bias, then the activation under ONE uniform branch (not one per element)
+#pragma unroll
+	for (int i = 0; i < MI; ++i)
+#pragma unroll
+		for (int j = 0; j < NI; ++j)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) acc[i][j][r] += bj[j];
+	if (p.act == ACT_GELU_NEW) {
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int j = 0; j < NI; ++j)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) acc[i][j][r] = gelu_new_f(acc[i][j][r]);
+	} else if (p.act == ACT_SILU) {
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int j = 0; j < NI; ++j)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
+	}
+	float res[MI][4][NI];
+	if (MODE == 1 && p.residual) {
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int j = 0; j < NI; ++j) {
+					const int gm = row0 + 16 * i + lr + r, gn = col0 + 16 * j + lc;
+					res[i][r][j] = (!GUARD || (gm < p.M && gn < p.N)) ? p.residual[(int64_t)gm * p.ldr + gn] : 0.f;
+				}
+	} else {
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int j = 0; j < NI; ++j) res[i][r][j] = 0.f;
+	}
+#pragma unroll
+	for (int i = 0; i < MI; ++i) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int gm = row0 + 16 * i + lr + r;
+			int bb = 0, t = 0;
+			if (MODE == 2) { bb = gm / p.rows_per_batch; t = gm - bb * p.rows_per_batch; }
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				const int gn = col0 + 16 * j + lc;
+				if (GUARD && (gm >= p.M || gn >= p.N)) continue;
+				const float v = acc[i][j][r] + res[i][r][j];
+				if (MODE == 2) ((float*)p.C)[((int64_t)bb * p.N + gn) * p.rows_per_batch + t] = v;
+				else if (MODE == 1) ((float*)p.C)[(int64_t)gm * p.ldc + gn] = v;
+				else ((T*)p.C)[(int64_t)gm * p.ldc + gn] = cvt<T>(v);
+			}
+		}
+	}
+}
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
@@ -23,59 +116,65 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
 	constexpr int FCH = 8 * ES / 16;   // 16-byte chunks per fragment
 	constexpr int EPC = 16 / ES;       // elements per chunk
 	constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-	constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+	constexpr int A_PC = BM / 8 / 4, B_PC = BN / 8 / 4;   // 1-KiB pieces per wave per tile
+	constexpr int PER_TILE = A_PC + B_PC;                  // glds instructions per wave per tile
+	constexpr int STAGE = (BM + BN) * 128;
+	constexpr int NSTAGE = 3;
 	typedef typename Frag<T>::type FragT;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave >> 1, wn = wave & 1;
 	const int tiles_m = (p.M + BM - 1) / BM;
 	const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * BN;
 	const int KT = p.K / BKE;
 	const int NTILES = p.nseg * KT;
 
-	uint4 ra[A_CH], rb[B_CH];
-	int trow[A_CH];   // row index inside its batch element (for shifted segments)
+	// this lane's row / chunk inside a piece, and the (fixed) rows it stages
+	const int prow = lane >> 3, pslot = lane & 7;
+	int a_gm[A_PC], a_t[A_PC];
 #pragma unroll
-	for (int i = 0; i < A_CH; ++i) {
-		const int gm = m0 + ((tid + 256 * i) >> 3);
-		trow[i] = p.rows_per_batch > 0 ? gm % p.rows_per_batch : 0;
+	for (int i = 0; i < A_PC; ++i) {
+		a_gm[i] = m0 + 8 * (wave + 4 * i) + prow;
+		a_t[i] = p.rows_per_batch > 0 ? a_gm[i] % p.rows_per_batch : 0;
 	}
+	const char* zero = (const char*)g_zero_page;
+	const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
 
-	auto load_tile = [&](int kt) {
-		const int sg = kt / KT;
-		const int k0 = (kt - sg * KT) * BKE;
+	// per-piece source cursors of the current segment: advance 128 B per k-tile (0 for zero-page rows)
+	const char* a_src[A_PC]; int a_inc[A_PC];
+	const char* b_src[B_PC];
+	int seg_i = 0, kk_i = 0;
+	auto set_segment = [&](int sg) {
 		const T* Ab = (const T*)p.seg[sg].A;
 		const int64_t lda = p.seg[sg].lda;
 		const int shift = p.seg[sg].shift;
 		const T* Wb = (const T*)p.W + p.seg[sg].w_off;
 #pragma unroll
-		for (int i = 0; i < A_CH; ++i) {
-			const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-			const int gm = m0 + row;
-			bool ok = gm < p.M;
-			if (shift != 0) { const int t = trow[i] + shift; ok = ok && t >= 0 && t < p.rows_per_batch; }
-			ra[i] = ok ? *(const uint4*)(Ab + (int64_t)(gm + shift) * lda + k0 + c * EPC) : make_uint4(0, 0, 0, 0);
+		for (int i = 0; i < A_PC; ++i) {
+			const int row = 8 * (wave + 4 * i) + prow;        // row inside the tile
+			const int c = pslot ^ (row & 7);                   // logical chunk landing in this lane's slot
+			const int t = a_t[i] + shift;
+			const bool ok = a_gm[i] < p.M && (shift == 0 || (t >= 0 && t < p.rows_per_batch));
+			a_src[i] = ok ? (const char*)(Ab + (int64_t)(a_gm[i] + shift) * lda + c * EPC) : zero;
+			a_inc[i] = ok ? 128 : 0;
 		}
 #pragma unroll
-		for (int i = 0; i < B_CH; ++i) {
-			const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-			rb[i] = *(const uint4*)(Wb + (int64_t)(n0 + row) * p.ldw + k0 + c * EPC);
+		for (int i = 0; i < B_PC; ++i) {
+			const int row = 8 * (wave + 4 * i) + prow;
+			const int c = pslot ^ (row & 7);
+			b_src[i] = (const char*)(Wb + (int64_t)(n0 + row) * p.ldw + c * EPC);
 		}
 	};
-	auto store_tile = [&](int buf) {
-		char* As = smem + buf * (BM + BN) * 128;
-		char* Bs = As + BM * 128;
+	auto issue = [&](int stage) {   // requests the next tile in (segment, k) order
+		if (kk_i == 0) set_segment(seg_i);
+		const unsigned As = smem_base + stage * STAGE;
+		const unsigned Bs = As + BM * 128;
 #pragma unroll
-		for (int i = 0; i < A_CH; ++i) {
-			const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-			*(uint4*)(As + row * 128 + ((c ^ (row & 7)) << 4)) = ra[i];
-		}
+		for (int i = 0; i < A_PC; ++i) { glds16(a_src[i], As + (wave + 4 * i) * 1024); a_src[i] += a_inc[i]; }
 #pragma unroll
-		for (int i = 0; i < B_CH; ++i) {
-			const int id = tid + 256 * i, row = id >> 3, c = id & 7;
-			*(uint4*)(Bs + row * 128 + ((c ^ (row & 7)) << 4)) = rb[i];
-		}
+		for (int i = 0; i < B_PC; ++i) { glds16(b_src[i], Bs + (wave + 4 * i) * 1024); b_src[i] += 128; }
+		if (++kk_i == KT) { kk_i = 0; ++seg_i; }
 	};
 
 	f32x4 acc[MI][NI];
@@ -84,8 +183,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
 #pragma unroll
 		for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-	auto compute = [&](int buf) {
-		const char* As = smem + buf * (BM + BN) * 128;
+	auto compute = [&](int stage) {
+		const char* As = smem + stage * STAGE;
 		const char* Bs = As + BM * 128;
 #pragma unroll
 		for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -110,54 +209,41 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
 		}
 	};
 
-	load_tile(0);
-	store_tile(0);
-	__syncthreads();
+	issue(0);
+	if (NTILES > 1) issue(1);
+	int stage = 0;
 	for (int kt = 0; kt < NTILES; ++kt) {
-		const int buf = kt & 1;
-		if (kt + 1 < NTILES) load_tile(kt + 1);
-		compute(buf);
-		if (kt + 1 < NTILES) store_tile(buf ^ 1);
-		__syncthreads();
+		// tile kt has landed for this wave (the younger tile kt+1 may stay in flight) ...
+		if (kt + 1 < NTILES) wait_vmcnt<PER_TILE>(); else wait_vmcnt<0>();
+		// ... and, after the barrier, for every wave; every wave has also finished reading stage (kt-1)%3 = (kt+2)%3
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+		if (kt + 2 < NTILES) issue(stage == 0 ? 2 : stage - 1);
+		compute(stage);
+		stage = stage == 2 ? 0 : stage + 1;
 	}
 
-	// epilogue: accumulator (i, j) register r is row 16i + 4*(lane>>4) + r, column 16j + (lane&15)
-#pragma unroll
-	for (int i = 0; i < MI; ++i) {
-#pragma unroll
-		for (int r = 0; r < 4; ++r) {
-			const int gm = m0 + wm * WM + 16 * i + 4 * (lane >> 4) + r;
-			if (gm >= p.M) continue;
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				const int gn = n0 + wn * WN + 16 * j + (lane & 15);
-				if (gn >= p.N) continue;
-				float v = acc[i][j][r];
-				if (p.bias) v += p.bias[gn];
-				v = apply_act(v, p.act);
-				if (p.residual) v += p.residual[(int64_t)gm * p.ldr + gn];
-				if (p.transpose_out) {
-					const int bb = gm / p.rows_per_batch, t = gm - bb * p.rows_per_batch;
-					((float*)p.C)[((int64_t)bb * p.N + gn) * p.rows_per_batch + t] = v;
-				} else if (p.out_f32) {
-					((float*)p.C)[(int64_t)gm * p.ldc + gn] = v;
-				} else {
-					((T*)p.C)[(int64_t)gm * p.ldc + gn] = cvt<T>(v);
-				}
-			}
-		}
-	}
+	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
+	const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+	if (p.transpose_out) { if (full) epilogue<T, 2, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 2, true, MI, NI>(p, acc, row0, col0, lane); }
+	else if (p.out_f32) { if (full) epilogue<T, 1, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 1, true, MI, NI>(p, acc, row0, col0, lane); }
+	else { if (full) epilogue<T, 0, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 0, true, MI, NI>(p, acc, row0, col0, lane); }
 }
 
 template <typename T>
 static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
+	static bool attr_set = false;
+	if (!attr_set) {   // 96 KiB of dynamic LDS for the 3-stage 128x128 ring
+		(void)hipFuncSetAttribute((const void*)k_gemm<T, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * 128);
+		attr_set = true;
+	}
 	const int t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
 	if (t128 >= 192) {
 		const int grid = t128;
-		hipLaunchKernelGGL((k_gemm<T, 128, 128>), dim3(grid), dim3(256), 2 * 256 * 128, s, p);
+		hipLaunchKernelGGL((k_gemm<T, 128, 128>), dim3(grid), dim3(256), 3 * 256 * 128, s, p);
 	} else {
 		const int grid = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-		hipLaunchKernelGGL((k_gemm<T, 64, 64>), dim3(grid), dim3(256), 2 * 128 * 128, s, p);
+		hipLaunchKernelGGL((k_gemm<T, 64, 64>), dim3(grid), dim3(256), 3 * 128 * 128, s, p);
 	}
 }
 

@@ -20,8 +20,10 @@
 
 namespace ttk {
 
-template <typename T, int MT, bool LN>
-__global__ void k_skinny(SkinnyParams p) {
+// KC = float4 chunks of a row per lane in the LayerNorm prologue (K <= 256 * KC); LN kernels run <= 8 waves (2 per SIMD,
+// 256 VGPRs), plain ones up to 16.
+template <typename T, int MT, bool LN, int KC>
+__global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	typedef typename Frag<T>::type FragT;
 	constexpr int ES = sizeof(T);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -32,71 +34,92 @@ __global__ void k_skinny(SkinnyParams p) {
 	char* a_lds = smem;
 	float* red = (float*)(smem + (LN ? 16 * MT * RS : 0));
 
-	if (LN) {
-		// rows distributed over waves; each lane owns float4 chunks lane, lane+64, ... of the row (K <= 2048)
-		for (int r = wave; r < 16 * MT; r += nw) {
-			float4 v[8];
-			const int nchunk = p.K / 4;
+	// Order of the memory requests matters (vmcnt retires in order): first the activation rows this wave normalises, then
+	// its whole first batch of weight fragments, so the HBM latency of the weights hides behind the LayerNorm arithmetic.
+	constexpr int RP = 2;                                // rows per LayerNorm pass of a wave
+	const int nchunk = p.K / 4;
+	float4 v[RP][KC];
+	auto ln_load = [&](int r0) {
+#pragma unroll
+		for (int j = 0; j < RP; ++j) {
+			const int r = r0 + j * nw;
 			const bool live = r < p.M;
-			float sum = 0.f;
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
+			for (int i = 0; i < KC; ++i) {
 				const int c = lane + 64 * i;
-				v[i] = (live && c < nchunk) ? *(const float4*)(p.x + (int64_t)r * p.ldx + 4 * c) : make_float4(0, 0, 0, 0);
-				sum += v[i].x + v[i].y + v[i].z + v[i].w;
+				v[j][i] = (live && c < nchunk) ? *(const float4*)(p.x + (int64_t)r * p.ldx + 4 * c) : make_float4(0, 0, 0, 0);
 			}
-			const float* gs[2] = {p.g1, p.g2};
-			const float* bs[2] = {p.b1, p.b2};
-			for (int pass = 0; pass < p.ln_count; ++pass) {
-				if (pass > 0) {
-					sum = 0.f;
+		}
+	};
+	auto ln_finish = [&](int r0) {
 #pragma unroll
-					for (int i = 0; i < 8; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
-				}
+		for (int j = 0; j < RP; ++j) {
+			const int r = r0 + j * nw;
+			if (r >= 16 * MT) continue;
+			const bool live = r < p.M;
+			for (int pass = 0; pass < p.ln_count; ++pass) {
+				const float* gp = pass ? p.g2 : p.g1;
+				const float* bp = pass ? p.b2 : p.b1;
+				float sum = 0.f;
+#pragma unroll
+				for (int i = 0; i < KC; ++i) sum += v[j][i].x + v[j][i].y + v[j][i].z + v[j][i].w;
 				const float mean = wave_sum(sum) / (float)p.K;
 				float sq = 0.f;
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
+				for (int i = 0; i < KC; ++i) {
 					if (lane + 64 * i < nchunk) {
-						const float a = v[i].x - mean, b = v[i].y - mean, c2 = v[i].z - mean, d = v[i].w - mean;
-						sq += a * a + b * b + c2 * c2 + d * d;
+						const float a0 = v[j][i].x - mean, a1 = v[j][i].y - mean, a2 = v[j][i].z - mean, a3 = v[j][i].w - mean;
+						sq += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
 					}
 				}
 				const float rstd = rsqrtf(wave_sum(sq) / (float)p.K + 1e-5f);
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
+				for (int i = 0; i < KC; ++i) {
 					const int c = lane + 64 * i;
 					if (c < nchunk) {
-						const float4 g = *(const float4*)(gs[pass] + 4 * c), b = *(const float4*)(bs[pass] + 4 * c);
-						v[i].x = (v[i].x - mean) * rstd * g.x + b.x;
-						v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
-						v[i].z = (v[i].z - mean) * rstd * g.z + b.z;
-						v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
+						const float4 g = *(const float4*)(gp + 4 * c), b = *(const float4*)(bp + 4 * c);
+						v[j][i].x = (v[j][i].x - mean) * rstd * g.x + b.x;
+						v[j][i].y = (v[j][i].y - mean) * rstd * g.y + b.y;
+						v[j][i].z = (v[j][i].z - mean) * rstd * g.z + b.z;
+						v[j][i].w = (v[j][i].w - mean) * rstd * g.w + b.w;
 					}
 				}
 			}
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
+			for (int i = 0; i < KC; ++i) {
 				const int c = lane + 64 * i;
 				if (c < nchunk) {
 					T* dst = (T*)(a_lds + r * RS) + 4 * c;
-					dst[0] = cvt<T>(live ? v[i].x : 0.f);
-					dst[1] = cvt<T>(live ? v[i].y : 0.f);
-					dst[2] = cvt<T>(live ? v[i].z : 0.f);
-					dst[3] = cvt<T>(live ? v[i].w : 0.f);
-					if (p.ln_out && nt == 0 && live) *(float4*)(p.ln_out + (int64_t)r * p.K + 4 * c) = v[i];
+					dst[0] = cvt<T>(live ? v[j][i].x : 0.f);
+					dst[1] = cvt<T>(live ? v[j][i].y : 0.f);
+					dst[2] = cvt<T>(live ? v[j][i].z : 0.f);
+					dst[3] = cvt<T>(live ? v[j][i].w : 0.f);
+					if (p.ln_out && nt == 0 && live) *(float4*)(p.ln_out + (int64_t)r * p.K + 4 * c) = v[j][i];
 				}
 			}
 		}
+	};
+	if (LN) ln_load(wave);
+
+	// ---- this wave's K slice of the weights; the first PRE fragments are requested now
+	const int ks0 = (KS * wave) / nw, ks1 = (KS * (wave + 1)) / nw;
+	const FragT* wp = (const FragT*)p.Wp + ((int64_t)nt * KS) * 64 + lane;
+	constexpr int PRE = 8;   // 8 x 1 KiB (bf16) in flight per wave
+	FragT bpre[PRE];
+	const int npre = min(ks1 - ks0, PRE);
+#pragma unroll
+	for (int u = 0; u < PRE; ++u)
+		if (u < npre) bpre[u] = __builtin_nontemporal_load(wp + (int64_t)(ks0 + u) * 64);
+
+	if (LN) {
+		ln_finish(wave);
+		for (int r0 = wave + RP * nw; r0 < 16 * MT; r0 += RP * nw) { ln_load(r0); ln_finish(r0); }
 		__syncthreads();
 	}
 
-	// ---- stream this wave's K slice
-	const int ks0 = (KS * wave) / nw, ks1 = (KS * (wave + 1)) / nw;
 	f32x4 acc[MT];
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-	const FragT* wp = (const FragT*)p.Wp + ((int64_t)nt * KS) * 64 + lane;
 	const int arow = lane & 15, ag = lane >> 4;
 	auto load_a = [&](int mt, int ks) -> FragT {
 		if (LN) {
@@ -111,8 +134,14 @@ __global__ void k_skinny(SkinnyParams p) {
 			return *(const FragT*)((const T*)p.a + (int64_t)row * p.lda + 32 * ks + 8 * ag);
 		}
 	};
-	constexpr int UN = 8;   // weight fragments in flight per wave (8 x 1 KiB bf16)
-	int ks = ks0;
+#pragma unroll
+	for (int u = 0; u < PRE; ++u)
+		if (u < npre) {
+#pragma unroll
+			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks0 + u), bpre[u], acc[mt]);
+		}
+	constexpr int UN = 8;
+	int ks = ks0 + npre;
 	for (; ks + UN <= ks1; ks += UN) {
 		FragT b[UN];
 #pragma unroll
@@ -169,11 +198,17 @@ static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
 	const int grid = (p.N + 15) / 16;
 	const size_t red = (size_t)waves * MT * 64 * 4 * sizeof(float);
 	if (p.ln_count > 0) {
-		const size_t lds = (size_t)16 * MT * (p.K * sizeof(T) + 16) + red;
-		if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL((k_skinny<T, MT, true>), dim3(grid), dim3(64 * waves), lds, s, p);
+		if (waves > 8) waves = 8;
+		const size_t lds = (size_t)16 * MT * (p.K * sizeof(T) + 16) + (size_t)waves * MT * 64 * 4 * sizeof(float);
+		if (p.K <= 1024) {
+			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL((k_skinny<T, MT, true, 4>), dim3(grid), dim3(64 * waves), lds, s, p);
+		} else {
+			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL((k_skinny<T, MT, true, 8>), dim3(grid), dim3(64 * waves), lds, s, p);
+		}
 	} else {
-		hipLaunchKernelGGL((k_skinny<T, MT, false>), dim3(grid), dim3(64 * waves), red, s, p);
+		hipLaunchKernelGGL((k_skinny<T, MT, false, 1>), dim3(grid), dim3(64 * waves), red, s, p);
 	}
 }
 

@@ -51,12 +51,14 @@ __device__ __forceinline__ float wave_max(float v) {
 	return v;
 }
 
-__device__ __forceinline__ float gelu_new_f(float x) {   // HF:activations.py:59-66
-	const float k = 0.7978845608028654f;
-	return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+// Branch-free activations on the hardware exp (v_exp_f32, ~1 ulp): they sit in GEMM epilogues, 64 values per lane.
+__device__ __forceinline__ float gelu_new_f(float x) {   // HF:activations.py:59-66; tanh(u) = 1 - 2 / (1 + e^{2u})
+	const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+	const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
+	return 0.5f * x * (1.0f + th);
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_precise(float x) { return silu_f(x); }
 
 enum Act { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_SILU = 2 };
 __device__ __forceinline__ float apply_act(float v, int act) {
