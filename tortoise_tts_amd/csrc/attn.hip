@@ -19,6 +19,7 @@ namespace ttk {
 
 constexpr int HD = 64;
 constexpr float NEG_BIG = -1e30f;
+constexpr float LOG2E = 1.4426950408889634f;
 
 template <typename T> struct VT;   // V^T fragment loader from an LDS tile [64 keys][64 d] with swizzled 16-byte chunks
 template <> struct VT<bf16> {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
 
 	if (BIAS) {
-		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid];
+		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid] * LOG2E;   // scores live in the log2 domain (exp2 = one v_exp_f32)
 	}
 
 	// Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32ks + 8g .. +8], scaled
@@ -152,33 +153,51 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 					for (int qt = 0; qt < 2; ++qt) s[qt][nt] = mma16<T>(kf.v, qf[qt][ks], s[qt][nt]);
 				}
 			}
-			// ---- bias, masks, online softmax (lane owns query column li of each q tile; keys 16nt + 4g + r)
+			// ---- bias, masks, online softmax in the log2 domain (lane owns query column li of each q tile; keys 16nt + 4g + r).
+			// Wave-uniform fast path: a tile with no sequence edge, no causal diagonal and every |key - q| >= 64 (the T5 bucket is
+			// saturated there) needs one fma per score; only the ~3 tiles around the diagonal take the per-element path.
+			const bool edge = k0 + 64 > p.T;
+			const bool diag = CAUSAL && (k0 + 63 > q0);
+			const bool near_band = BIAS && (k0 - (q0 + 31) < 64) && (q0 - (k0 + 63) < 64);
+			const float cbias = BIAS ? (k0 > q0 ? bias_s[128] : bias_s[0]) : 0.f;
 #pragma unroll
 			for (int qt = 0; qt < 2; ++qt) {
 				const int qi = q0 + 16 * qt + li;
 				float tmax = NEG_BIG;
+				if (edge || diag || near_band) {
 #pragma unroll
-				for (int nt = 0; nt < 4; ++nt)
+					for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-					for (int r = 0; r < 4; ++r) {
-						const int key = k0 + 16 * nt + 4 * g + r;
-						float v = s[qt][nt][r];
-						if (BIAS) { int rel = key - qi; rel = rel < -64 ? -64 : (rel > 64 ? 64 : rel); v += bias_s[rel + 64]; }
-						if (key >= p.T || (CAUSAL && key > qi)) v = NEG_BIG;
-						s[qt][nt][r] = v;
-						tmax = fmaxf(tmax, v);
-					}
+						for (int r = 0; r < 4; ++r) {
+							const int key = k0 + 16 * nt + 4 * g + r;
+							float bv = 0.f;
+							if (BIAS) { int rel = key - qi; rel = rel < -64 ? -64 : (rel > 64 ? 64 : rel); bv = bias_s[rel + 64]; }
+							float v = fmaf(s[qt][nt][r], LOG2E, bv);
+							if (key >= p.T || (CAUSAL && key > qi)) v = NEG_BIG;
+							s[qt][nt][r] = v;
+							tmax = fmaxf(tmax, v);
+						}
+				} else {
+#pragma unroll
+					for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							const float v = fmaf(s[qt][nt][r], LOG2E, cbias);
+							s[qt][nt][r] = v;
+							tmax = fmaxf(tmax, v);
+						}
+				}
 				tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
 				tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
 				const float m_new = fmaxf(m_run[qt], tmax);
-				const float alpha = __expf(m_run[qt] - m_new);
+				const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
 				m_run[qt] = m_new;
 				float psum = 0.f;
 #pragma unroll
 				for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
 					for (int r = 0; r < 4; ++r) {
-						const float pv = __expf(s[qt][nt][r] - m_new);
+						const float pv = __builtin_amdgcn_exp2f(s[qt][nt][r] - m_new);
 						s[qt][nt][r] = pv;
 						psum += pv;
 					}

@@ -13,6 +13,8 @@
 // (cdna_hip_programming.md section 5 "Pipelining across barriers").  The swizzle lives on the per-lane SOURCE address (LDS
 // destination of a glds is lane-linear); rows outside M or outside a conv tap's batch element read a zero page instead.
 // Roofline: MFMA-bound for the diffusion shapes (M = b*T ~ 2k rows, N,K in 1k..3k); bytes/flop is tiny.
+#include <stdlib.h>
+
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -109,7 +111,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 }
 
 template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(GemmParams p) {
 	constexpr int ES = sizeof(T);
 	constexpr int BKE = 128 / ES;      // K elements per tile row
 	constexpr int KSTEPS = BKE / 32;   // MFMA k-steps per tile
@@ -230,21 +232,34 @@ __global__ __launch_bounds__(256) void k_gemm(GemmParams p) {
 	else { if (full) epilogue<T, 0, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 0, true, MI, NI>(p, acc, row0, col0, lane); }
 }
 
-template <typename T>
-static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
+template <typename T, int BM, int BN>
+static void launch_tile(const GemmParams& p, hipStream_t s) {
+	constexpr int LDS = 3 * (BM + BN) * 128;
 	static bool attr_set = false;
-	if (!attr_set) {   // 96 KiB of dynamic LDS for the 3-stage 128x128 ring
-		(void)hipFuncSetAttribute((const void*)k_gemm<T, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 256 * 128);
+	if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
+		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_set = true;
 	}
-	const int t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-	if (t128 >= 192) {
-		const int grid = t128;
-		hipLaunchKernelGGL((k_gemm<T, 128, 128>), dim3(grid), dim3(256), 3 * 256 * 128, s, p);
-	} else {
-		const int grid = ((p.M + 63) / 64) * ((p.N + 63) / 64);
-		hipLaunchKernelGGL((k_gemm<T, 64, 64>), dim3(grid), dim3(256), 3 * 128 * 128, s, p);
+	const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+	hipLaunchKernelGGL((k_gemm<T, BM, BN>), dim3(grid), dim3(256), LDS, s, p);
+}
+
+// Tile choice: the diffusion GEMMs are small (M = 2b*T ~ 2k rows), so the grid must cover the 256 CUs; 128x64 tiles run two
+// workgroups per CU (72 KiB LDS, <= 128 VGPRs) so one workgroup's MFMAs overlap the other's staging.
+int g_force_tile = -1;   // TTK_GEMM_TILE=0|1|2 (tuning only)
+template <typename T>
+static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
+	if (g_force_tile < 0) { const char* e = getenv("TTK_GEMM_TILE"); g_force_tile = e ? atoi(e) + 100 : 99; }
+	int tile;
+	if (g_force_tile >= 100) tile = g_force_tile - 100;
+	else {
+		const int t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+		const int t12864 = ((p.M + 127) / 128) * ((p.N + 63) / 64);
+		tile = t128 >= 384 ? 0 : (t12864 >= 128 ? 1 : 2);
 	}
+	if (tile == 0) launch_tile<T, 128, 128>(p, s);
+	else if (tile == 1) launch_tile<T, 128, 64>(p, s);
+	else launch_tile<T, 64, 64>(p, s);
 }
 
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s) {

@@ -116,43 +116,66 @@ void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStrea
 	hipLaunchKernelGGL(k_gn_stats, dim3(32, nb, gn_num_chunks(T, C)), dim3(256), 0, s, x, T, C, gn_rows_per_chunk(C), part);
 }
 
-// apply: one thread per 4 channels of one output row
+// apply: a block owns a strip of output rows of ONE batch element.  It first merges that element's 32 groups' chunk statistics
+// (Chan et al.) into LDS, then streams its rows: thread = 4 consecutive channels (one group, since C/32 % 4 == 0).
+constexpr int GN_PASSES = 8;
 template <typename OT>
-__global__ void k_gn_apply(GnApplyParams p) {
-	const int c4 = p.C / 4;
-	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const int64_t total = (int64_t)p.nb * p.Tout * c4;
-	if (idx >= total) return;
-	const int c = (int)(idx % c4) * 4;
-	const int64_t orow = idx / c4;
-	const int b = (int)(orow / p.Tout), to = (int)(orow - (int64_t)b * p.Tout);
-	const int ti = p.row_idx ? p.row_idx[to] : to;
-	const float4 xv = *(const float4*)(p.x + ((int64_t)b * p.T + ti) * p.C + c);
-	// merge this group's chunk statistics (Chan et al.): cpg % 4 == 0, so the 4 channels share one group
-	const int g = c / (p.C / 32);
-	const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
-	float nt = 0.f, mean = 0.f;
-	for (int k = 0; k < p.nchunks; ++k) { nt += part[3 * k]; mean += part[3 * k] * part[3 * k + 1]; }
-	mean /= nt;
-	float m2 = 0.f;
-	for (int k = 0; k < p.nchunks; ++k) { const float d = part[3 * k + 1] - mean; m2 += part[3 * k + 2] + part[3 * k] * d * d; }
-	const float rstd = rsqrtf(m2 / nt + 1e-5f);
-	float in[4] = {xv.x, xv.y, xv.z, xv.w}, o[4];
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const int cc = c + j;
-		float v = (in[j] - mean) * rstd * p.gamma[cc] + p.beta[cc];
-		if (p.scale) v = v * (1.0f + p.scale[(int64_t)b * p.ss_stride + cc]) + p.shift[(int64_t)b * p.ss_stride + cc];
-		o[j] = apply_act(v, p.act);
+__global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
+	__shared__ float s_mean[32], s_rstd[32];
+	const int c4n = p.C / 4;                    // threads per row
+	const int rpp = 256 / c4n;                  // rows per pass (C <= 1024)
+	const int strip = rpp * GN_PASSES;
+	const int strips = (p.Tout + strip - 1) / strip;
+	const int b = blockIdx.x / strips, t0 = (blockIdx.x - b * strips) * strip;
+	if (threadIdx.x < 32) {
+		const float* part = p.ms + ((int64_t)b * 32 + threadIdx.x) * p.nchunks * 3;
+		float nt = 0.f, mean = 0.f;
+		for (int k = 0; k < p.nchunks; ++k) { nt += part[3 * k]; mean += part[3 * k] * part[3 * k + 1]; }
+		mean /= nt;
+		float m2 = 0.f;
+		for (int k = 0; k < p.nchunks; ++k) { const float d = part[3 * k + 1] - mean; m2 += part[3 * k + 2] + part[3 * k] * d * d; }
+		s_mean[threadIdx.x] = mean;
+		s_rstd[threadIdx.x] = rsqrtf(m2 / nt + 1e-5f);
 	}
-	OT* dst = (OT*)p.out + orow * p.C + c;
-	dst[0] = (OT)o[0]; dst[1] = (OT)o[1]; dst[2] = (OT)o[2]; dst[3] = (OT)o[3];
+	__syncthreads();
+	const int c = (threadIdx.x % c4n) * 4, rr = threadIdx.x / c4n;
+	const int g = c / (p.C / 32);
+	const float mean = s_mean[g], rstd = s_rstd[g];
+	const float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
+	float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+	if (p.scale) { sc = *(const float4*)(p.scale + (int64_t)b * p.ss_stride + c); sh = *(const float4*)(p.shift + (int64_t)b * p.ss_stride + c); }
+	// fold everything into y = x * a + d per channel
+	const float a0 = rstd * ga.x * (1.f + sc.x), a1 = rstd * ga.y * (1.f + sc.y), a2 = rstd * ga.z * (1.f + sc.z), a3 = rstd * ga.w * (1.f + sc.w);
+	const float d0 = (be.x - mean * rstd * ga.x) * (1.f + sc.x) + sh.x, d1 = (be.y - mean * rstd * ga.y) * (1.f + sc.y) + sh.y;
+	const float d2 = (be.z - mean * rstd * ga.z) * (1.f + sc.z) + sh.z, d3 = (be.w - mean * rstd * ga.w) * (1.f + sc.w) + sh.w;
+	float4 xv[GN_PASSES];
+#pragma unroll
+	for (int i = 0; i < GN_PASSES; ++i) {
+		const int to = t0 + i * rpp + rr;
+		const int ti = to < p.Tout ? (p.row_idx ? p.row_idx[to] : to) : 0;
+		xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + ti) * p.C + c);
+	}
+#pragma unroll
+	for (int i = 0; i < GN_PASSES; ++i) {
+		const int to = t0 + i * rpp + rr;
+		if (to >= p.Tout) continue;
+		float o0 = xv[i].x * a0 + d0, o1 = xv[i].y * a1 + d1, o2 = xv[i].z * a2 + d2, o3 = xv[i].w * a3 + d3;
+		if (p.act == ACT_SILU) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+		OT* dst = (OT*)p.out + ((int64_t)b * p.Tout + to) * p.C + c;
+		if (sizeof(OT) == 2) {
+			union { bf16x4 v; uint2 u; } pk;
+			pk.v = bf16x4{(bf16)o0, (bf16)o1, (bf16)o2, (bf16)o3};
+			*(uint2*)dst = pk.u;
+		} else {
+			*(float4*)dst = make_float4(o0, o1, o2, o3);
+		}
+	}
 }
 
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
 	ProfScope prof(PROF_GN_APPLY, (double)p.nb * p.Tout * p.C * (4.0 + (p.out_f32 ? 4.0 : dtype_size(dt))), s);
-	const int64_t total = (int64_t)p.nb * p.Tout * (p.C / 4);
-	const int grid = (int)((total + 255) / 256);
+	const int strip = (256 / (p.C / 4)) * GN_PASSES;
+	const int grid = p.nb * ((p.Tout + strip - 1) / strip);
 	if (p.out_f32 || dt == DT_F32) hipLaunchKernelGGL((k_gn_apply<float>), dim3(grid), dim3(256), 0, s, p);
 	else hipLaunchKernelGGL((k_gn_apply<bf16>), dim3(grid), dim3(256), 0, s, p);
 }
