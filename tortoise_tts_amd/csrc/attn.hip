@@ -75,20 +75,18 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid] * LOG2E;   // scores live in the log2 domain (exp2 = one v_exp_f32)
 	}
 
-	// Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32ks + 8g .. +8], scaled
-	FragT qf[2][2];
-#pragma unroll
-	for (int qt = 0; qt < 2; ++qt) {
+	// Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32ks + 8g .. +8], scaled.  Four named values (an indexed
+	// array of vectors ends up in scratch memory).
+	auto load_q = [&](int qt, int ks) -> FragT {
 		int row = q0 + 16 * qt + li;
 		row = row < p.T ? row : p.T - 1;
+		const FragT f = *(const FragT*)(base + (int64_t)row * p.ld + qc + 32 * ks + 8 * g);
+		FragT o;
 #pragma unroll
-		for (int ks = 0; ks < 2; ++ks) {
-			FragT f = *(const FragT*)(base + (int64_t)row * p.ld + qc + 32 * ks + 8 * g);
-#pragma unroll
-			for (int j = 0; j < 8; ++j) f[j] = cvt<T>((float)f[j] * p.scale);
-			qf[qt][ks] = f;
-		}
-	}
+		for (int j = 0; j < 8; ++j) o[j] = cvt<T>((float)f[j] * p.scale);
+		return o;
+	};
+	const FragT q00 = load_q(0, 0), q01 = load_q(0, 1), q10 = load_q(1, 0), q11 = load_q(1, 1);
 
 	f32x4 o[2][4];
 	float m_run[2], l_run[2];
@@ -102,26 +100,30 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 	int nkt = (p.T + 63) / 64;
 	if (CAUSAL) { const int last_q = min(blockIdx.x * 128 + 127, p.T - 1); nkt = min(nkt, last_q / 64 + 1); }
 
-	uint4 rk[CPT], rv[CPT];
+	// staging registers as named scalars (indexed arrays captured by the lambdas were placed in scratch memory)
+	uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+	rk2 = rk3 = rv2 = rv3 = make_uint4(0, 0, 0, 0);
+	auto ld1 = [&](int kt, int i, uint4& k, uint4& v) {
+		const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
+		int key = kt * 64 + row;
+		key = key < p.T ? key : p.T - 1;
+		const T* src = base + (int64_t)key * p.ld + c * (16 / ES);
+		k = *(const uint4*)(src + kc);
+		v = *(const uint4*)(src + vc);
+	};
+	auto st1 = [&](int i, const uint4& k, const uint4& v) {
+		const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
+		const int off = row * ROWB + ((c ^ (row & SWM)) << 4);
+		*(uint4*)(Ks + off) = k;
+		*(uint4*)(Vs + off) = v;
+	};
 	auto load_kv = [&](int kt) {
-#pragma unroll
-		for (int i = 0; i < CPT; ++i) {
-			const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
-			int key = kt * 64 + row;
-			key = key < p.T ? key : p.T - 1;
-			const T* src = base + (int64_t)key * p.ld + c * (16 / ES);
-			rk[i] = *(const uint4*)(src + kc);
-			rv[i] = *(const uint4*)(src + vc);
-		}
+		ld1(kt, 0, rk0, rv0); ld1(kt, 1, rk1, rv1);
+		if (CPT > 2) { ld1(kt, 2, rk2, rv2); ld1(kt, 3, rk3, rv3); }
 	};
 	auto store_kv = [&]() {
-#pragma unroll
-		for (int i = 0; i < CPT; ++i) {
-			const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
-			const int off = row * ROWB + ((c ^ (row & SWM)) << 4);
-			*(uint4*)(Ks + off) = rk[i];
-			*(uint4*)(Vs + off) = rv[i];
-		}
+		st1(0, rk0, rv0); st1(1, rk1, rv1);
+		if (CPT > 2) { st1(2, rk2, rv2); st1(3, rk3, rv3); }
 	};
 
 	load_kv(0);
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 		__syncthreads();            // previous tile's readers are done
 		store_kv();
 		__syncthreads();
-		if (kt + 1 < nkt) load_kv(kt + 1);
+		load_kv(kt + 1 < nkt ? kt + 1 : kt);   // unconditional (the last tile is re-read): keeps the staging registers out of scratch
 
 		const int k0 = kt * 64;
 		const bool wave_active = !CAUSAL || k0 <= q0 + 31;
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 					const int c0 = (32 * ks + 8 * g) * ES / 16;
 #pragma unroll
 					for (int f = 0; f < FCH; ++f) kf.q[f] = *(const uint4*)(Ks + row * ROWB + (((c0 + f) ^ (row & SWM)) << 4));
-#pragma unroll
-					for (int qt = 0; qt < 2; ++qt) s[qt][nt] = mma16<T>(kf.v, qf[qt][ks], s[qt][nt]);
+					s[0][nt] = mma16<T>(kf.v, ks == 0 ? q00 : q01, s[0][nt]);
+					s[1][nt] = mma16<T>(kf.v, ks == 0 ? q10 : q11, s[1][nt]);
 				}
 			}
 			// ---- bias, masks, online softmax in the log2 domain (lane owns query column li of each q tile; keys 16nt + 4g + r).
