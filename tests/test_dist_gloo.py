@@ -1,0 +1,58 @@
+"""N>1 path on CPU: 2 gloo ranks exercising the candidate partition and the id all-gather of tortoise_tts_amd/dist.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tortoise_tts_amd import dist as D
+
+
+def test_candidate_shards_partition_exactly():
+	for n in (1, 7, 16, 256):
+		for world in (1, 2, 3, 8):
+			spans = [D.candidate_shard(n, r, world) for r in range(world)]
+			assert spans[0][0] == 0 and spans[-1][1] == n
+			assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+			sizes = [hi - lo for lo, hi in spans]
+			assert max(sizes) - min(sizes) <= 1
+	assert D.utterance_shard(8, 1, 4) == [1, 5]
+	with pytest.raises(ValueError):
+		D.candidate_shard(4, 2, 2)
+
+
+def _worker(rank, world, port, q):
+	os.environ["MASTER_ADDR"] = "127.0.0.1"
+	os.environ["MASTER_PORT"] = str(port)
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	try:
+		n = 5
+		lo, hi = D.candidate_shard(n, rank, world)
+		L = 4 + rank                                        # ragged lengths: ranks stop at different steps
+		local = torch.arange(lo, hi)[:, None] * 100 + torch.arange(L)[None, :]
+		ids = D.gather_candidate_ids(local, n, pad_token=8193)
+		q.put((rank, ids))
+	finally:
+		dist.destroy_process_group()
+
+
+def test_gather_candidate_ids_two_ranks():
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+	ctx = mp.get_context("spawn")
+	q = ctx.Queue()
+	procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+	for p in procs:
+		p.start()
+	got = dict(q.get(timeout=120) for _ in range(2))
+	for p in procs:
+		p.join(timeout=60)
+		assert p.exitcode == 0
+	assert torch.equal(got[0], got[1])
+	ids = got[0]
+	assert ids.shape == (5, 5)
+	assert ids[0].tolist() == [0, 1, 2, 3, 8193]             # rank 0 rows: length 4, padded
+	assert ids[4].tolist() == [400, 401, 402, 403, 404]       # rank 1 rows: length 5

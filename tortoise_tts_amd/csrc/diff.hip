@@ -169,6 +169,8 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	TTK_REQUIRE(cfg->model_channels % 64 == 0 && cfg->num_heads * 64 == cfg->model_channels, TTK_E_ARG,
 				"ttk_diff_create: head_dim must be 64 (channels %d, heads %d)", cfg->model_channels, cfg->num_heads);
 	TTK_REQUIRE(cfg->in_latent_channels % 64 == 0, TTK_E_ARG, "ttk_diff_create: in_latent_channels %% 64 != 0");
+	TTK_REQUIRE(cfg->model_channels % 128 == 0 && cfg->model_channels <= 1024 && 1024 % cfg->model_channels == 0, TTK_E_ARG,
+				"ttk_diff_create: model_channels %d unsupported (128, 256, 512 or 1024)", cfg->model_channels);
 	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
 	ttk_diff* h = new ttk_diff();
 	h->cfg = *cfg;
