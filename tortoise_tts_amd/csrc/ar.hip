@@ -86,6 +86,7 @@ struct ttk_ar {
 	int* d_pos;             // device scalar: number of valid cache rows
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
+	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV
 	WsBuf ws_x, ws_a, ws_qkv, ws_ao, ws_h;
 	int B = 0, P = 0, k = 0, ready = 0;
 };
@@ -194,6 +195,9 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc(&h->attn_out, (size_t)cfg->max_batch * d * h->es));
 	AR_TRY(h->arena.alloc(&h->hbuf, (size_t)cfg->max_batch * 4 * d * h->es));
+	AR_TRY(h->arena.alloc((void**)&h->slab, (size_t)(d / 16) * 4 * 4 * 256 * sizeof(float)));
+	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)(d / 16) * sizeof(int)));
+	if (hipMemset(h->tickets, 0, (size_t)(d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 #undef AR_TRY
 	hipError_t e = hipDeviceSynchronize();
 	if (e != hipSuccess) { set_error("ttk_ar_create: %s", hipGetErrorString(e)); return fail(TTK_E_HIP); }
@@ -268,7 +272,8 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
 		p = {};
 		p.Wp = L.proj2.wfrag; p.N = d; p.K = 4 * d; p.M = B; p.bias = L.proj2.bias; p.a = h->hbuf; p.lda = 4 * d;
 		p.mode = SK_RESIDUAL; p.out_f32 = h->x; p.ldc = d;
-		launch_skinny(dt, p, d >= 1024 ? 16 : 4, s);
+		if (d >= 1024) { p.ksplit = 4; p.slab = h->slab; p.tickets = h->tickets; }   // 64 n-tiles x 4 K-slices = 256 workgroups
+		launch_skinny(dt, p, d >= 1024 ? 8 : 4, s);
 	}
 	head_launch(h, B, logits_out, hidden_out, s);
 	launch_add_int(h->d_pos, 1, s);

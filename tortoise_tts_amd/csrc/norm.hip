@@ -118,7 +118,7 @@ void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStrea
 
 // apply: a block owns a strip of output rows of ONE batch element.  It first merges that element's 32 groups' chunk statistics
 // (Chan et al.) into LDS, then streams its rows: thread = 4 consecutive channels (one group, since C/32 % 4 == 0).
-constexpr int GN_PASSES = 8;
+constexpr int GN_PASSES = 2;
 template <typename OT>
 __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	__shared__ float s_mean[32], s_rstd[32];

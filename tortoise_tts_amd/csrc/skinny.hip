@@ -20,6 +20,24 @@
 
 namespace ttk {
 
+// Diagnostic build only (-DTTK_STAMPS, tests/diag/skinny_stamps.cpp): wave 0 / lane 0 of every workgroup records a 100 MHz
+// timestamp per phase.  Expands to nothing in the product build.
+// weight-stream cache policy: non-temporal (streamed once per token) unless built with -DTTK_NT=0
+#ifndef TTK_NT
+#define TTK_NT 1
+#endif
+#if TTK_NT
+#define TTK_WLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define TTK_WLOAD(p) (*(p))
+#endif
+
+#ifdef TTK_STAMPS
+#define TTK_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TTK_STAMP(i) do {} while (0)
+#endif
+
 // KC = float4 chunks of a row per lane in the LayerNorm prologue (K <= 256 * KC); LN kernels run <= 8 waves (2 per SIMD,
 // 256 VGPRs), plain ones up to 16.
 template <typename T, int MT, bool LN, int KC>
@@ -28,7 +46,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	constexpr int ES = sizeof(T);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-	const int nt = blockIdx.x;
+	const int nt = blockIdx.x / p.ksplit, kslice = blockIdx.x - nt * p.ksplit;   // ksplit workgroups share one n-tile
 	const int KS = p.K / 32;
 	const int RS = p.K * ES + 16;                       // padded LDS row stride (bytes), LN mode only
 	char* a_lds = smem;
@@ -45,46 +63,74 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			const int r = r0 + j * nw;
 			const bool live = r < p.M;
 #pragma unroll
-			for (int i = 0; i < KC; ++i) {
-				const int c = lane + 64 * i;
-				v[j][i] = (live && c < nchunk) ? *(const float4*)(p.x + (int64_t)r * p.ldx + 4 * c) : make_float4(0, 0, 0, 0);
+			for (int i = 0; i < KC; ++i) {   // unconditional loads (clamped address + select): a branch around a load makes hipcc
+				const int c = lane + 64 * i;     // fall back to s_waitcnt vmcnt(0), which would also wait for the weight stream
+				const int cc = c < nchunk ? c : nchunk - 1;
+				const int rr = live ? r : 0;
+				const float4 t = *(const float4*)(p.x + (int64_t)rr * p.ldx + 4 * cc);
+				v[j][i] = (live && c < nchunk) ? t : make_float4(0, 0, 0, 0);
 			}
 		}
 	};
+	// LayerNorm of RP rows at once: per-lane partial (sum, sum of squares) of every row first, then ONE butterfly in which the
+	// 2*RP independent chains interleave (a dependent 6-step cross-lane chain costs ~0.3 us; the first version ran four of them
+	// back to back per row and the prologue took 4 us).  Variance = E[x^2] - mean^2 in f32 (K <= 2048, |mean| << rms).
+	// gamma/beta of the first LayerNorm are requested together with the rows, BEFORE the weight stream: vmcnt retires in order,
+	// so a gamma load issued after the weights would make the normalisation wait for the whole HBM stream.
+	float4 g0[KC], b0[KC];
+	auto ln_load_affine = [&]() {
+#pragma unroll
+		for (int i = 0; i < KC; ++i) {
+			const int c = lane + 64 * i;
+			const int cc = c < nchunk ? c : nchunk - 1;
+			const float4 tg = *(const float4*)(p.g1 + 4 * cc), tb = *(const float4*)(p.b1 + 4 * cc);
+			g0[i] = c < nchunk ? tg : make_float4(0, 0, 0, 0);
+			b0[i] = c < nchunk ? tb : make_float4(0, 0, 0, 0);
+		}
+	};
 	auto ln_finish = [&](int r0) {
+		for (int pass = 0; pass < p.ln_count; ++pass) {
+			float4 gg[KC], bb[KC];
+#pragma unroll
+			for (int i = 0; i < KC; ++i) {
+				const int c = lane + 64 * i;
+				if (pass == 0) { gg[i] = g0[i]; bb[i] = b0[i]; }
+				else {
+					gg[i] = c < nchunk ? *(const float4*)(p.g2 + 4 * c) : make_float4(0, 0, 0, 0);
+					bb[i] = c < nchunk ? *(const float4*)(p.b2 + 4 * c) : make_float4(0, 0, 0, 0);
+				}
+			}
+			float s1[RP], s2[RP];
+#pragma unroll
+			for (int j = 0; j < RP; ++j) {
+				s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+				for (int i = 0; i < KC; ++i) {
+					s1[j] += v[j][i].x + v[j][i].y + v[j][i].z + v[j][i].w;
+					s2[j] += v[j][i].x * v[j][i].x + v[j][i].y * v[j][i].y + v[j][i].z * v[j][i].z + v[j][i].w * v[j][i].w;
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < RP; ++j) { s1[j] = wave_sum(s1[j]); s2[j] = wave_sum(s2[j]); }   // independent chains: they interleave
+#pragma unroll
+			for (int j = 0; j < RP; ++j) {
+				const float mean = s1[j] / (float)p.K;
+				const float var = fmaxf(s2[j] / (float)p.K - mean * mean, 0.f);
+				const float rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+				for (int i = 0; i < KC; ++i) {   // lanes beyond the row hold zeros and zero gamma/beta: harmless
+					v[j][i].x = (v[j][i].x - mean) * rstd * gg[i].x + bb[i].x;
+					v[j][i].y = (v[j][i].y - mean) * rstd * gg[i].y + bb[i].y;
+					v[j][i].z = (v[j][i].z - mean) * rstd * gg[i].z + bb[i].z;
+					v[j][i].w = (v[j][i].w - mean) * rstd * gg[i].w + bb[i].w;
+				}
+			}
+		}
 #pragma unroll
 		for (int j = 0; j < RP; ++j) {
 			const int r = r0 + j * nw;
 			if (r >= 16 * MT) continue;
 			const bool live = r < p.M;
-			for (int pass = 0; pass < p.ln_count; ++pass) {
-				const float* gp = pass ? p.g2 : p.g1;
-				const float* bp = pass ? p.b2 : p.b1;
-				float sum = 0.f;
-#pragma unroll
-				for (int i = 0; i < KC; ++i) sum += v[j][i].x + v[j][i].y + v[j][i].z + v[j][i].w;
-				const float mean = wave_sum(sum) / (float)p.K;
-				float sq = 0.f;
-#pragma unroll
-				for (int i = 0; i < KC; ++i) {
-					if (lane + 64 * i < nchunk) {
-						const float a0 = v[j][i].x - mean, a1 = v[j][i].y - mean, a2 = v[j][i].z - mean, a3 = v[j][i].w - mean;
-						sq += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
-					}
-				}
-				const float rstd = rsqrtf(wave_sum(sq) / (float)p.K + 1e-5f);
-#pragma unroll
-				for (int i = 0; i < KC; ++i) {
-					const int c = lane + 64 * i;
-					if (c < nchunk) {
-						const float4 g = *(const float4*)(gp + 4 * c), b = *(const float4*)(bp + 4 * c);
-						v[j][i].x = (v[j][i].x - mean) * rstd * g.x + b.x;
-						v[j][i].y = (v[j][i].y - mean) * rstd * g.y + b.y;
-						v[j][i].z = (v[j][i].z - mean) * rstd * g.z + b.z;
-						v[j][i].w = (v[j][i].w - mean) * rstd * g.w + b.w;
-					}
-				}
-			}
 #pragma unroll
 			for (int i = 0; i < KC; ++i) {
 				const int c = lane + 64 * i;
@@ -99,23 +145,27 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			}
 		}
 	};
-	if (LN) ln_load(wave);
+	TTK_STAMP(0);
+	if (LN) { ln_load(wave); ln_load_affine(); }
 
 	// ---- this wave's K slice of the weights; the first PRE fragments are requested now
-	const int ks0 = (KS * wave) / nw, ks1 = (KS * (wave + 1)) / nw;
+	const int kw0 = (KS * kslice) / p.ksplit, kw1 = (KS * (kslice + 1)) / p.ksplit;   // this workgroup's k-steps
+	const int ks0 = kw0 + ((kw1 - kw0) * wave) / nw, ks1 = kw0 + ((kw1 - kw0) * (wave + 1)) / nw;
 	const FragT* wp = (const FragT*)p.Wp + ((int64_t)nt * KS) * 64 + lane;
 	constexpr int PRE = 8;   // 8 x 1 KiB (bf16) in flight per wave
 	FragT bpre[PRE];
 	const int npre = min(ks1 - ks0, PRE);
 #pragma unroll
-	for (int u = 0; u < PRE; ++u)
-		if (u < npre) bpre[u] = __builtin_nontemporal_load(wp + (int64_t)(ks0 + u) * 64);
+	for (int u = 0; u < PRE; ++u)   // unconditional: slots beyond npre re-read the last fragment (never multiplied)
+		bpre[u] = TTK_WLOAD(wp + (int64_t)(ks0 + (u < npre ? u : npre - 1)) * 64);
 
 	if (LN) {
 		ln_finish(wave);
+		TTK_STAMP(1);
 		for (int r0 = wave + RP * nw; r0 < 16 * MT; r0 += RP * nw) { ln_load(r0); ln_finish(r0); }
 		__syncthreads();
 	}
+	TTK_STAMP(2);
 
 	f32x4 acc[MT];
 #pragma unroll
@@ -145,33 +195,74 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	for (; ks + UN <= ks1; ks += UN) {
 		FragT b[UN];
 #pragma unroll
-		for (int u = 0; u < UN; ++u) b[u] = __builtin_nontemporal_load(wp + (int64_t)(ks + u) * 64);
+		for (int u = 0; u < UN; ++u) b[u] = TTK_WLOAD(wp + (int64_t)(ks + u) * 64);
 #pragma unroll
 		for (int u = 0; u < UN; ++u)
 #pragma unroll
 			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks + u), b[u], acc[mt]);
 	}
 	for (; ks < ks1; ++ks) {
-		const FragT b = __builtin_nontemporal_load(wp + (int64_t)ks * 64);
+		const FragT b = TTK_WLOAD(wp + (int64_t)ks * 64);
 #pragma unroll
 		for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks), b, acc[mt]);
 	}
 
+	TTK_STAMP(3);
 	// ---- cross-wave reduction through LDS, then epilogue by the first 256 threads
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) *(f32x4*)(red + ((wave * MT + mt) * 64 + lane) * 4) = acc[mt];
 	__syncthreads();
-	if (tid >= 256) return;
+	TTK_STAMP(4);
 	const int l2 = tid & 63, r = tid >> 6;
 	const int n = nt * 16 + (l2 & 15);
+	float vsum[MT];
+	if (tid < 256) {
+#pragma unroll
+		for (int mt = 0; mt < MT; ++mt) {
+			float v = 0.f;
+			for (int w = 0; w < nw; ++w) v += red[((w * MT + mt) * 64 + l2) * 4 + r];
+			vsum[mt] = v;
+		}
+	}
+	if (p.ksplit > 1) {
+		// Split-K over workgroups with a deterministic in-launch combine (cdna_hip_programming.md section 5, "In-launch split-K
+		// reduction", write-through form): every slice stores its 16x16 partial with sc1 stores, drains them, and one lane
+		// takes a ticket; the workgroup that draws the last ticket reads all slices back with sc1 loads IN SLICE ORDER (bitwise
+		// reproducible, unlike float atomics) and runs the epilogue.  The ticket counter is reset by its last user.
+		float* slab = p.slab + ((int64_t)nt * p.ksplit) * 256 * MT;
+		if (tid < 256) {
+#pragma unroll
+			for (int mt = 0; mt < MT; ++mt)
+				__hip_atomic_store(slab + ((int64_t)kslice * MT + mt) * 256 + tid, vsum[mt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		int* flag = (int*)red;                  // LDS word reused as the "I am last" broadcast
+		if (tid == 0) {
+			const int ticket = __hip_atomic_fetch_add(p.tickets + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			*flag = ticket == p.ksplit - 1;
+			if (ticket == p.ksplit - 1) __hip_atomic_store(p.tickets + nt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__syncthreads();
+		if (!*flag) return;
+		if (tid < 256) {
+#pragma unroll
+			for (int mt = 0; mt < MT; ++mt) {
+				float v = 0.f;
+				for (int sl = 0; sl < p.ksplit; ++sl)
+					v += __hip_atomic_load(slab + ((int64_t)sl * MT + mt) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				vsum[mt] = v;
+			}
+		}
+	}
+	if (tid >= 256) return;
 	if (n >= p.N) return;
 	const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) {
 		const int m = mt * 16 + 4 * (l2 >> 4) + r;
 		if (m >= p.M) continue;
-		float v = bias;
-		for (int w = 0; w < nw; ++w) v += red[((w * MT + mt) * 64 + l2) * 4 + r];
+		const float v = vsum[mt] + bias;
 		if (p.mode == SK_STORE_F32) {
 			p.out_f32[(int64_t)m * p.ldc + n] = v;
 		} else if (p.mode == SK_RESIDUAL) {
@@ -191,11 +282,12 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			}
 		}
 	}
+	TTK_STAMP(5);
 }
 
 template <typename T, int MT>
 static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
-	const int grid = (p.N + 15) / 16;
+	const int grid = ((p.N + 15) / 16) * p.ksplit;
 	const size_t red = (size_t)waves * MT * 64 * 4 * sizeof(float);
 	if (p.ln_count > 0) {
 		if (waves > 8) waves = 8;
@@ -219,7 +311,9 @@ static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s) {
 	else launch_skinny_mt<T, 4>(p, waves, s);
 }
 
-void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s) {
+void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
+	SkinnyParams p = p_in;
+	if (p.ksplit < 1 || !p.slab || !p.tickets) p.ksplit = 1;
 	if (waves < 4) waves = 4;
 	// algorithmic bytes: the weight matrix once + bias + the M activation rows in and out
 	ProfScope prof(PROF_SKINNY, (double)p.N * p.K * dtype_size(dt) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, s);

@@ -40,10 +40,20 @@ template <typename T> __device__ __forceinline__ T cvt(float x);
 template <> __device__ __forceinline__ float cvt<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 cvt<bf16>(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
 
+// Wave64 sum, result in every lane.  DPP inside each 16-lane row (quad swaps, row_half_mirror, row_mirror: VALU-rate, no LDS
+// crossbar), then the four row sums are read back through SGPRs.  ~12 instructions instead of six dependent ds_bpermute.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+	return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-	return v;
+	v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+	v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+	v = dpp_add<0x141>(v);   // row_half_mirror
+	v = dpp_add<0x140>(v);   // row_mirror
+	const int iv = __float_as_int(v);
+	const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+	const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+	return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

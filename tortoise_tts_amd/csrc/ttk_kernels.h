@@ -72,6 +72,11 @@ struct SkinnyParams {
 	void* out_T;                    // SK_ACT_T, [M][N]
 	// SK_QKV: n in [0,3d): q -> qbuf[m][n] f32 (pre-scaled), k/v -> cache[m][h][*pos][64]
 	float* qbuf; void* kcache; void* vcache; const int* d_pos; int max_ctx, H; float q_scale;
+	// optional split-K over workgroups: slab f32 [n_tiles][ksplit][MT][256], tickets int [n_tiles] (zero between launches)
+	int ksplit; float* slab; int* tickets;
+#ifdef TTK_STAMPS
+	unsigned long long* stamps;   // diagnostic build only
+#endif
 };
 void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s);
 
