@@ -43,8 +43,8 @@ def parse():
 
 def cpu_baseline(seed):
 	"""The CPU oracle (oracle/tortoise_oracle.py, kind 'port') on a bounded sample of the same workload, on this box's host
-	cores: 2 KV-cached decode steps at B=16 after a prefill (scaled to 250), and 1 DDIM step (cond + cond-free evaluation)
-	at T = 272 frames, scaled by the network's flop model F(T) to T = 1088 and to 80 steps."""
+	cores: 16 KV-cached decode steps at B=16 after a prefill (scaled to 250), and 4 DDIM steps (cond + cond-free evaluation)
+	at T = 544 frames, scaled by the network's flop model F(T) to T = 1088 and to 80 steps."""
 	sys.path.insert(0, os.path.join(ROOT, "oracle"))
 	import tortoise_oracle as O
 	from tortoise_tts_amd import weights as W
@@ -64,19 +64,21 @@ def cpu_baseline(seed):
 		logits, past, _ = ar.prefill(ar.prefix_embeddings(cond, text), CANDIDATES)
 		t_prefill = time.perf_counter() - t0
 		tok = torch.randint(0, 8192, (CANDIDATES,), generator=g)
+		n_dec = 16
 		t0 = time.perf_counter()
-		for k in (1, 2):
+		for k in range(1, n_dec + 1):
 			_, past, _ = ar.decode(tok, k, past)
-		t_dec = (time.perf_counter() - t0) / 2
+		t_dec = (time.perf_counter() - t0) / n_dec
 		del ar, past
 		d = O.DiffusionOracle(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL)
-		Ts = 272
+		Ts, n_st = 544, 4
 		x = torch.randn(1, 100, Ts, generator=g)
 		E = torch.randn(1, 1024, Ts, generator=g)
 		sched = O.SpacedSchedule(steps=DDIM_STEPS)
 		t0 = time.perf_counter()
-		sched.ddim_step(d, x, DDIM_STEPS - 1, E)
-		t_step = time.perf_counter() - t0
+		for i in range(n_st):
+			x = sched.ddim_step(d, x, DDIM_STEPS - 1 - i, E)
+		t_step = (time.perf_counter() - t0) / n_st
 
 	def F(T):   # flop per evaluation, SURVEY.md section 8d
 		return 236 * 1024 ** 2 * T + 52 * 1024 * T * T + 1_843_200 * T
@@ -84,7 +86,7 @@ def cpu_baseline(seed):
 	est = t_prefill + MEL_TOKENS * t_dec + DDIM_STEPS * t_step * F(T) / F(Ts)
 	audio = T * 256 / 24000
 	return {"value": audio / est, "unit": "audio-sec/wall-sec", "cores": cores, "kind": "port",
-			"sample": f"prefill + 2 decode steps at B=16 (x125) + 1 DDIM step at T={Ts} scaled by F(T) to T={T} x80; "
+			"sample": f"prefill + {n_dec} decode steps at B=16 (scaled to 250) + {n_st} DDIM steps at T={Ts} scaled by F(T) to T={T} and to 80 steps; "
 					  f"measured {t_prefill:.2f}s + {t_dec * 1e3:.0f} ms/decode-step + {t_step:.2f} s/DDIM-step; latent pass not included"}
 
 

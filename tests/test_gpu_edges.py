@@ -1,0 +1,153 @@
+"""GPU parity on the edges the domain has: ragged/odd lengths, a single candidate, many candidates, the streaming generator,
+and size-independent properties at BASELINE sizes (full-size models)."""
+import numpy as np
+import pytest
+import torch
+
+import tortoise_oracle as O
+from tortoise_tts_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def gen(seed):
+	return torch.Generator().manual_seed(seed)
+
+
+def maxerr(a, b):
+	return (torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def small_ar():
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	sd = W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 31)
+	return UnifiedVoice(sd, W.AR_SMALL, dtype="f32", device=DEV, max_batch=32, max_ctx=160), O.AROracle(sd, W.AR_SMALL)
+
+
+@pytest.fixture(scope="module")
+def small_diff():
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	sd = W.synth_state_dict(W.diffusion_shapes(W.DIFF_SMALL), 32)
+	return DiffusionTTS(sd, W.DIFF_SMALL, dtype="f32", device=DEV), O.DiffusionOracle(sd, W.DIFF_SMALL)
+
+
+@pytest.mark.parametrize("B,Tt,M", [(1, 1, 1), (3, 5, 7), (17, 11, 33), (32, 2, 70)])
+def test_latent_pass_ragged_shapes(small_ar, B, Tt, M):
+	"""Sequence lengths that are not multiples of any tile (S = Tt + M + 5), one to 32 candidates."""
+	model, oracle = small_ar
+	text = torch.randint(1, 255, (B, Tt), generator=gen(B))
+	cond = torch.randn(B, 128, generator=gen(B + 1))
+	codes = torch.randint(0, 8192, (B, M), generator=gen(B + 2))
+	got = model.forward(cond.to(DEV), text.to(DEV), torch.tensor([Tt] * B), codes.to(DEV), torch.tensor([M * 1024] * B), return_latent=True, clip_inputs=False)
+	with torch.inference_mode():
+		ref = oracle.forward_latents(cond, text, codes)
+	assert got.shape == (B, M, 128) and maxerr(got, ref) < 2e-4
+
+
+def test_latent_pass_applies_mel_padding(small_ar):
+	"""set_mel_padding (unified_voice.py:494-506): codes past wav_lengths // 1024 + 1 become the stop token."""
+	model, oracle = small_ar
+	text = torch.randint(1, 255, (2, 4), generator=gen(5))
+	cond = torch.randn(2, 128, generator=gen(6))
+	codes = torch.randint(0, 8192, (2, 12), generator=gen(7))
+	got = model.forward(cond.to(DEV), text.to(DEV), torch.tensor([4, 4]), codes.to(DEV), torch.tensor([5 * 1024, 12 * 1024]), return_latent=True, clip_inputs=False)
+	padded = codes.clone()
+	padded[0, 6:] = 8193
+	with torch.inference_mode():
+		ref = oracle.forward_latents(cond, text, padded)
+	assert maxerr(got, ref) < 2e-4
+
+
+@pytest.mark.parametrize("B", [1, 5, 16, 32])
+def test_decode_batch_sizes_teacher_forced(small_ar, B):
+	"""KV-cached decode at several candidate counts (MFMA M-tiles of 16), logits vs the oracle for 5 forced tokens."""
+	model, oracle = small_ar
+	text = torch.randint(1, 255, (1, 6), generator=gen(B))
+	cond = torch.randn(1, 128, generator=gen(B + 9))
+	toks = torch.randint(0, 8192, (B, 5), generator=gen(B + 10))
+	logits = model._prefill(cond.to(DEV), text.to(DEV), B)
+	with torch.inference_mode():
+		ref, past, _ = oracle.prefill(oracle.prefix_embeddings(cond, text), B)
+		assert maxerr(logits, ref[:, -1]) < 2e-4
+		for k in range(1, 6):
+			model._decode(toks[:, k - 1].contiguous().to(DEV), logits)
+			ref, past, _ = oracle.decode(toks[:, k - 1], k, past)
+			assert maxerr(logits, ref) < 2e-4, k
+
+
+def test_streaming_generator_matches_oracle_tokens_and_latents(small_ar):
+	"""a6: get_generator yields (codes, final_norm(hidden)) per token (stream_generator.py:1172)."""
+	model, oracle = small_ar
+	text = torch.randint(1, 255, (1, 6), generator=gen(40))
+	cond = torch.randn(1, 128, generator=gen(41))
+	ids = model.compute_embeddings(cond.to(DEV), text.to(DEV))
+	out = list(model.get_generator(inputs=ids, max_length=ids.shape[1] + 8, temperature=0.8, do_sample=True, num_return_sequences=1,
+								   suppress_tokens=[8193]))
+	got_tok = torch.stack([t for t, _ in out], 1).cpu()
+	with torch.inference_mode():
+		ref_tok = O.inference_speech(oracle, cond, text, num_return_sequences=1, max_generate_length=8, temperature=0.8,
+									 suppress_tokens=[8193], sample_device="cuda")
+		assert torch.equal(got_tok, ref_tok[:, :got_tok.shape[1]])
+		# latent yielded with token k is final_norm(ln_f(h)) of the step that consumed it
+		logits, past, _ = oracle.prefill(oracle.prefix_embeddings(cond, text), 1)
+		for k in range(1, got_tok.shape[1] + 1):
+			_, past, hidden = oracle.decode(ref_tok[:, k - 1], k, past)
+			lat = O.layer_norm(hidden, oracle.w["final_norm.weight"], oracle.w["final_norm.bias"])
+			assert maxerr(out[k - 1][1], lat) < 2e-4
+
+
+@pytest.mark.parametrize("b,M,T", [(1, 1, 4), (2, 7, 30), (1, 40, 174), (3, 70, 129)])
+def test_diffusion_odd_lengths(small_diff, b, M, T):
+	"""Frame counts that straddle the 64-key attention tiles and the 128-row GEMM tiles; nearest-neighbour expansion M -> T."""
+	model, oracle = small_diff
+	lat = torch.randn(b, M, 128, generator=gen(M))
+	cond = torch.randn(b, 256, generator=gen(M + 1))
+	x = torch.randn(b, 100, T, generator=gen(M + 2))
+	t = torch.randint(0, 4000, (b,), generator=gen(M + 3))
+	E = model.timestep_independent(lat.to(DEV), cond.to(DEV), T, False)
+	with torch.inference_mode():
+		Er = oracle.timestep_independent(lat, cond, T)
+		assert maxerr(E, Er) < 2e-4
+		assert maxerr(model(x.to(DEV), t.to(DEV), precomputed_aligned_embeddings=Er.to(DEV)), oracle.forward(x, t, Er)) < 5e-4
+		assert maxerr(model(x.to(DEV), t.to(DEV), conditioning_free=True), oracle.forward(x, t, None, conditioning_free=True)) < 5e-4
+
+
+def test_ddim_linearity_of_the_epilogue_and_clamp(small_diff):
+	"""Property: with cond_free off the DDIM update is x0*sqrt(ab_prev) + sqrt(1-ab_prev)*eps' with x0 clamped to [-1, 1]; a
+	huge start noise must therefore give |mel| <= sqrt(ab_prev) + sqrt(1-ab_prev)*|eps'| and stay finite."""
+	from tortoise_tts_amd.diffusion import get_diffuser
+	model, _ = small_diff
+	T = 50
+	E = torch.randn(1, 128, T, generator=gen(3)).to(DEV)
+	mel = get_diffuser(steps=5, cond_free=False).sample_loop(model, (1, 100, T), sampler="ddim", noise=1e3 * torch.randn(1, 100, T, generator=gen(4)).to(DEV),
+															 model_kwargs={"precomputed_aligned_embeddings": E})
+	assert torch.isfinite(mel).all()
+
+
+def test_full_size_bf16_properties():
+	"""BASELINE-size models (configs[1] shapes, bf16): determinism of the sampled ids across two runs and across graph/eager,
+	all ids in range, fixed length with the stop token suppressed; DDIM mel finite and in the clamp-implied range."""
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	from tortoise_tts_amd.diffusion import DiffusionTTS, get_diffuser
+	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtype="bf16", device=DEV, max_batch=16, max_ctx=64 + 4 + 40 + 8)
+	text = torch.randint(1, 255, (1, 64), generator=gen(1)).to(DEV)
+	cond = torch.randn(1, 1024, generator=gen(2)).to(DEV)
+	kw = dict(do_sample=True, temperature=0.8, num_return_sequences=16, max_generate_length=40, suppress_tokens=[8193])
+	a = ar.inference_speech(cond, text, **kw)
+	b = ar.inference_speech(cond, text, **kw)
+	ar.use_graph = False
+	c = ar.inference_speech(cond, text, **kw)
+	assert a.shape == (16, 40) and torch.equal(a, b) and torch.equal(a, c)
+	assert int(a.min()) >= 0 and int(a.max()) < 8193
+	lat = ar.forward(cond.expand(16, -1), text.expand(16, -1), torch.tensor([64] * 16), a, torch.tensor([40 * 1024] * 16), return_latent=True, clip_inputs=False)
+	assert lat.shape == (16, 40, 1024) and torch.isfinite(lat).all()
+	del ar
+	df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL, dtype="bf16", device=DEV)
+	T = 40 * 4 * 24000 // 22050
+	E = df.timestep_independent(lat[:1], torch.randn(1, 2048, generator=gen(3)).to(DEV), T, False)
+	noise = torch.randn(1, 100, T, generator=gen(4)).to(DEV)
+	m1 = get_diffuser(6, True).sample_loop(df, (1, 100, T), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E})
+	m2 = get_diffuser(6, True).sample_loop(df, (1, 100, T), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E})
+	assert torch.equal(m1, m2) and torch.isfinite(m1).all() and m1.abs().max() <= 1.0 + 1e-5     # last step: ab_prev = 1 -> x = clamp(x0)
