@@ -50,8 +50,10 @@ template <> struct VT<float> {
 	}
 };
 
-template <typename T, bool CAUSAL, bool BIAS>
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
+// QT = 16-query tiles per wave: 2 (128 queries per workgroup) when that still gives >= 2 waves per SIMD, else 1 (64 per
+// workgroup): a lone wave on a SIMD issues a wave64 VALU op every 4 cycles instead of 2 and cannot overlap its MFMAs.
+template <typename T, bool CAUSAL, bool BIAS, int QT>
+__global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
 	typedef typename Frag<T>::type FragT;
 	constexpr int ES = sizeof(T);
 	constexpr int ROWB = HD * ES;             // LDS row bytes (128 bf16 / 256 f32)
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int h = blockIdx.y, b = blockIdx.z;
-	const int q0 = blockIdx.x * 128 + wave * 32;      // first query row of this wave
+	constexpr int QW = 16 * QT, QB = 4 * QW;          // queries per wave / per workgroup
+	const int q0 = blockIdx.x * QB + wave * QW;       // first query row of this wave
 	const int li = lane & 15, g = lane >> 4;
 	const T* base = (const T*)p.qkv + (int64_t)b * p.T * p.ld;
 	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
@@ -86,19 +89,19 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 		for (int j = 0; j < 8; ++j) o[j] = cvt<T>((float)f[j] * p.scale);
 		return o;
 	};
-	const FragT q00 = load_q(0, 0), q01 = load_q(0, 1), q10 = load_q(1, 0), q11 = load_q(1, 1);
+	const FragT q00 = load_q(0, 0), q01 = load_q(0, 1), q10 = load_q(QT - 1, 0), q11 = load_q(QT - 1, 1);
 
-	f32x4 o[2][4];
-	float m_run[2], l_run[2];
+	f32x4 o[QT][4];
+	float m_run[QT], l_run[QT];
 #pragma unroll
-	for (int qt = 0; qt < 2; ++qt) {
+	for (int qt = 0; qt < QT; ++qt) {
 		m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
 #pragma unroll
 		for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 	}
 
 	int nkt = (p.T + 63) / 64;
-	if (CAUSAL) { const int last_q = min(blockIdx.x * 128 + 127, p.T - 1); nkt = min(nkt, last_q / 64 + 1); }
+	if (CAUSAL) { const int last_q = min((int)blockIdx.x * QB + QB - 1, p.T - 1); nkt = min(nkt, last_q / 64 + 1); }
 
 	// staging registers as named scalars (indexed arrays captured by the lambdas were placed in scratch memory)
 	uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
@@ -134,12 +137,12 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 		load_kv(kt + 1 < nkt ? kt + 1 : kt);   // unconditional (the last tile is re-read): keeps the staging registers out of scratch
 
 		const int k0 = kt * 64;
-		const bool wave_active = !CAUSAL || k0 <= q0 + 31;
+		const bool wave_active = !CAUSAL || k0 <= q0 + QW - 1;
 		if (wave_active) {
 			// ---- S^T tile: 4 key sub-tiles x 2 query tiles
-			f32x4 s[2][4];
+			f32x4 s[QT][4];
 #pragma unroll
-			for (int qt = 0; qt < 2; ++qt)
+			for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
 				for (int nt = 0; nt < 4; ++nt) s[qt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 #pragma unroll
 					for (int f = 0; f < FCH; ++f) kf.q[f] = *(const uint4*)(Ks + row * ROWB + (((c0 + f) ^ (row & SWM)) << 4));
 					s[0][nt] = mma16<T>(kf.v, ks == 0 ? q00 : q01, s[0][nt]);
-					s[1][nt] = mma16<T>(kf.v, ks == 0 ? q10 : q11, s[1][nt]);
+					if (QT > 1) s[QT - 1][nt] = mma16<T>(kf.v, ks == 0 ? q10 : q11, s[QT - 1][nt]);
 				}
 			}
 			// ---- bias, masks, online softmax in the log2 domain (lane owns query column li of each q tile; keys 16nt + 4g + r).
@@ -160,13 +163,14 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 			// saturated there) needs one fma per score; only the ~3 tiles around the diagonal take the per-element path.
 			const bool edge = k0 + 64 > p.T;
 			const bool diag = CAUSAL && (k0 + 63 > q0);
-			const bool near_band = BIAS && (k0 - (q0 + 31) < 64) && (q0 - (k0 + 63) < 64);
+			const bool near_band = BIAS && (k0 - (q0 + QW - 1) < 64) && (q0 - (k0 + 63) < 64);
 			const float cbias = BIAS ? (k0 > q0 ? bias_s[128] : bias_s[0]) : 0.f;
 #pragma unroll
-			for (int qt = 0; qt < 2; ++qt) {
+			for (int qt = 0; qt < QT; ++qt) {
 				const int qi = q0 + 16 * qt + li;
+				const bool slow = edge || diag || near_band;
 				float tmax = NEG_BIG;
-				if (edge || diag || near_band) {
+				if (slow) {   // per-element bias lookup and masks; scores become log2-domain values in place
 #pragma unroll
 					for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -179,47 +183,63 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 							s[qt][nt][r] = v;
 							tmax = fmaxf(tmax, v);
 						}
-				} else {
+				} else {      // one max over the raw scores; the affine map is folded into the exp2 argument below
+#pragma unroll
+					for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[qt][nt][r]);
+					tmax = fmaf(tmax, LOG2E, cbias);
+				}
+				tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+				tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+				// deferred rescale (cdna_hip_programming.md T13): keep the running max unless this tile exceeds it by more than 2^8;
+				// P then stays <= 256, exact enough in bf16 (same relative precision) with f32 accumulation.  Everything at the old
+				// scale (O, l) is multiplied exactly once, before any P of this tile exists.
+				if (__any(tmax > m_run[qt] + 8.0f)) {
+					const float m_new = fmaxf(m_run[qt], tmax);
+					const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+					m_run[qt] = m_new;
+					l_run[qt] *= alpha;
+#pragma unroll
+					for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+				}
+				const float mq = m_run[qt];
+				float psum = 0.f;
+				if (slow) {
 #pragma unroll
 					for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
 						for (int r = 0; r < 4; ++r) {
-							const float v = fmaf(s[qt][nt][r], LOG2E, cbias);
-							s[qt][nt][r] = v;
-							tmax = fmaxf(tmax, v);
+							const float pv = __builtin_amdgcn_exp2f(s[qt][nt][r] - mq);
+							s[qt][nt][r] = pv;
+							psum += pv;
+						}
+				} else {
+					const float cm = cbias - mq;
+#pragma unroll
+					for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							const float pv = __builtin_amdgcn_exp2f(fmaf(s[qt][nt][r], LOG2E, cm));
+							s[qt][nt][r] = pv;
+							psum += pv;
 						}
 				}
-				tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-				tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-				const float m_new = fmaxf(m_run[qt], tmax);
-				const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-				m_run[qt] = m_new;
-				float psum = 0.f;
-#pragma unroll
-				for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-					for (int r = 0; r < 4; ++r) {
-						const float pv = __builtin_amdgcn_exp2f(s[qt][nt][r] - m_new);
-						s[qt][nt][r] = pv;
-						psum += pv;
-					}
-				l_run[qt] = l_run[qt] * alpha + psum;
-#pragma unroll
-				for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+				l_run[qt] += psum;
 			}
 			// ---- O^T += V^T P^T
 #pragma unroll
 			for (int sidx = 0; sidx < 2; ++sidx) {
-				FragT pf[2];
+				FragT pf[QT];
 #pragma unroll
-				for (int qt = 0; qt < 2; ++qt)
+				for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
 					for (int j = 0; j < 8; ++j) pf[qt][j] = cvt<T>(s[qt][2 * sidx + (j >> 2)][j & 3]);
 #pragma unroll
 				for (int dt = 0; dt < 4; ++dt) {
 					const FragT vf = VT<T>::load(Vs, 32 * sidx, 16 * dt, lane);
 #pragma unroll
-					for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mma16<T>(vf, pf[qt], o[qt][dt]);
+					for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mma16<T>(vf, pf[qt], o[qt][dt]);
 				}
 			}
 		}
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 
 	// ---- normalise and store: lane holds d = 16dt + 4g + r of query column li
 #pragma unroll
-	for (int qt = 0; qt < 2; ++qt) {
+	for (int qt = 0; qt < QT; ++qt) {
 		float l = l_run[qt];
 		l += __shfl_xor(l, 16);
 		l += __shfl_xor(l, 32);
@@ -245,10 +265,18 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnParams p) {
 
 template <typename T>
 static void launch_attn_fwd_t(const AttnParams& p, hipStream_t s) {
-	dim3 grid((p.T + 127) / 128, p.H, p.nb);
-	if (p.causal) hipLaunchKernelGGL((k_attn_fwd<T, true, false>), grid, dim3(256), 0, s, p);
-	else if (p.bias) hipLaunchKernelGGL((k_attn_fwd<T, false, true>), grid, dim3(256), 0, s, p);
-	else hipLaunchKernelGGL((k_attn_fwd<T, false, false>), grid, dim3(256), 0, s, p);
+	const bool big = (int64_t)((p.T + 127) / 128) * p.H * p.nb >= 512;   // enough 128-query blocks for 2 waves per SIMD
+	if (big) {
+		dim3 grid((p.T + 127) / 128, p.H, p.nb);
+		if (p.causal) hipLaunchKernelGGL((k_attn_fwd<T, true, false, 2>), grid, dim3(256), 0, s, p);
+		else if (p.bias) hipLaunchKernelGGL((k_attn_fwd<T, false, true, 2>), grid, dim3(256), 0, s, p);
+		else hipLaunchKernelGGL((k_attn_fwd<T, false, false, 2>), grid, dim3(256), 0, s, p);
+	} else {
+		dim3 grid((p.T + 63) / 64, p.H, p.nb);
+		if (p.causal) hipLaunchKernelGGL((k_attn_fwd<T, true, false, 1>), grid, dim3(256), 0, s, p);
+		else if (p.bias) hipLaunchKernelGGL((k_attn_fwd<T, false, true, 1>), grid, dim3(256), 0, s, p);
+		else hipLaunchKernelGGL((k_attn_fwd<T, false, false, 1>), grid, dim3(256), 0, s, p);
+	}
 }
 void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s) {
 	ProfScope prof(PROF_ATTN_FWD, 4.0 * p.nb * p.H * (double)p.T * p.T * HD * (p.causal ? 0.5 : 1.0), s);
