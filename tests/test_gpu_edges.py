@@ -151,3 +151,25 @@ def test_full_size_bf16_properties():
 	m1 = get_diffuser(6, True).sample_loop(df, (1, 100, T), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E})
 	m2 = get_diffuser(6, True).sample_loop(df, (1, 100, T), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E})
 	assert torch.equal(m1, m2) and torch.isfinite(m1).all() and m1.abs().max() <= 1.0 + 1e-5     # last step: ab_prev = 1 -> x = clamp(x0)
+
+
+def test_full_size_fused_groupnorm_stats_match_oracle_and_unfused(monkeypatch):
+	"""At T % 64 == 0 and C = 1024 the GEMM epilogues emit the GroupNorm statistics (csrc/gemm.hip); check that path against
+	the CPU oracle and against the separate-kernel path (TTK_NO_FUSED_GN=1), full-size network, f32."""
+	import os
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	sd = W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 9)
+	fused = DiffusionTTS(sd, W.DIFF_FULL, dtype="f32", device=DEV)
+	monkeypatch.setenv("TTK_NO_FUSED_GN", "1")
+	plain = DiffusionTTS(sd, W.DIFF_FULL, dtype="f32", device=DEV)
+	monkeypatch.delenv("TTK_NO_FUSED_GN")
+	T = 128
+	x = torch.randn(1, 100, T, generator=gen(1))
+	E = torch.randn(1, 1024, T, generator=gen(2))
+	t = torch.tensor([1500])
+	a = fused(x.to(DEV), t.to(DEV), precomputed_aligned_embeddings=E.to(DEV))
+	b = plain(x.to(DEV), t.to(DEV), precomputed_aligned_embeddings=E.to(DEV))
+	assert maxerr(a, b) < 1e-4
+	with torch.inference_mode():
+		ref = O.DiffusionOracle(sd, W.DIFF_FULL).forward(x, t, E)
+	assert maxerr(a, ref) < 1e-3

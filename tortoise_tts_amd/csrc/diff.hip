@@ -5,6 +5,8 @@
 // different code embedding) so each weight is read once per step.
 // Reference: /root/reference/tortoise_tts/models/diffusion.py:1316-1574 (ResBlock, DiffusionLayer, DiffusionTTS),
 //            :325-431,646-694,510-554 (p_mean_variance, ddim_sample, p_sample); arch_utils.py:136-190 (AttentionBlock).
+#include <stdlib.h>
+
 #include "ttk_common.h"
 #include "ttk_host.h"
 
@@ -32,32 +34,46 @@ struct ttk_diff {
 	// workspaces
 	WsBuf cs, xs, hf, a, qkv, ao, h0, csT, xcl, outb, ecl, ms, temb, e1, e2, se, emb_all, lat_T;
 	int cur_b = 0, cur_T = 0, staged = 0;
+	const void* ms_owner = nullptr;   // tensor whose GroupNorm statistics currently sit in `ms` (written by a GEMM epilogue)
+	int fuse_stats = 1;
 };
 
+// gn_T > 0: the output is a GroupNorm input of gn_T rows per batch element; its statistics are produced in the epilogue when the
+// shape allows (gemm_fuses_gn_stats), which saves the separate k_gn_stats launch.
+static void want_stats(ttk_diff* h, GemmParams& g, int gn_T) {
+	h->ms_owner = nullptr;
+	if (h->fuse_stats && gn_T > 0 && g.out_f32 && !g.transpose_out && gemm_fuses_gn_stats(g.M, g.N, h->cfg.model_channels, gn_T)) {
+		g.gn_part = (float*)h->ms.p; g.gn_T = gn_T; h->ms_owner = g.C;
+	}
+}
+
 static void gemm1(ttk_diff* h, const void* A, int64_t lda, const Mat& m, int M, void* C, int64_t ldc, int out_f32, int act,
-				  const float* residual, hipStream_t s) {
+				  const float* residual, hipStream_t s, int gn_T = 0) {
 	GemmParams g = {};
 	g.nseg = 1; g.seg[0] = {A, lda, 0, 0};
 	g.W = m.w; g.ldw = m.Kpad; g.M = M; g.N = m.N; g.K = m.Kpad; g.bias = m.bias;
 	g.residual = residual; g.ldr = ldc; g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.act = act;
+	want_stats(h, g, gn_T);
 	launch_gemm(h->dt, g, s);
 }
 
 // k=3 'same' conv over rows inside each batch element: tap j multiplies row t + j - 1
 static void gemm_conv3(ttk_diff* h, const void* A, int64_t lda, const Mat& m, int M, int Tper, void* C, int64_t ldc, int out_f32,
-					   const float* residual, int transpose_out, hipStream_t s) {
+					   const float* residual, int transpose_out, hipStream_t s, int gn_T = 0) {
 	GemmParams g = {};
 	g.nseg = 3;
 	for (int j = 0; j < 3; ++j) g.seg[j] = {A, lda, j - 1, (int64_t)j * m.Npad * m.Kpad};
 	g.W = m.w; g.ldw = m.Kpad; g.M = M; g.N = m.N; g.K = m.Kpad; g.rows_per_batch = Tper; g.bias = m.bias;
 	g.residual = residual; g.ldr = ldc; g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.transpose_out = transpose_out;
+	want_stats(h, g, gn_T);
 	launch_gemm(h->dt, g, s);
 }
 
 static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, const float* beta, const float* scale, const float* shift,
 			   int64_t ss_stride, int act, void* out, int out_f32, const int* row_idx, int Tout, hipStream_t s) {
 	const int C = h->cfg.model_channels;
-	launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);
+	if (h->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);   // else: left by the producing GEMM
+	h->ms_owner = nullptr;
 	GnApplyParams p = {};
 	p.x = x; p.ms = (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
 	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.nchunks = gn_num_chunks(T, C); p.act = act; p.out = out; p.out_f32 = out_f32;
@@ -73,17 +89,17 @@ static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, h
 	a.qkv = h->qkv.p; a.ld = 3 * C; a.q_off = 0; a.k_off = 64; a.v_off = 128; a.head_stride = 192;   // head-major [H][3][64], arch_utils.py:79
 	a.out = h->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f;
 	launch_attn_fwd(h->dt, a, s);
-	gemm1(h, h->ao.p, C, A.proj, rows, x, C, 1, ACT_NONE, x, s);
+	gemm1(h, h->ao.p, C, A.proj, rows, x, C, 1, ACT_NONE, x, s, T);
 }
 
 // x = x + conv3(SiLU(GN(conv1(SiLU(GN(x)))) * (1 + scale) + shift))        diffusion.py:1363-1376
 static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, const float* emb_all, int64_t emb_stride, hipStream_t s) {
 	const int C = h->cfg.model_channels, rows = nb * T;
 	gn(h, x, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s);
-	gemm1(h, h->a.p, C, R.in, rows, h->hf.p, C, 1, ACT_NONE, nullptr, s);
+	gemm1(h, h->a.p, C, R.in, rows, h->hf.p, C, 1, ACT_NONE, nullptr, s, T);
 	const float* sc = emb_all + (int64_t)R.emb_slot * 2 * C;
 	gn(h, (const float*)h->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->a.p, 0, nullptr, T, s);
-	gemm_conv3(h, h->a.p, C, R.out3, rows, T, x, C, 1, x, 0, s);
+	gemm_conv3(h, h->a.p, C, R.out3, rows, T, x, C, 1, x, 0, s, T);
 }
 
 static int reserve_ws(ttk_diff* h, int nb, int T) {
@@ -130,6 +146,7 @@ static void network(ttk_diff* h, int nb, int T, const float* emb_all, int64_t em
 		g.seg[1] = {h->csT.p, C, 0, C};
 		g.W = h->integ.w; g.ldw = h->integ.Kpad; g.M = rows; g.N = C; g.K = C; g.bias = h->integ.bias;
 		g.C = x; g.ldc = C; g.out_f32 = 1;
+		want_stats(h, g, T);
 		launch_gemm(h->dt, g, s);
 	}
 	for (size_t i = 0; i < h->layers.size(); ++i) {
@@ -177,6 +194,7 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	h->dt = cfg->dtype;
 	h->es = dtype_size(h->dt);
 	h->in_pad = round_up(cfg->in_channels, 64);
+	h->fuse_stats = getenv("TTK_NO_FUSED_GN") ? 0 : 1;
 	const int C = cfg->model_channels;
 	WeightMap wm(w, n_w);
 	int rc = TTK_OK;
@@ -240,7 +258,7 @@ int ttk_diff_precompute(ttk_diff* h, const float* latents, const float* cond, co
 	TTK_TRY(h->lat_T.reserve((size_t)b * M * Cl * h->es));
 	float* x = (float*)h->xs.p;
 	launch_cast(h->dt, latents, h->lat_T.p, (int64_t)b * M * Cl, s);   // latents are already [b][M][Cl] = channels-last
-	gemm_conv3(h, h->lat_T.p, Cl, h->lat_conv, b * M, M, x, C, 1, nullptr, 0, s);
+	gemm_conv3(h, h->lat_T.p, Cl, h->lat_conv, b * M, M, x, C, 1, nullptr, 0, s, M);
 	for (int i = 0; i < 4; ++i) attn_block(h, h->lat_attn[i], x, b, M, s);
 	// code_norm(x) * (1 + scale) + shift, then nearest-neighbour expansion M -> T      diffusion.py:1492,1498,1507
 	gn(h, x, b, M, h->code_g, h->code_b, cond, cond + C, 2 * C, ACT_NONE, h->ecl.p, 1, interp_idx, T, s);

@@ -102,9 +102,39 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 				const int gn = col0 + 16 * j + lc;
 				if (GUARD && (gm >= p.M || gn >= p.N)) continue;
 				const float v = acc[i][j][r] + res[i][r][j];
+				acc[i][j][r] = v;
 				if (MODE == 2) ((float*)p.C)[((int64_t)bb * p.N + gn) * p.rows_per_batch + t] = v;
 				else if (MODE == 1) ((float*)p.C)[(int64_t)gm * p.ldc + gn] = v;
 				else ((T*)p.C)[(int64_t)gm * p.ldc + gn] = cvt<T>(v);
+			}
+		}
+	}
+	// Fused GroupNorm32 statistics of the values just written (the next op on this tensor is always a GroupNorm): the wave's
+	// block is 64 rows x NI/2 whole groups of 32 channels; exact two-pass (mean, then centred squares) in registers, two DPP wave
+	// reductions per group, one (count, mean, M2) triple per (batch, group, 64-row chunk) for k_gn_apply to merge.
+	if (MODE == 1 && p.gn_part && MI == 4 && row0 < p.M) {
+		const int b = row0 / p.gn_T, chunk = (row0 - b * p.gn_T) / 64, nch = p.gn_T / 64;
+#pragma unroll
+		for (int gq = 0; gq < NI / 2; ++gq) {
+			float sum = 0.f;
+#pragma unroll
+			for (int i = 0; i < MI; ++i)
+#pragma unroll
+				for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) sum += acc[i][2 * gq + jj][r];
+			const float mean = wave_sum(sum) * (1.0f / 2048.0f);
+			float sq = 0.f;
+#pragma unroll
+			for (int i = 0; i < MI; ++i)
+#pragma unroll
+				for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) { const float d = acc[i][2 * gq + jj][r] - mean; sq += d * d; }
+			sq = wave_sum(sq);
+			if (lane == 0) {
+				float* o = p.gn_part + (((int64_t)b * 32 + (col0 / 32 + gq)) * nch + chunk) * 3;
+				o[0] = 2048.0f; o[1] = mean; o[2] = sq;
 			}
 		}
 	}
@@ -244,18 +274,26 @@ static void launch_tile(const GemmParams& p, hipStream_t s) {
 	hipLaunchKernelGGL((k_gemm<T, BM, BN>), dim3(grid), dim3(256), LDS, s, p);
 }
 
+int g_force_tile = -1;   // TTK_GEMM_TILE=0|1|2 (tuning only)
+static int pick_tile(int M, int N) {
+	const int t128 = ((M + 127) / 128) * ((N + 127) / 128);
+	const int t12864 = ((M + 127) / 128) * ((N + 63) / 64);
+	return t128 >= 384 ? 0 : (t12864 >= 128 ? 1 : 2);
+}
+bool gemm_fuses_gn_stats(int M, int N, int C, int T) {
+	if (g_force_tile >= 100 && g_force_tile - 100 == 2) return false;
+	return C == 1024 && N == C && T % 64 == 0 && M % 64 == 0 && pick_tile(M, N) != 2;
+}
+
 // Tile choice: the diffusion GEMMs are small (M = 2b*T ~ 2k rows), so the grid must cover the 256 CUs; 128x64 tiles run two
 // workgroups per CU (72 KiB LDS, <= 128 VGPRs) so one workgroup's MFMAs overlap the other's staging.
-int g_force_tile = -1;   // TTK_GEMM_TILE=0|1|2 (tuning only)
 template <typename T>
 static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
 	if (g_force_tile < 0) { const char* e = getenv("TTK_GEMM_TILE"); g_force_tile = e ? atoi(e) + 100 : 99; }
 	int tile;
 	if (g_force_tile >= 100) tile = g_force_tile - 100;
 	else {
-		const int t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-		const int t12864 = ((p.M + 127) / 128) * ((p.N + 63) / 64);
-		tile = t128 >= 384 ? 0 : (t12864 >= 128 ? 1 : 2);
+		tile = pick_tile(p.M, p.N);
 	}
 	if (tile == 0) launch_tile<T, 128, 128>(p, s);
 	else if (tile == 1) launch_tile<T, 128, 64>(p, s);

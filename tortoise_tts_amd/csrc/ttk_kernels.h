@@ -50,8 +50,13 @@ struct GemmParams {
 	int act;            // ttk::Act
 	int out_f32;        // C is f32 (else T)
 	int transpose_out;  // C is f32 [M / rows_per_batch][N][rows_per_batch]
+	// optional fused GroupNorm32 statistics of the f32 output (see gemm_fuses_gn_stats): part[b][32][gn_T / 64][3]
+	float* gn_part; int gn_T;
 };
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s);
+// true when launch_gemm(M, N) picks a 128-row tile, i.e. each wave owns 64 rows x one or two whole 32-channel groups and can emit
+// the (count, mean, M2) triple of its block in the epilogue (needs N % 64 == 0, 32 channels per group, T % 64 == 0)
+bool gemm_fuses_gn_stats(int M, int N, int C, int T);
 
 // ---------------------------------------------------------------- skinny GEMM for decode (skinny.hip)
 // out[M<=16*MT, N] = epilogue( LN?(x)[M,K] * W[N,K]^T + bias ), weights streamed once from HBM in MFMA-fragment
