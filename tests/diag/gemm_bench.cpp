@@ -1,0 +1,61 @@
+// Diagnostic (not a test, not product code): times the dense GEMM on the shapes of the benchmark step.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tortoise_tts_amd/csrc tests/diag/gemm_bench.cpp -o /tmp/gemm_bench && /tmp/gemm_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+#include "../../tortoise_tts_amd/csrc/gemm.hip"
+bool ttk::g_prof_on = false;
+void ttk::prof_start(int, double, hipStream_t) {}
+void ttk::prof_stop(hipStream_t) {}
+using namespace ttk;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+__global__ void fill(unsigned short* p, size_t n, unsigned seed) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) { unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 13; h *= 0x5bd1e995; p[i] = (unsigned short)(0x3c00 + (h & 0x3ff) - ((h >> 10) & 1) * 0x8000); }   // ~[-2, 2) bf16 bit patterns
+}
+int main(int argc, char** argv) {
+	struct Shape { const char* name; int M, N, K, nseg, T, resid; } shapes[] = {
+		{"1x1 conv  2176x1024x1024", 2176, 1024, 1024, 1, 1088, 0},
+		{"proj+res  2176x1024x1024", 2176, 1024, 1024, 1, 1088, 1},
+		{"conv3+res 2176x1024x3x1024", 2176, 1024, 1024, 3, 1088, 1},
+		{"qkv       2176x3072x1024", 2176, 3072, 1024, 1, 1088, 0},
+		{"integ     2176x1024x2x1024", 2176, 1024, 1024, 2, 1088, 0},
+		{"ar c_attn 5104x3072x1024", 5104, 3072, 1024, 1, 0, 0},
+		{"ar c_fc   5104x4096x1024", 5104, 4096, 1024, 1, 0, 0},
+		{"ar proj2  5104x1024x4096", 5104, 1024, 4096, 1, 0, 1},
+	};
+	hipStream_t s; CK(hipStreamCreate(&s));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	for (auto& sh : shapes) {
+		const int Npad = (sh.N + 127) / 128 * 128;
+		void *A, *W, *Cb; float *bias, *Cf;
+		const size_t an = (size_t)sh.M * sh.K * (sh.nseg == 2 ? 2 : 1), wn = (size_t)sh.nseg * Npad * sh.K;
+		CK(hipMalloc(&A, an * 2)); CK(hipMalloc(&W, wn * 2)); CK(hipMalloc(&Cb, (size_t)sh.M * sh.N * 2)); CK(hipMalloc(&Cf, (size_t)sh.M * sh.N * 4)); CK(hipMalloc(&bias, sh.N * 4));
+		fill<<<(an + 255) / 256, 256, 0, s>>>((unsigned short*)A, an, 1); fill<<<(wn + 255) / 256, 256, 0, s>>>((unsigned short*)W, wn, 2);
+		CK(hipMemsetAsync(bias, 0, sh.N * 4, s)); CK(hipMemsetAsync(Cf, 0, (size_t)sh.M * sh.N * 4, s));
+		GemmParams g = {};
+		g.nseg = sh.nseg;
+		for (int j = 0; j < sh.nseg; ++j) {
+			if (sh.nseg == 3) g.seg[j] = {A, sh.K, j - 1, (int64_t)j * Npad * sh.K};
+			else if (sh.nseg == 2) g.seg[j] = {(char*)A + (size_t)j * sh.M * sh.K * 2, sh.K, 0, (int64_t)j * sh.K};
+			else g.seg[j] = {A, sh.K, 0, 0};
+		}
+		g.W = W; g.ldw = sh.nseg == 2 ? 2 * sh.K : sh.K; g.M = sh.M; g.N = sh.N; g.K = sh.K; g.rows_per_batch = sh.T; g.bias = bias;
+		if (sh.resid) { g.residual = Cf; g.ldr = sh.N; g.C = Cf; g.ldc = sh.N; g.out_f32 = 1; } else { g.C = Cb; g.ldc = sh.N; }
+		for (int tile = 0; tile < 4; ++tile) {
+			g_force_tile = 100 + tile;
+			for (int i = 0; i < 5; ++i) launch_gemm(DT_BF16, g, s);
+			CK(hipStreamSynchronize(s));
+			const int reps = 50;
+			CK(hipEventRecord(e0, s));
+			for (int i = 0; i < reps; ++i) launch_gemm(DT_BF16, g, s);
+			CK(hipEventRecord(e1, s));
+			CK(hipEventSynchronize(e1));
+			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+			const double us = ms * 1e3 / reps, tf = 2.0 * sh.M * sh.N * (double)sh.K * sh.nseg / (us * 1e-6) / 1e12;
+			printf("%-30s tile %s  %8.2f us  %7.1f TF/s\n", sh.name, tile == 0 ? "128x128 8w" : tile == 1 ? "128x64  4w" : tile == 3 ? "128x128 4w" : "64x64   4w", us, tf);
+		}
+		CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(Cb)); CK(hipFree(Cf)); CK(hipFree(bias));
+	}
+	return 0;
+}

@@ -140,15 +140,18 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 	}
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(GemmParams p) {
+// NWM x NWN waves per workgroup; 8 waves (2 per SIMD) let one wave's MFMAs run under another's LDS reads and DMA issue.
+template <typename T, int BM, int BN, int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	constexpr int ES = sizeof(T);
 	constexpr int BKE = 128 / ES;      // K elements per tile row
 	constexpr int KSTEPS = BKE / 32;   // MFMA k-steps per tile
 	constexpr int FCH = 8 * ES / 16;   // 16-byte chunks per fragment
 	constexpr int EPC = 16 / ES;       // elements per chunk
-	constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 16, NI = WN / 16;
-	constexpr int A_PC = BM / 8 / 4, B_PC = BN / 8 / 4;   // 1-KiB pieces per wave per tile
+	constexpr int NW = NWM * NWN;
+	constexpr int WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
+	constexpr int A_PC = BM / 8 / NW, B_PC = BN / 8 / NW;   // 1-KiB pieces per wave per tile
+	static_assert(A_PC >= 1 && B_PC >= 1 && A_PC * 8 * NW == BM && B_PC * 8 * NW == BN, "tile does not split into 1-KiB pieces per wave");
 	constexpr int PER_TILE = A_PC + B_PC;                  // glds instructions per wave per tile
 	constexpr int STAGE = (BM + BN) * 128;
 	constexpr int NSTAGE = 3;
@@ -156,9 +159,17 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(Gem
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int wm = wave >> 1, wn = wave & 1;
+	const int wm = wave / NWN, wn = wave % NWN;
 	const int tiles_m = (p.M + BM - 1) / BM;
-	const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * BN;
+	// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give
+	// each XCD label (blockIdx % 8) a CONTIGUOUS run of the n-major tile order = a few n-tiles x all m-tiles.  Its private 4 MiB
+	// L2 then holds that weight slice while the activations stream through once, instead of every XCD caching all of W.
+	int tile_id;
+	{
+		const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+		tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+	}
+	const int m0 = (tile_id % tiles_m) * BM, n0 = (tile_id / tiles_m) * BN;
 	const int KT = p.K / BKE;
 	const int NTILES = p.nseg * KT;
 
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(Gem
 	int a_gm[A_PC], a_t[A_PC];
 #pragma unroll
 	for (int i = 0; i < A_PC; ++i) {
-		a_gm[i] = m0 + 8 * (wave + 4 * i) + prow;
+		a_gm[i] = m0 + 8 * (wave + NW * i) + prow;
 		a_t[i] = p.rows_per_batch > 0 ? a_gm[i] % p.rows_per_batch : 0;
 	}
 	const char* zero = (const char*)g_zero_page;
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(Gem
 		const T* Wb = (const T*)p.W + p.seg[sg].w_off;
 #pragma unroll
 		for (int i = 0; i < A_PC; ++i) {
-			const int row = 8 * (wave + 4 * i) + prow;        // row inside the tile
+			const int row = 8 * (wave + NW * i) + prow;        // row inside the tile
 			const int c = pslot ^ (row & 7);                   // logical chunk landing in this lane's slot
 			const int t = a_t[i] + shift;
 			const bool ok = a_gm[i] < p.M && (shift == 0 || (t >= 0 && t < p.rows_per_batch));
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(Gem
 		}
 #pragma unroll
 		for (int i = 0; i < B_PC; ++i) {
-			const int row = 8 * (wave + 4 * i) + prow;
+			const int row = 8 * (wave + NW * i) + prow;
 			const int c = pslot ^ (row & 7);
 			b_src[i] = (const char*)(Wb + (int64_t)(n0 + row) * p.ldw + c * EPC);
 		}
@@ -203,9 +214,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(Gem
 		const unsigned As = smem_base + stage * STAGE;
 		const unsigned Bs = As + BM * 128;
 #pragma unroll
-		for (int i = 0; i < A_PC; ++i) { glds16(a_src[i], As + (wave + 4 * i) * 1024); a_src[i] += a_inc[i]; }
+		for (int i = 0; i < A_PC; ++i) { glds16(a_src[i], As + (wave + NW * i) * 1024); a_src[i] += a_inc[i]; }
 #pragma unroll
-		for (int i = 0; i < B_PC; ++i) { glds16(b_src[i], Bs + (wave + 4 * i) * 1024); b_src[i] += 128; }
+		for (int i = 0; i < B_PC; ++i) { glds16(b_src[i], Bs + (wave + NW * i) * 1024); b_src[i] += 128; }
 		if (++kk_i == KT) { kk_i = 0; ++seg_i; }
 	};
 
@@ -262,31 +273,33 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64) ? 2 : 1) void k_gemm(Gem
 	else { if (full) epilogue<T, 0, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 0, true, MI, NI>(p, acc, row0, col0, lane); }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NWM, int NWN>
 static void launch_tile(const GemmParams& p, hipStream_t s) {
 	constexpr int LDS = 3 * (BM + BN) * 128;
 	static bool attr_set = false;
 	if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_set = true;
 	}
 	const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-	hipLaunchKernelGGL((k_gemm<T, BM, BN>), dim3(grid), dim3(256), LDS, s, p);
+	hipLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN>), dim3(grid), dim3(64 * NWM * NWN), LDS, s, p);
 }
 
 int g_force_tile = -1;   // TTK_GEMM_TILE=0|1|2 (tuning only)
 static int pick_tile(int M, int N) {
 	const int t128 = ((M + 127) / 128) * ((N + 127) / 128);
 	const int t12864 = ((M + 127) / 128) * ((N + 63) / 64);
-	return t128 >= 384 ? 0 : (t12864 >= 128 ? 1 : 2);
+	return t128 >= 256 ? 0 : (t12864 >= 128 ? 1 : 2);
 }
 bool gemm_fuses_gn_stats(int M, int N, int C, int T) {
 	if (g_force_tile >= 100 && g_force_tile - 100 == 2) return false;
 	return C == 1024 && N == C && T % 64 == 0 && M % 64 == 0 && pick_tile(M, N) != 2;
 }
 
-// Tile choice: the diffusion GEMMs are small (M = 2b*T ~ 2k rows), so the grid must cover the 256 CUs; 128x64 tiles run two
-// workgroups per CU (72 KiB LDS, <= 128 VGPRs) so one workgroup's MFMAs overlap the other's staging.
+// Tile choice.  Measured (tests/diag/gemm_bench.cpp): on these shapes the kernel is bound by the per-CU LDS-DMA fill rate
+// (~70 GB/s from L2), so what matters is bytes staged per flop and an even spread over the 256 CUs: 128x128 x 8 waves once there
+// are >= 256 such tiles (575-600 TF/s at M = 5k), else 128x64 x 4 waves with two workgroups per CU (the 2k-row diffusion GEMMs,
+// 335-520 TF/s), 64x64 for tiny M.
 template <typename T>
 static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
 	if (g_force_tile < 0) { const char* e = getenv("TTK_GEMM_TILE"); g_force_tile = e ? atoi(e) + 100 : 99; }
@@ -295,9 +308,10 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
 	else {
 		tile = pick_tile(p.M, p.N);
 	}
-	if (tile == 0) launch_tile<T, 128, 128>(p, s);
-	else if (tile == 1) launch_tile<T, 128, 64>(p, s);
-	else launch_tile<T, 64, 64>(p, s);
+	if (tile == 0) launch_tile<T, 128, 128, 2, 4>(p, s);       // 8 waves, wave block 64 x 32
+	else if (tile == 1) launch_tile<T, 128, 64, 2, 2>(p, s);   // 4 waves, wave block 64 x 32, two workgroups per CU
+	else if (tile == 3) launch_tile<T, 128, 128, 2, 2>(p, s);  // 4 waves, wave block 64 x 64 (tuning only)
+	else launch_tile<T, 64, 64, 2, 2>(p, s);
 }
 
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
