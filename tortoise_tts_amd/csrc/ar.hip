@@ -86,7 +86,10 @@ struct ttk_ar {
 	int* d_pos;             // device scalar: number of valid cache rows
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
-	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV
+	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
+	int nsplit = 1;               // row groups decoded concurrently (TTK_AR_SPLIT; measured slower: 283 -> 340 ms at 2, see below)
+	hipStream_t side[3] = {nullptr, nullptr, nullptr};
+	hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 	WsBuf ws_x, ws_a, ws_qkv, ws_ao, ws_h;
 	int B = 0, P = 0, k = 0, ready = 0;
 };
@@ -145,6 +148,55 @@ static void head_launch(ttk_ar* h, int B, float* logits, float* hidden_out, hipS
 	launch_skinny(h->dt, p, h->cfg.model_dim >= 1024 ? 8 : 4, s);
 }
 
+// one row group [r0, r0 + nrows) of a decode step on stream s: 30 x {ln_1+c_attn+KV append, attention, c_proj+res, ln_2+c_fc+gelu,
+// mlp.c_proj+res} + ln_f/final_norm/mel_head
+static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out, float* hidden_out, hipStream_t s) {
+	const ttk_ar_config& c = h->cfg;
+	const int d = c.model_dim, H = c.heads, dt = h->dt;
+	const size_t es = h->es;
+	float* x = h->x + (size_t)r0 * d;
+	float* qbuf = h->qbuf + (size_t)r0 * d;
+	char* attn_out = (char*)h->attn_out + (size_t)r0 * d * es;
+	char* hbuf = (char*)h->hbuf + (size_t)r0 * 4 * d * es;
+	const size_t kv_row = (size_t)H * c.max_ctx * 64 * es;
+	const int wv_small = d >= 1024 ? 8 : 4;   // waves per workgroup that split K = d
+	for (int l = 0; l < c.layers; ++l) {
+		const ARLayer& L = h->L[l];
+		char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
+		char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
+		SkinnyParams p = {};
+		p.Wp = L.attn.wfrag; p.N = 3 * d; p.K = d; p.M = nrows; p.bias = L.attn.bias;
+		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b;
+		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
+		launch_skinny(dt, p, wv_small, s);
+		AttnDecodeParams a = {};
+		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out;
+		launch_attn_decode(dt, a, s);
+		p = {};
+		p.Wp = L.proj.wfrag; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d;
+		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
+		launch_skinny(dt, p, wv_small, s);
+		p = {};
+		p.Wp = L.fc.wfrag; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
+		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b;
+		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf;
+		launch_skinny(dt, p, wv_small, s);
+		p = {};
+		p.Wp = L.proj2.wfrag; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d;
+		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
+		if (d >= 1024) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
+			p.ksplit = 4; p.slab = h->slab + (size_t)gi * (d / 16) * 4 * 4 * 256; p.tickets = h->tickets + (size_t)gi * (d / 16);
+		}
+		launch_skinny(dt, p, d >= 1024 ? 8 : 4, s);
+	}
+	SkinnyParams p = {};
+	p.Wp = h->head.wfrag; p.N = c.number_mel_codes; p.K = d; p.M = nrows; p.bias = h->head.bias;
+	p.ln_count = 2; p.x = x; p.ldx = d;
+	p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hidden_out ? hidden_out + (size_t)r0 * d : nullptr;
+	p.mode = SK_STORE_F32; p.out_f32 = logits_out + (size_t)r0 * c.number_mel_codes; p.ldc = c.number_mel_codes;
+	launch_skinny(dt, p, d >= 1024 ? 8 : 4, s);
+}
+
 extern "C" {
 
 int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view* w, int n_w) {
@@ -195,9 +247,19 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc(&h->attn_out, (size_t)cfg->max_batch * d * h->es));
 	AR_TRY(h->arena.alloc(&h->hbuf, (size_t)cfg->max_batch * 4 * d * h->es));
-	AR_TRY(h->arena.alloc((void**)&h->slab, (size_t)(d / 16) * 4 * 4 * 256 * sizeof(float)));
-	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)(d / 16) * sizeof(int)));
-	if (hipMemset(h->tickets, 0, (size_t)(d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
+	AR_TRY(h->arena.alloc((void**)&h->slab, (size_t)4 * (d / 16) * 4 * 4 * 256 * sizeof(float)));
+	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)4 * (d / 16) * sizeof(int)));
+	if (hipMemset(h->tickets, 0, (size_t)4 * (d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
+	{
+		const char* e = getenv("TTK_AR_SPLIT");
+		h->nsplit = e ? atoi(e) : 1;
+		if (h->nsplit != 1 && h->nsplit != 2 && h->nsplit != 4) h->nsplit = 1;
+		if (hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(TTK_E_HIP);
+		for (int i = 0; i < 3; ++i) {
+			if (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess) return fail(TTK_E_HIP);
+			if (hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) != hipSuccess) return fail(TTK_E_HIP);
+		}
+	}
 #undef AR_TRY
 	hipError_t e = hipDeviceSynchronize();
 	if (e != hipSuccess) { set_error("ttk_ar_create: %s", hipGetErrorString(e)); return fail(TTK_E_HIP); }
@@ -208,6 +270,8 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 int ttk_ar_destroy(ttk_ar* h) {
 	if (!h) return TTK_OK;
 	(void)hipDeviceSynchronize();
+	for (int i = 0; i < 3; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
+	if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
 	h->ws_x.release(); h->ws_a.release(); h->ws_qkv.release(); h->ws_ao.release(); h->ws_h.release();
 	h->arena.release();
 	delete h;
@@ -247,35 +311,25 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)
 	launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s);
-	const int wv_small = d >= 1024 ? 8 : 4;   // waves per workgroup that split K = d
-	for (int l = 0; l < c.layers; ++l) {
-		const ARLayer& L = h->L[l];
-		char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * h->es;
-		char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * h->es;
-		SkinnyParams p = {};
-		p.Wp = L.attn.wfrag; p.N = 3 * d; p.K = d; p.M = B; p.bias = L.attn.bias;
-		p.ln_count = 1; p.x = h->x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b;
-		p.mode = SK_QKV; p.qbuf = h->qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
-		launch_skinny(dt, p, wv_small, s);
-		AttnDecodeParams a = {};
-		a.qbuf = h->qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = B; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = h->attn_out;
-		launch_attn_decode(dt, a, s);
-		p = {};
-		p.Wp = L.proj.wfrag; p.N = d; p.K = d; p.M = B; p.bias = L.proj.bias; p.a = h->attn_out; p.lda = d;
-		p.mode = SK_RESIDUAL; p.out_f32 = h->x; p.ldc = d;
-		launch_skinny(dt, p, wv_small, s);
-		p = {};
-		p.Wp = L.fc.wfrag; p.N = 4 * d; p.K = d; p.M = B; p.bias = L.fc.bias;
-		p.ln_count = 1; p.x = h->x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b;
-		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = h->hbuf;
-		launch_skinny(dt, p, wv_small, s);
-		p = {};
-		p.Wp = L.proj2.wfrag; p.N = d; p.K = 4 * d; p.M = B; p.bias = L.proj2.bias; p.a = h->hbuf; p.lda = 4 * d;
-		p.mode = SK_RESIDUAL; p.out_f32 = h->x; p.ldc = d;
-		if (d >= 1024) { p.ksplit = 4; p.slab = h->slab; p.tickets = h->tickets; }   // 64 n-tiles x 4 K-slices = 256 workgroups
-		launch_skinny(dt, p, d >= 1024 ? 8 : 4, s);
+	// Experiment kept behind TTK_AR_SPLIT (default 1 = off): cut the candidates into row groups whose launch chains run on forked
+	// streams.  Rows are independent, so results are unchanged -- but on MI355X it LOSES (B=16, 250 tokens: 283 ms -> 340 ms with
+	// 2 groups, 517 ms with 4): the LayerNorm kernels already hold one 8-wave workgroup per CU, so the second chain cannot
+	// co-reside and only the doubled weight traffic remains.
+	int nsplit = h->nsplit;
+	while (nsplit > 1 && B / nsplit < 1) nsplit >>= 1;
+	if (nsplit > 1) {
+		TTK_HIP(hipEventRecord(h->ev_fork, s));
+		for (int gi = 1; gi < nsplit; ++gi) TTK_HIP(hipStreamWaitEvent(h->side[gi - 1], h->ev_fork, 0));
 	}
-	head_launch(h, B, logits_out, hidden_out, s);
+	for (int gi = 0; gi < nsplit; ++gi) {
+		hipStream_t gs = gi == 0 ? s : h->side[gi - 1];
+		const int r0 = (B * gi) / nsplit, r1 = (B * (gi + 1)) / nsplit;
+		decode_rows(h, r0, r1 - r0, gi, logits_out, hidden_out, gs);
+	}
+	for (int gi = 1; gi < nsplit; ++gi) {
+		TTK_HIP(hipEventRecord(h->ev_join[gi - 1], h->side[gi - 1]));
+		TTK_HIP(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
+	}
 	launch_add_int(h->d_pos, 1, s);
 	h->k += 1;
 	TTK_HIP(hipGetLastError());

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
 	{
 		const float* qp = p.qbuf + ((int64_t)b * p.H + h) * HD + 8 * dg;
 #pragma unroll
-		for (int j = 0; j < 8; ++j) q[j] = qp[j];
+		for (int j = 0; j < 8; ++j) q[j] = qp[j] * LOG2E;   // log2-domain scores: exp2 is a single v_exp_f32
 	}
 	// this wave's contiguous key range, in groups of 8 keys
 	const int groups = (n + 7) / 8;
@@ -325,13 +325,13 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
 			float sdot = 0.f;
 #pragma unroll
 			for (int j = 0; j < 8; ++j) sdot += q[j] * (float)kf[u][j];
-			sdot += __shfl_xor(sdot, 1);
-			sdot += __shfl_xor(sdot, 2);
-			sdot += __shfl_xor(sdot, 4);
+			sdot = dpp_add<0xB1>(sdot);    // the 8 lanes of a key: quad swaps + row_half_mirror, all DPP
+			sdot = dpp_add<0x4E>(sdot);
+			sdot = dpp_add<0x141>(sdot);
 			const bool valid = (gb + u) < g1 && key < n;
 			if (valid) {
 				const float m_new = fmaxf(m, sdot);
-				const float alpha = __expf(m - m_new), pv = __expf(sdot - m_new);
+				const float alpha = __builtin_amdgcn_exp2f(m - m_new), pv = __builtin_amdgcn_exp2f(sdot - m_new);
 				l = l * alpha + pv;
 #pragma unroll
 				for (int j = 0; j < 8; ++j) acc[j] = acc[j] * alpha + pv * (float)vf[u][j];
@@ -339,29 +339,21 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
 			}
 		}
 	}
-	// merge the 8 key slots of the wave (lanes differing in bits 3..5)
+	// merge the 32 (wave, key-slot) partial softmaxes through LDS: one barrier and a 32-term loop per output element instead
+	// of ~30 dependent cross-lane permutes
+	__shared__ float sm[32], sl[32], sacc[32][HD + 1];
+	const int ps = wave * 8 + slot;
+	if (dg == 0) { sm[ps] = m; sl[ps] = l; }
 #pragma unroll
-	for (int off = 8; off < 64; off <<= 1) {
-		const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
-		const float mn = fmaxf(m, m2);
-		const float a1 = __expf(m - mn), a2 = __expf(m2 - mn);
-		l = l * a1 + l2 * a2;
-#pragma unroll
-		for (int j = 0; j < 8; ++j) { const float o2 = __shfl_xor(acc[j], off); acc[j] = acc[j] * a1 + o2 * a2; }
-		m = mn;
-	}
-	__shared__ float sm[4], sl[4], sacc[4][HD];
-	if (slot == 0) {
-		if (dg == 0) { sm[wave] = m; sl[wave] = l; }
-#pragma unroll
-		for (int j = 0; j < 8; ++j) sacc[wave][8 * dg + j] = acc[j];
-	}
+	for (int j = 0; j < 8; ++j) sacc[ps][8 * dg + j] = acc[j];
 	__syncthreads();
 	if (tid < HD) {
-		const float mn = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+		float mn = NEG_BIG;
+#pragma unroll
+		for (int i = 0; i < 32; ++i) mn = fmaxf(mn, sm[i]);
 		float lt = 0.f, ot = 0.f;
 #pragma unroll
-		for (int w = 0; w < 4; ++w) { const float a = __expf(sm[w] - mn); lt += sl[w] * a; ot += sacc[w][tid] * a; }
+		for (int i = 0; i < 32; ++i) { const float a = __builtin_amdgcn_exp2f(sm[i] - mn); lt += sl[i] * a; ot += sacc[i][tid] * a; }
 		((T*)p.out)[((int64_t)b * p.H + h) * HD + tid] = cvt<T>(ot / lt);
 	}
 }
