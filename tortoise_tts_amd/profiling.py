@@ -37,6 +37,18 @@ def collect(step_fn, ar=None):
 	return {k: dict(ms=res[i].ms, launches=int(res[i].launches), work=res[i].work) for i, k in enumerate(KINDS)}
 
 
+def _pmc_traffic(kind):
+	"""HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json); PMC counters cannot be
+	read from inside a running benchmark, so this is the last measured value, or None for kernels without a PMC pass."""
+	import glob
+	import json
+	import os
+	files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r*_pmc_traffic.json")))
+	if not files or kind != "skinny_gemm":
+		return None
+	return json.load(open(files[-1])).get("k_skinny_avg_hbm_bytes_per_launch")
+
+
 def dominant_kernel_roofline(step_fn, ar, df):
 	table = collect(step_fn, ar)
 	kind = max(table, key=lambda k: table[k]["ms"])
@@ -47,6 +59,6 @@ def dominant_kernel_roofline(step_fn, ar, df):
 		achieved, peak, unit, bound = r["work"] / sec / 1e12, PEAK_TFLOPS[df.dtype], "TFLOP/s", "mfma"
 	else:
 		achieved, peak, unit, bound = r["work"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-	return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": None,
+	return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": _pmc_traffic(kind),
 			"kernel": KERNEL_NAMES[kind], "launches_per_step": r["launches"], "avg_launch_us": 1e3 * r["ms"] / max(r["launches"], 1),
 			"algorithmic_work_per_launch": r["work"] / max(r["launches"], 1), "per_kernel_ms": breakdown}
