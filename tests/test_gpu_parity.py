@@ -197,3 +197,17 @@ def test_p_sampler_matches_oracle_with_same_noise(lib, golden):
 			mean, log_var, _ = sched.p_mean_variance(d, x, i, Eg)
 			x = mean + (0.0 if i == 0 else 1.0) * torch.exp(0.5 * log_var) * draws[j]
 	assert maxerr(mel, x) < 1e-3
+
+
+def test_multinomial1_is_torch_multinomial_on_device():
+	"""sampling.multinomial1 must stay bit-identical (values AND generator consumption) to torch.multinomial(p, 1)."""
+	from tortoise_tts_amd.sampling import multinomial1
+	for shape, seed in (((16, 8194), 0), ((3, 8194), 5), ((1, 17), 9)):
+		p = torch.softmax(torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * 3, -1).to(DEV)
+		torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
+		a = [torch.multinomial(p, num_samples=1).squeeze(1) for _ in range(5)]
+		after_a = torch.rand(4, device=DEV)
+		torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
+		b = [multinomial1(p) for _ in range(5)]
+		after_b = torch.rand(4, device=DEV)
+		assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(after_a, after_b)

@@ -18,7 +18,7 @@ from typing import Dict, Iterator, Optional, Tuple
 import torch
 
 from . import _lib
-from .sampling import LogitsPipeline, setup_seed
+from .sampling import LogitsPipeline, multinomial1, setup_seed
 from .weights import ARConfig, ar_shapes
 
 
@@ -226,7 +226,7 @@ class UnifiedVoice:
 			hist[:, -1] = c.start_mel_token
 			for n in range(max_new):
 				scores = pipe(hist if pipe.needs_history else None, logits)
-				nxt = torch.multinomial(torch.nn.functional.softmax(scores, dim=-1), num_samples=1).squeeze(1)
+				nxt = multinomial1(torch.nn.functional.softmax(scores, dim=-1))
 				nxt = nxt * unfinished + c.stop_mel_token * (1 - unfinished)
 				unfinished = unfinished * (nxt != c.stop_mel_token).long()
 				if pipe.needs_history:
@@ -268,7 +268,7 @@ class _GenState:
 		hist = None if self.history is None else self.history[:, :self.trunc_index + n]
 		scores = self.pipe(hist, self.logits)
 		probs = torch.nn.functional.softmax(scores, dim=-1)
-		nxt = torch.multinomial(probs, num_samples=1).squeeze(1)
+		nxt = multinomial1(probs)
 		nxt = nxt * self.unfinished + self.stop * (1 - self.unfinished)
 		self.tok.copy_(nxt)
 		self.ids.index_copy_(1, self.col, nxt[:, None])

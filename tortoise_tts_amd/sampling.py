@@ -80,6 +80,16 @@ class LogitsPipeline:
 		return s
 
 
+def multinomial1(probs: torch.Tensor) -> torch.Tensor:
+	"""One draw per row, bit-identical to `torch.multinomial(probs, num_samples=1).squeeze(1)` including the generator stream:
+	for n_sample == 1 ATen's multinomial IS `q = empty_like(p).exponential_(1); argmax(p / q)` (aten/src/ATen/native/
+	Distributions.cpp, "s = argmax(p / q) where q ~ Exp(1)") preceded by three validity reductions + `_assert_async` on the
+	input.  Calling the same three ops directly drops those ~8 tiny launches per token; `tests/test_gpu_parity.py` checks the
+	equality on the device so a future change of ATen's algorithm cannot pass unnoticed."""
+	q = torch.empty_like(probs).exponential_(1)
+	return torch.argmax(probs / q, dim=-1)
+
+
 def setup_seed(seed: int):
 	"""stream_generator.py:38-46 (called with seed=0 on every generate, :223,:296)."""
 	import random
