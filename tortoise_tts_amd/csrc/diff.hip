@@ -103,6 +103,7 @@ static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, con
 }
 
 static int reserve_ws(ttk_diff* h, int nb, int T) {
+	TTK_REQUIRE(gn_num_chunks(T, h->cfg.model_channels) <= 64, TTK_E_ARG, "%d frames exceed the GroupNorm chunk table (64 chunks)", T);
 	const size_t rows = (size_t)nb * T, C = h->cfg.model_channels, es = h->es;
 	TTK_TRY(h->cs.reserve(rows * C * 4)); TTK_TRY(h->xs.reserve(rows * C * 4)); TTK_TRY(h->hf.reserve(rows * C * 4));
 	TTK_TRY(h->a.reserve(rows * C * es)); TTK_TRY(h->qkv.reserve(rows * 3 * C * es)); TTK_TRY(h->ao.reserve(rows * C * es));

@@ -127,15 +127,28 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	const int strip = rpp * GN_PASSES;
 	const int strips = (p.Tout + strip - 1) / strip;
 	const int b = blockIdx.x / strips, t0 = (blockIdx.x - b * strips) * strip;
-	if (threadIdx.x < 32) {
-		const float* part = p.ms + ((int64_t)b * 32 + threadIdx.x) * p.nchunks * 3;
-		float nt = 0.f, mean = 0.f;
-		for (int k = 0; k < p.nchunks; ++k) { nt += part[3 * k]; mean += part[3 * k] * part[3 * k + 1]; }
-		mean /= nt;
+	{   // merge: 8 lanes per group, every chunk triple requested up front (one L2 latency, not one per chunk), DPP sums
+		const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
+		float cn[8], cm[8], c2[8];
+		float nt = 0.f, wsum = 0.f;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group
+			const int k = sub + 8 * i;
+			const bool ok = k < p.nchunks;
+			const int kk = ok ? k : 0;
+			const float a0 = part[3 * kk], a1 = part[3 * kk + 1], a2 = part[3 * kk + 2];
+			cn[i] = ok ? a0 : 0.f; cm[i] = ok ? a1 : 0.f; c2[i] = ok ? a2 : 0.f;
+			nt += cn[i]; wsum += cn[i] * cm[i];
+		}
+		nt = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(nt)));
+		wsum = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(wsum)));
+		const float mean = wsum / nt;
 		float m2 = 0.f;
-		for (int k = 0; k < p.nchunks; ++k) { const float d = part[3 * k + 1] - mean; m2 += part[3 * k + 2] + part[3 * k] * d * d; }
-		s_mean[threadIdx.x] = mean;
-		s_rstd[threadIdx.x] = rsqrtf(m2 / nt + 1e-5f);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { const float d = cm[i] - mean; m2 += c2[i] + cn[i] * d * d; }
+		m2 = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(m2)));
+		if (sub == 0) { s_mean[g] = mean; s_rstd[g] = rsqrtf(m2 / nt + 1e-5f); }
 	}
 	__syncthreads();
 	const int c = (threadIdx.x % c4n) * 4, rr = threadIdx.x / c4n;
