@@ -102,12 +102,20 @@ def main():
 	if world != a.gpus:
 		if world == 1 and a.gpus > 1:
 			raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+	# TTK_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- lets the N>1 control flow run on a 1-GPU box
+	# (RCCL refuses two ranks on one device).  Never used by the driver; the number it prints is not a scaling result.
+	rehearsal = os.environ.get("TTK_BENCH_REHEARSAL") == "1"
+	if rehearsal:
+		local = 0
 	torch.cuda.set_device(local)
 	dev = f"cuda:{local}"
 	import torch.distributed as dist
 	if world > 1:
 		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-		dist.init_process_group("nccl", device_id=torch.device(dev))
+		if rehearsal:
+			dist.init_process_group("gloo")
+		else:
+			dist.init_process_group("nccl", device_id=torch.device(dev))
 
 	from tortoise_tts_amd import _lib, weights as W
 	from tortoise_tts_amd.autoregressive import UnifiedVoice
@@ -125,12 +133,13 @@ def main():
 	df_lat = torch.randn(1, 2 * df_cfg.model_channels, generator=g).to(dev)
 	kw = dict(max_ar_steps=MEL_TOKENS, max_diffusion_steps=DDIM_STEPS, ar_temp=0.8, candidates=CANDIDATES,
 			  suppress_tokens=[ar_cfg.stop_mel_token], return_all=True)
-	gathered = [torch.empty((CANDIDATES, MEL_TOKENS), dtype=torch.long, device=dev) for _ in range(world)] if world > 1 else None
+	gdev = "cpu" if rehearsal else dev
+	gathered = [torch.empty((CANDIDATES, MEL_TOKENS), dtype=torch.long, device=gdev) for _ in range(world)] if world > 1 else None
 
 	def step():
 		mels, seconds, aux = tts.inference(text, ar_lat, df_lat, **kw)
 		if world > 1:   # hand the candidate ids to the scoring rank (RCCL all-gather over xGMI, 32 KB per rank)
-			dist.all_gather(gathered, aux["codes"].contiguous())
+			dist.all_gather(gathered, aux["codes"].contiguous().to(gdev))
 		return seconds
 
 	def fence():
@@ -149,7 +158,7 @@ def main():
 		audio += step()
 	fence()
 	dt = time.perf_counter() - t0
-	tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+	tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
 	if world > 1:
 		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 	dt = float(tmax.item())

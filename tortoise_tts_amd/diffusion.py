@@ -257,7 +257,7 @@ class SpacedDiffusion:
 		return s
 
 	def sample_loop(self, model: DiffusionTTS, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-					model_kwargs=None, device=None, progress=False, eta=0.0, sampler="ddim"):
+					model_kwargs=None, device=None, progress=False, eta=0.0, sampler="ddim", consume_rng=True):
 		"""diffusion.py:500-508 -> ddim_sample_loop :734-810 / p_sample_loop :556-644.  Returns f32 [b, 100, T]."""
 		sampler = sampler.lower()
 		if sampler not in ("ddim", "p"):
@@ -282,8 +282,10 @@ class SpacedDiffusion:
 				_lib.check(model.lib.ttk_diff_sample_ddim(model._h, x.data_ptr(), E.data_ptr(), b, T, steps, n, _lib.stream_ptr()),
 						   "ttk_diff_sample_ddim")
 				# ddim_sample draws (and ignores) one randn_like(x) per step (:685); keep the generator stream aligned
-				for _ in range(n):
-					torch.randn_like(x)
+				# (consume_rng=False: the caller already made these draws, see TTSHotPath.inference_lines)
+				if consume_rng:
+					for _ in range(n):
+						torch.randn_like(x)
 			else:
 				_lib.check(model.lib.ttk_diff_begin(model._h, E.data_ptr(), b, T, _lib.stream_ptr()), "ttk_diff_begin")
 				for i in reversed(range(n)):
