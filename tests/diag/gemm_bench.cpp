@@ -15,6 +15,8 @@ __global__ void fill(unsigned short* p, size_t n, unsigned seed) {
 }
 int main(int argc, char** argv) {
 	struct Shape { const char* name; int M, N, K, nseg, T, resid; } shapes[] = {
+		{"fixed-cost probe K=128 bf16 out", 2176, 1024, 128, 1, 1088, 0},
+		{"fixed-cost probe K=128 f32+res", 2176, 1024, 128, 1, 1088, 1},
 		{"1x1 conv  2176x1024x1024", 2176, 1024, 1024, 1, 1088, 0},
 		{"proj+res  2176x1024x1024", 2176, 1024, 1024, 1, 1088, 1},
 		{"conv3+res 2176x1024x3x1024", 2176, 1024, 1024, 3, 1088, 1},

@@ -8,10 +8,12 @@
 //
 // Tiling: 256 threads = 4 waves (2x2), BMxBN block tile, 128-byte-row LDS tiles (64 bf16 / 32 f32 of K) with XOR-swizzled
 // 16-byte chunks, 16x16 MFMA sub-tiles, f32 accumulate.  Operand staging is direct-to-LDS (`global_load_lds_dwordx4`, one
-// 1-KiB piece = 8 tile rows per wave instruction) into a 3-stage ring: tile k+2 is requested while tile k is multiplied, a
-// counted `s_waitcnt vmcnt(N)` leaves one tile in flight across the single raw `s_barrier` of each k-step
+// 1-KiB piece = 8 tile rows per wave instruction) into a 3-stage ring: tile k+3 is requested and tile k+1's fragments are read
+// while tile k is multiplied (register ping-pong), a counted `s_waitcnt vmcnt(N)` leaves one tile in flight across the single
+// raw `s_barrier` of each k-step
 // (cdna_hip_programming.md section 5 "Pipelining across barriers").  The swizzle lives on the per-lane SOURCE address (LDS
-// destination of a glds is lane-linear); rows outside M or outside a conv tap's batch element read a zero page instead.
+// destination of a glds is lane-linear); rows outside M or outside a conv tap's batch element use an out-of-range buffer offset
+// (the buffer hardware returns zeros).
 // Roofline: MFMA-bound for the diffusion shapes (M = b*T ~ 2k rows, N,K in 1k..3k); bytes/flop is tiny.
 #include <stdlib.h>
 
@@ -20,16 +22,15 @@
 
 namespace ttk {
 
-__device__ uint4 g_zero_page[16];   // 256 B of zeros: source of out-of-range tile rows
-
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024).
+// One LDS-DMA piece: 64 lanes x 16 B from buffer offsets (per-lane voff + scalar soff) to LDS bytes [lds_dst, lds_dst + 1024).
 // Issued from inline asm on purpose: hipcc's waitcnt pass would otherwise put `s_waitcnt vmcnt(0)` in front of the first ds_read
 // of every k-step (it cannot prove that the ring stage being read is not the one being filled) and serialise the ring; hidden
 // from it, the only vmcnt waits in the k-loop are the counted ones below (cdna_hip_programming.md section 5.7, items 1-2).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+// M0 carries the LDS base; it is compiler-reserved, so it is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(unsigned voff, __amdgpu_buffer_rsrc_t srd, unsigned soff, unsigned lds_dst /* wave-uniform */) {
 	unsigned keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-				 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+				 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
 	return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
@@ -71,6 +72,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 #pragma unroll
 				for (int r = 0; r < 4; ++r) acc[i][j][r] = silu_f(acc[i][j][r]);
 	}
+	// residual loads all issued before the first store: the residual aliases C, so interleaving them serialises load -> store pairs
 	float res[MI][4][NI];
 	if (MODE == 1 && p.residual) {
 #pragma unroll
@@ -173,7 +175,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	const int KT = p.K / BKE;
 	const int NTILES = p.nseg * KT;
 
-	// this lane's row / chunk inside a piece, and the (fixed) rows it stages
+	// Staging addresses.  Both operands go through buffer descriptors: the per-lane byte offset inside the matrix (row, swizzled
+	// chunk) is fixed for a whole segment, the k advance is the instruction's SCALAR offset, and a lane whose row is outside M or
+	// outside its conv tap's batch element gets an out-of-range offset, for which the buffer hardware returns zeros -- so a k-tile
+	// costs one s_add per operand instead of 64-bit pointer arithmetic per piece (the first version spent ~600 issue cycles per
+	// k-tile on that, next to 256 cycles of MFMA).
 	const int prow = lane >> 3, pslot = lane & 7;
 	int a_gm[A_PC], a_t[A_PC];
 #pragma unroll
@@ -181,42 +187,52 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 		a_gm[i] = m0 + 8 * (wave + NW * i) + prow;
 		a_t[i] = p.rows_per_batch > 0 ? a_gm[i] % p.rows_per_batch : 0;
 	}
-	const char* zero = (const char*)g_zero_page;
 	const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-
-	// per-piece source cursors of the current segment: advance 128 B per k-tile (0 for zero-page rows)
-	const char* a_src[A_PC]; int a_inc[A_PC];
-	const char* b_src[B_PC];
+	constexpr unsigned OOR = 0x80000000u;   // beyond any descriptor's num_records (buffers are < 2 GiB)
+	unsigned va[A_PC], vb[B_PC];
+#pragma unroll
+	for (int i = 0; i < B_PC; ++i) {
+		const int row = 8 * (wave + NW * i) + prow;
+		const int c = pslot ^ (row & 7);                   // logical chunk landing in this lane's slot
+		vb[i] = (unsigned)(((int64_t)(n0 + row) * p.ldw + c * EPC) * ES);
+	}
+	const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+	__amdgpu_buffer_rsrc_t srdA = srdB;
+	unsigned b_seg_off = 0;
 	int seg_i = 0, kk_i = 0;
 	auto set_segment = [&](int sg) {
-		const T* Ab = (const T*)p.seg[sg].A;
 		const int64_t lda = p.seg[sg].lda;
 		const int shift = p.seg[sg].shift;
-		const T* Wb = (const T*)p.W + p.seg[sg].w_off;
+		srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[sg].A, 0, (unsigned)((int64_t)p.M * lda * ES), 0x00020000);
+		b_seg_off = (unsigned)(p.seg[sg].w_off * ES);
 #pragma unroll
 		for (int i = 0; i < A_PC; ++i) {
-			const int row = 8 * (wave + NW * i) + prow;        // row inside the tile
-			const int c = pslot ^ (row & 7);                   // logical chunk landing in this lane's slot
-			const int t = a_t[i] + shift;
-			const bool ok = a_gm[i] < p.M && (shift == 0 || (t >= 0 && t < p.rows_per_batch));
-			a_src[i] = ok ? (const char*)(Ab + (int64_t)(a_gm[i] + shift) * lda + c * EPC) : zero;
-			a_inc[i] = ok ? 128 : 0;
-		}
-#pragma unroll
-		for (int i = 0; i < B_PC; ++i) {
 			const int row = 8 * (wave + NW * i) + prow;
 			const int c = pslot ^ (row & 7);
-			b_src[i] = (const char*)(Wb + (int64_t)(n0 + row) * p.ldw + c * EPC);
+			const int t = a_t[i] + shift;
+			const bool ok = a_gm[i] < p.M && (shift == 0 || (t >= 0 && t < p.rows_per_batch));
+			va[i] = ok ? (unsigned)(((int64_t)(a_gm[i] + shift) * lda + c * EPC) * ES) : OOR;
 		}
 	};
 	auto issue = [&](int stage) {   // requests the next tile in (segment, k) order
 		if (kk_i == 0) set_segment(seg_i);
 		const unsigned As = smem_base + stage * STAGE;
 		const unsigned Bs = As + BM * 128;
+		const unsigned soffA = (unsigned)kk_i * 128u, soffB = b_seg_off + (unsigned)kk_i * 128u;
 #pragma unroll
-		for (int i = 0; i < A_PC; ++i) { glds16(a_src[i], As + (wave + NW * i) * 1024); a_src[i] += a_inc[i]; }
+		for (int i = 0; i < A_PC; ++i) {
+#ifdef TTK_DIAG_SKIP
+			if ((TTK_DIAG_SKIP & 1) && (seg_i > 0 || kk_i > 1)) continue;   // diagnostic: stale A tiles
+#endif
+			glds16(va[i], srdA, soffA, As + (wave + NW * i) * 1024);
+		}
 #pragma unroll
-		for (int i = 0; i < B_PC; ++i) { glds16(b_src[i], Bs + (wave + NW * i) * 1024); b_src[i] += 128; }
+		for (int i = 0; i < B_PC; ++i) {
+#ifdef TTK_DIAG_SKIP
+			if ((TTK_DIAG_SKIP & 2) && (seg_i > 0 || kk_i > 1)) continue;   // diagnostic: stale B tiles
+#endif
+			glds16(vb[i], srdB, soffB, Bs + (wave + NW * i) * 1024);
+		}
 		if (++kk_i == KT) { kk_i = 0; ++seg_i; }
 	};
 
@@ -226,44 +242,72 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 #pragma unroll
 		for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-	auto compute = [&](int stage) {
+	// Fragment registers of one k-tile (all k-steps), two sets used ping-pong: the ds_reads of tile k+1 are in flight under the
+	// MFMAs of tile k (with one wave per SIMD nothing else hides the ~130-cycle LDS latency; measured 735 cycles per k-tile for
+	// 256 cycles of MFMA before this).  Named structs + a 2x unrolled loop: an indexed array of register sets would go to scratch.
+	struct Frags { uint4 a[KSTEPS][MI][FCH]; uint4 b[KSTEPS][NI][FCH]; };
+	auto read_frags = [&](Frags& fr, int stage) {
 		const char* As = smem + stage * STAGE;
 		const char* Bs = As + BM * 128;
 #pragma unroll
 		for (int ks = 0; ks < KSTEPS; ++ks) {
-			union { FragT v; uint4 q[FCH]; } a[MI], b[NI];
 			const int c0 = (ks * 32 + 8 * (lane >> 4)) / EPC;
 #pragma unroll
 			for (int i = 0; i < MI; ++i) {
 				const int row = wm * WM + 16 * i + (lane & 15);
 #pragma unroll
-				for (int f = 0; f < FCH; ++f) a[i].q[f] = *(const uint4*)(As + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
+				for (int f = 0; f < FCH; ++f) fr.a[ks][i][f] = *(const uint4*)(As + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
 			}
 #pragma unroll
 			for (int j = 0; j < NI; ++j) {
 				const int row = wn * WN + 16 * j + (lane & 15);
 #pragma unroll
-				for (int f = 0; f < FCH; ++f) b[j].q[f] = *(const uint4*)(Bs + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
+				for (int f = 0; f < FCH; ++f) fr.b[ks][j][f] = *(const uint4*)(Bs + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
 			}
+		}
+	};
+	auto mfma_tile = [&](const Frags& fr) {
+#pragma unroll
+		for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
 			for (int i = 0; i < MI; ++i)
 #pragma unroll
-				for (int j = 0; j < NI; ++j) acc[i][j] = mma16<T>(a[i].v, b[j].v, acc[i][j]);
-		}
+				for (int j = 0; j < NI; ++j) {
+					union { FragT v; uint4 q[FCH]; } ua, ub;
+#pragma unroll
+					for (int f = 0; f < FCH; ++f) { ua.q[f] = fr.a[ks][i][f]; ub.q[f] = fr.b[ks][j][f]; }
+					acc[i][j] = mma16<T>(ua.v, ub.v, acc[i][j]);
+				}
+	};
+	// One pipeline step for tile kt whose fragments are already in `cur`:
+	//   wait until tile kt+1 has landed for this wave (tile kt+2 may stay in flight) and this wave's reads of tile kt are done;
+	//   barrier: now tile kt+1 has landed for every wave and stage kt%3 is free everywhere;
+	//   request tile kt+3 into stage kt%3, start reading tile kt+1's fragments, multiply tile kt.
+	auto step = [&](int kt, const Frags& cur, Frags& nxt) {
+		if (kt + 1 < NTILES) { if (kt + 2 < NTILES) wait_vmcnt<PER_TILE>(); else wait_vmcnt<0>(); }
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_s_barrier();
+		asm volatile("" ::: "memory");
+		if (kt + 3 < NTILES) issue(kt % 3);
+#ifdef TTK_DIAG_SKIP
+		if ((TTK_DIAG_SKIP & 4) && kt > 0) { mfma_tile(cur); return; }   // diagnostic: no LDS fragment reads (stale registers)
+		if ((TTK_DIAG_SKIP & 8) && kt > 0) { if (kt + 1 < NTILES) read_frags(nxt, (kt + 1) % 3); return; }   // diagnostic: no MFMAs
+#endif
+		if (kt + 1 < NTILES) read_frags(nxt, (kt + 1) % 3);
+		mfma_tile(cur);
 	};
 
 	issue(0);
 	if (NTILES > 1) issue(1);
-	int stage = 0;
-	for (int kt = 0; kt < NTILES; ++kt) {
-		// tile kt has landed for this wave (the younger tile kt+1 may stay in flight) ...
-		if (kt + 1 < NTILES) wait_vmcnt<PER_TILE>(); else wait_vmcnt<0>();
-		// ... and, after the barrier, for every wave; every wave has also finished reading stage (kt-1)%3 = (kt+2)%3
-		__builtin_amdgcn_s_barrier();
-		asm volatile("" ::: "memory");
-		if (kt + 2 < NTILES) issue(stage == 0 ? 2 : stage - 1);
-		compute(stage);
-		stage = stage == 2 ? 0 : stage + 1;
+	if (NTILES > 2) issue(2);
+	if (NTILES > 2) wait_vmcnt<2 * PER_TILE>(); else if (NTILES > 1) wait_vmcnt<PER_TILE>(); else wait_vmcnt<0>();
+	__builtin_amdgcn_s_barrier();
+	asm volatile("" ::: "memory");
+	Frags f0, f1;
+	read_frags(f0, 0);
+	for (int kt = 0; kt < NTILES; kt += 2) {
+		step(kt, f0, f1);
+		if (kt + 1 < NTILES) step(kt + 1, f1, f0);
 	}
 
 	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
