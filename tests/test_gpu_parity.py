@@ -211,3 +211,58 @@ def test_multinomial1_is_torch_multinomial_on_device():
 		b = [multinomial1(p) for _ in range(5)]
 		after_b = torch.rand(4, device=DEV)
 		assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(after_a, after_b)
+
+
+def test_fused_sample_step_is_the_reference_sampling_chain():
+	"""ttk_sample_step == HF `_sample`'s per-token chain run as torch ops on the device (temperature warper, softmax,
+	torch.multinomial, finished-row padding, id append, unfinished update), including the generator stream it consumes."""
+	from tortoise_tts_amd import _lib
+	lib = _lib.load()
+	stop = 8193
+	for B, V, temp, seed, sup in ((16, 8194, 0.8, 0, (8193,)), (3, 8194, 1.0, 5, ()), (5, 1000, 0.2, 9, (1, 7, 500)), (64, 8194, 1.3, 2, ())):
+		mask = None
+		if sup:
+			mask = torch.zeros(V, dtype=torch.bool, device=DEV)
+			mask[list(sup)] = True
+		g = torch.Generator().manual_seed(seed)
+		steps = 6
+		logits = [(torch.randn((B, V), generator=g) * 4).to(DEV) for _ in range(steps)]
+		for lg in logits:                      # make the stop token likely enough that rows finish inside the test
+			lg[:, stop if stop < V else V - 1] += 6.0
+		stop_id = stop if stop < V else V - 1
+		# reference chain (torch ops)
+		torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
+		unf = torch.ones(B, dtype=torch.long, device=DEV)
+		ref_ids = []
+		for lg in logits:
+			lg = lg if mask is None else torch.where(mask, -float("inf"), lg)
+			probs = torch.softmax(lg / temp if temp != 1.0 else lg, dim=-1)
+			nxt = torch.multinomial(probs, num_samples=1).squeeze(1)
+			nxt = nxt * unf + stop_id * (1 - unf)
+			unf = unf.mul((nxt != stop_id).long())
+			ref_ids.append(nxt)
+		ref_ids = torch.stack(ref_ids, 1)
+		after_ref = torch.rand(4, device=DEV)
+		# fused kernel
+		torch.manual_seed(seed); torch.cuda.manual_seed_all(seed)
+		unf2 = torch.ones(B, dtype=torch.long, device=DEV)
+		tok = torch.empty(B, dtype=torch.long, device=DEV)
+		ids = torch.full((B, steps - 1), -1, dtype=torch.long, device=DEV)       # one column short: the last write must be skipped
+		col = torch.zeros(B, dtype=torch.long, device=DEV)
+		hist = torch.full((B, 3 + steps), -7, dtype=torch.long, device=DEV)
+		q = torch.empty((B, V), device=DEV)
+		toks = []
+		for lg in logits:
+			q.exponential_(1)
+			_lib.check(lib.ttk_sample_step(lg.data_ptr(), lg.stride(0), B, V, q.data_ptr(), q.stride(0), _lib.ptr(mask), temp, stop_id, unf2.data_ptr(),
+										   tok.data_ptr(), ids.data_ptr(), ids.stride(0), ids.shape[1], col.data_ptr(), hist.data_ptr(),
+										   hist.stride(0), 3, _lib.stream_ptr()), "ttk_sample_step")
+			toks.append(tok.clone())
+		after = torch.rand(4, device=DEV)
+		toks = torch.stack(toks, 1)
+		assert torch.equal(toks, ref_ids), (B, V, temp)
+		assert torch.equal(ids, ref_ids[:, :steps - 1]) and torch.equal(hist[:, 3:], ref_ids) and bool((hist[:, :3] == -7).all())
+		assert torch.equal(unf2, unf) and bool((col == steps).all()) and torch.equal(after, after_ref)
+	# argument checking: a null pointer / bad temperature is an error code with a message, not a crash
+	assert lib.ttk_sample_step(None, 0, 1, 1, None, 0, None, 1.0, 0, None, None, None, 0, 0, None, None, 0, 0, None) != 0
+	assert b"ttk_sample_step" in lib.ttk_last_error()

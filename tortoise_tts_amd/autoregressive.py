@@ -251,8 +251,14 @@ class _GenState:
 		self.ids = torch.empty((B, max_new), dtype=torch.long, device=dev)
 		self.tok = torch.empty(B, dtype=torch.long, device=dev)
 		self.unfinished = torch.ones(B, dtype=torch.long, device=dev)
-		self.col = torch.zeros(1, dtype=torch.long, device=dev)
+		self.col = torch.zeros(B, dtype=torch.long, device=dev)         # per-row output column (all rows move together)
+		self.q = torch.empty((B, c.number_mel_codes), device=dev, dtype=torch.float32)   # Exp(1) noise of multinomial
 		self.history = torch.ones((B, trunc_index + max_new), dtype=torch.long, device=dev) if self.pipe.needs_history else None
+		# suppress_tokens and temperature are folded into the fused kernel (the common case); any other warper runs as torch ops
+		# first and the kernel then sees finished scores
+		p = self.pipe
+		self.fused_temperature = p.temperature or 1.0
+		self.fused = p.top_k is None and p.top_p is None and p.repetition_penalty is None and p.typical_mass is None
 		self.graph = None
 
 	def reset(self, c):
@@ -265,14 +271,18 @@ class _GenState:
 
 	def sample(self, n):
 		"""one token from self.logits: warp, sample, pad finished rows, record      (HF:generation/utils.py:2894-2937)"""
-		hist = None if self.history is None else self.history[:, :self.trunc_index + n]
-		scores = self.pipe(hist, self.logits)
-		probs = torch.nn.functional.softmax(scores, dim=-1)
-		nxt = multinomial1(probs)
-		nxt = nxt * self.unfinished + self.stop * (1 - self.unfinished)
-		self.tok.copy_(nxt)
-		self.ids.index_copy_(1, self.col, nxt[:, None])
-		self.col.add_(1)
-		self.unfinished.mul_((nxt != self.stop).long())
-		if self.history is not None:
-			self.history[:, self.trunc_index + n] = nxt
+		if self.fused:
+			scores, temperature, suppress = self.logits, self.fused_temperature, self.pipe.suppress_mask
+		else:
+			hist = None if self.history is None else self.history[:, :self.trunc_index + n]
+			scores, temperature, suppress = self.pipe(hist, self.logits), 1.0, None
+			if not scores.is_contiguous():
+				scores = scores.contiguous()
+		# multinomial(softmax(scores), 1) == argmax(softmax(scores) / q), q ~ Exp(1) from the torch generator (see sampling.multinomial1)
+		self.q.exponential_(1)
+		V = scores.shape[1]
+		_lib.check(_lib.load().ttk_sample_step(scores.data_ptr(), scores.stride(0), self.B, V, self.q.data_ptr(), self.q.stride(0),
+											   _lib.ptr(suppress), float(temperature), self.stop, self.unfinished.data_ptr(), self.tok.data_ptr(),
+											   self.ids.data_ptr(), self.ids.stride(0), self.ids.shape[1], self.col.data_ptr(),
+											   _lib.ptr(self.history), 0 if self.history is None else self.history.stride(0),
+											   self.trunc_index, _lib.stream_ptr()), "ttk_sample_step")
