@@ -124,6 +124,42 @@ def schedule_case(d_mod):
 	return out
 
 
+def lora_case(uv_mod, cfg, seed, rank, alpha):
+	"""The reference's own LoRA attachment (models/lora.py apply_lora with the default parametrised pathway and the `gpt` policy,
+	config.py:297-313) on a synthetic UnifiedVoice: the adapter tensors, the state_dict key names they get, the effective weights the
+	reference's forward then uses, and prefill logits through the adapted model."""
+	import importlib
+	lora_mod = importlib.import_module("tortoise_tts.models.lora")
+	sd = W.synth_state_dict(W.ar_shapes(cfg), seed)
+	m = uv_mod.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, checkpointing=False)
+	load_into(m, sd)
+	m = lora_mod.apply_lora(m, rank=rank, alpha=alpha, policy=dict(include=["gpt"], exclude=[]), use_parametrize=True)
+	m.eval()
+	g = gen(seed + 7)
+	out = dict(seed=np.int64(seed), rank=np.int64(rank), alpha=np.int64(alpha))
+	with torch.no_grad():
+		for name, p in m.named_parameters():
+			if "lora_" in name:
+				p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+	full = m.state_dict()
+	lora, rest = lora_mod.lora_get_state_dict(full, split=True)
+	out["lora_keys"] = np.array(sorted(lora.keys()))
+	out["base_keys"] = np.array(sorted(k for k in rest.keys() if "parametrizations" in k))
+	for k, v in lora.items():
+		out["lora::" + k] = v.detach().numpy()
+	for name, mod in m.named_modules():
+		if hasattr(mod, "parametrizations"):
+			out["eff::" + name + ".weight"] = mod.weight.detach().numpy().copy()
+	Tt, B = 9, 2
+	text = torch.randint(1, 255, (1, Tt), generator=gen(seed + 1))
+	cond = torch.randn(1, cfg.model_dim, generator=gen(seed + 2))
+	with torch.inference_mode():
+		ids = m.compute_embeddings(cond, text).repeat(B, 1)
+		r = m.inference_model.forward(input_ids=ids, attention_mask=torch.ones(B, ids.shape[1], dtype=torch.long), use_cache=True, return_dict=True)
+	out.update(text=text.numpy(), cond=cond.numpy(), B=np.int64(B), prefill_logits=r.logits[:, -1].float().numpy())
+	return out
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -134,6 +170,7 @@ def main():
 		("diff_small", lambda: diff_case(d_mod, W.DIFF_SMALL, 21, b=2, M=10, full=False)),
 		("ar_full", lambda: ar_case(uv_mod, W.AR_FULL, 12, B=1, Tt=8, n_dec=2, M=6, full=True)),
 		("diff_full", lambda: diff_case(d_mod, W.DIFF_FULL, 22, b=1, M=6, full=True)),
+		("lora_small", lambda: lora_case(uv_mod, W.AR_SMALL, 13, rank=4, alpha=8)),
 	]
 	only = set(sys.argv[1:])
 	for name, fn in jobs:

@@ -3,7 +3,8 @@ mel-token decode and the DiffusionTTS DDIM mel decoder -- as hand-written HIP ke
 exposed under the reference's own method names.  See DESIGN.md and INTEGRATION.md."""
 from .weights import ARConfig, DiffusionConfig  # noqa: F401
 
-__all__ = ["ARConfig", "DiffusionConfig", "UnifiedVoice", "DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel"]
+__all__ = ["ARConfig", "DiffusionConfig", "UnifiedVoice", "DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel",
+		   "load_autoregressive", "load_diffusion"]
 
 
 def __getattr__(name):   # lazy: importing the package must not need the built library (CPU-side tools, oracle, weights)
@@ -13,4 +14,7 @@ def __getattr__(name):   # lazy: importing the package must not need the built l
 	if name in ("DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel", "SpacedDiffusion"):
 		from . import diffusion
 		return getattr(diffusion, name)
+	if name in ("load_autoregressive", "load_diffusion"):
+		from . import checkpoint
+		return getattr(checkpoint, name)
 	raise AttributeError(name)
