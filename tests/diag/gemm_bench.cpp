@@ -17,6 +17,8 @@ int main(int argc, char** argv) {
 	struct Shape { const char* name; int M, N, K, nseg, T, resid; } shapes[] = {
 		{"fixed-cost probe K=128 bf16 out", 2176, 1024, 128, 1, 1088, 0},
 		{"fixed-cost probe K=128 f32+res", 2176, 1024, 128, 1, 1088, 1},
+		{"tail probe 2048x1024x1024 (256 tiles)", 2048, 1024, 1024, 1, 1024, 0},
+		{"tail probe 4096x1024x1024 (512 tiles)", 4096, 1024, 1024, 1, 1024, 0},
 		{"1x1 conv  2176x1024x1024", 2176, 1024, 1024, 1, 1088, 0},
 		{"proj+res  2176x1024x1024", 2176, 1024, 1024, 1, 1088, 1},
 		{"conv3+res 2176x1024x3x1024", 2176, 1024, 1024, 3, 1088, 1},

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <vector>
 #include <algorithm>
+#include <stdlib.h>
 #include "../../tortoise_tts_amd/csrc/skinny.hip"
 bool ttk::g_prof_on = false;
 void ttk::prof_start(int, double, hipStream_t) {}
@@ -11,7 +12,8 @@ void ttk::prof_stop(hipStream_t) {}
 using namespace ttk;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-int main() {
+int main(int argc, char** argv) {
+	const int narrow = argc > 1 ? atoi(argv[1]) : 1;
 	const int d = 1024, B = 16, H = 16, max_ctx = 512;
 	// two alternating "layers" so weights are not L2-resident between launches: 40 distinct weight sets (> 256 MiB total)
 	const int NSET = 48;
@@ -36,18 +38,19 @@ int main() {
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = dpos; p.max_ctx = max_ctx; p.H = H; p.q_scale = 0.125f;
 		p.stamps = which == 0 ? st : nullptr;
 		launch_skinny(DT_BF16, p, 8, s);
-		p = {}; p.Wp = sets[i].wproj; p.N = d; p.K = d; p.M = B; p.bias = bias; p.a = ao; p.lda = d; p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
+		p = {}; p.Wp = sets[i].wproj; p.N = d; p.K = d; p.M = B; p.bias = bias; p.a = ao; p.lda = d; p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.narrow = narrow;
 		p.stamps = which == 1 ? st : nullptr;
 		launch_skinny(DT_BF16, p, 8, s);
 		p = {}; p.Wp = sets[i].wfc; p.N = 4 * d; p.K = d; p.M = B; p.bias = bias; p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = g; p.b1 = b;
 		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hb; p.stamps = which == 2 ? st : nullptr;
 		launch_skinny(DT_BF16, p, 8, s);
 		p = {}; p.Wp = sets[i].wproj2; p.N = d; p.K = 4 * d; p.M = B; p.bias = bias; p.a = hb; p.lda = 4 * d; p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
-		p.stamps = which == 3 ? st : nullptr; p.ksplit = 4; p.slab = slab; p.tickets = tickets;
-		launch_skinny(DT_BF16, p, 8, s);
+		p.stamps = which == 3 ? st : nullptr; p.narrow = narrow;
+		if (!narrow) { p.ksplit = 4; p.slab = slab; p.tickets = tickets; }
+		launch_skinny(DT_BF16, p, narrow ? 16 : 8, s);
 	};
 	const char* names[4] = {"ln1+qkv (192 WG x 8 waves)", "c_proj (64 WG x 8)", "ln2+fc+gelu (256 WG x 8)", "mlp.c_proj (64x4 WG x 8)"};
-	const int grids[4] = {192, 64, 256, 256};
+	const int grids[4] = {192, narrow ? 256 : 64, 256, 256};
 	for (int which = 0; which < 4; ++which) {
 		for (int i = 0; i < NSET; ++i) run_layer(i, nullptr, -1);   // warm
 		CK(hipStreamSynchronize(s));

@@ -10,7 +10,7 @@ from typing import Dict, List, Sequence
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libttk.so")
+LIB_PATH = os.environ.get("TTK_LIB") or os.path.join(HERE, "libttk.so")   # TTK_LIB: A/B runs of an experimental build
 
 TTK_F32, TTK_BF16 = 0, 1
 DTYPES = {"f32": TTK_F32, "fp32": TTK_F32, "float32": TTK_F32, "bf16": TTK_BF16, "bfloat16": TTK_BF16}

@@ -87,6 +87,8 @@ struct ttk_ar {
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
+	int wv_proj = 8, wv_proj2 = 16;   // waves per workgroup of the two plain decode GEMVs (TTK_AR_WV_PROJ / TTK_AR_WV_PROJ2)
+	int narrow = 1;               // c_proj / mlp.c_proj decode GEMVs as 4-column workgroups without split-K (TTK_AR_NARROW=0: 16-column + split-K)
 	int nsplit = 1;               // row groups decoded concurrently (TTK_AR_SPLIT; measured slower: 283 -> 340 ms at 2, see below)
 	hipStream_t side[3] = {nullptr, nullptr, nullptr};
 	hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -174,8 +176,8 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		launch_attn_decode(dt, a, s);
 		p = {};
 		p.Wp = L.proj.wfrag; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d;
-		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
-		launch_skinny(dt, p, wv_small, s);
+		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.narrow = h->narrow;
+		launch_skinny(dt, p, d >= 1024 ? h->wv_proj : 4, s);
 		p = {};
 		p.Wp = L.fc.wfrag; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
 		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b;
@@ -184,10 +186,11 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		p = {};
 		p.Wp = L.proj2.wfrag; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
-		if (d >= 1024) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
+		p.narrow = h->narrow;
+		if (d >= 1024 && !h->narrow) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
 			p.ksplit = 4; p.slab = h->slab + (size_t)gi * (d / 16) * 4 * 4 * 256; p.tickets = h->tickets + (size_t)gi * (d / 16);
 		}
-		launch_skinny(dt, p, d >= 1024 ? 8 : 4, s);
+		launch_skinny(dt, p, d >= 1024 ? h->wv_proj2 : 4, s);
 	}
 	SkinnyParams p = {};
 	p.Wp = h->head.wfrag; p.N = c.number_mel_codes; p.K = d; p.M = nrows; p.bias = h->head.bias;
@@ -251,6 +254,13 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)4 * (d / 16) * sizeof(int)));
 	if (hipMemset(h->tickets, 0, (size_t)4 * (d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	{
+		const char* en = getenv("TTK_AR_NARROW");
+		h->narrow = en ? (atoi(en) != 0) : 1;
+		const char* e1 = getenv("TTK_AR_WV_PROJ");
+		const char* e2 = getenv("TTK_AR_WV_PROJ2");
+		if (e1 && atoi(e1) >= 4 && atoi(e1) <= 16) h->wv_proj = atoi(e1);
+		h->wv_proj2 = h->narrow ? 16 : 8;
+		if (e2 && atoi(e2) >= 4 && atoi(e2) <= 16) h->wv_proj2 = atoi(e2);
 		const char* e = getenv("TTK_AR_SPLIT");
 		h->nsplit = e ? atoi(e) : 1;
 		if (h->nsplit != 1 && h->nsplit != 2 && h->nsplit != 4) h->nsplit = 1;

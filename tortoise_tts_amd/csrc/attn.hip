@@ -12,6 +12,8 @@
 //   4 waves x 32 queries per workgroup, 64-key K/V tiles staged through LDS, f32 softmax/accumulators.
 //
 // k_attn_decode: single-query KV-cached attention for the AR decode step (HBM-bound: streams the K/V cache once).
+#include <stdlib.h>
+
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -285,12 +287,17 @@ void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ decode
-// grid (H, B), 256 threads.  Lane (slot = lane>>3, dg = lane&7) owns 8 head dims of every 8th key of its wave's
-// key range: one wave instruction reads 8 consecutive cache rows = 1 KiB (bf16).  Online softmax per slot, then
-// slots (shuffles) and waves (LDS) are merged.  Algorithmic bytes: 2 * (pos+1) * 64 * sizeof(T) per (b, h).
-template <typename T>
-__global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
+// grid (H, B), NW waves.  Lane (slot = lane>>3, dg = lane&7) owns 8 head dims of one key; a wave instruction reads 8 consecutive
+// cache rows = 1 KiB (bf16).  Key groups (8 keys) are dealt round-robin to the waves and a wave requests UN groups of K and V at
+// once, so for up to NW*UN*8 keys (384 with the values below: every position of the benchmark's 64-token prompt + 250 mel tokens)
+// the whole cache slice of this (b, h) is in flight after ONE dependent step (the position scalar), instead of one round trip
+// per 128 keys.  Online softmax per (wave, slot), partials merged through LDS in two levels.
+// Algorithmic bytes: 2 * (pos+1) * 64 * sizeof(T) per (b, h).
+template <typename T, int NW, int UN>
+__global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	typedef typename Frag<T>::type FragT;
+	constexpr int NP = NW * 8;           // (wave, slot) partial softmaxes
+	constexpr int L1 = NP / 32;          // first merge level: L1 groups of 32 partials
 	const int h = blockIdx.x, b = blockIdx.y;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int slot = lane >> 3, dg = lane & 7;
@@ -303,33 +310,29 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
 #pragma unroll
 		for (int j = 0; j < 8; ++j) q[j] = qp[j] * LOG2E;   // log2-domain scores: exp2 is a single v_exp_f32
 	}
-	// this wave's contiguous key range, in groups of 8 keys
 	const int groups = (n + 7) / 8;
-	const int g0 = (groups * wave) / 4, g1 = (groups * (wave + 1)) / 4;
 	float m = NEG_BIG, l = 0.f, acc[8];
 #pragma unroll
 	for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-	constexpr int UN = 4;
-	for (int gb = g0; gb < g1; gb += UN) {
+	for (int gb = wave; gb < groups; gb += NW * UN) {
 		FragT kf[UN], vf[UN];
 #pragma unroll
-		for (int u = 0; u < UN; ++u) {
-			int key = (gb + u) * 8 + slot;
+		for (int u = 0; u < UN; ++u) {     // unconditional, clamped: all 2*UN requests leave before the first use
+			int key = (gb + u * NW) * 8 + slot;
 			key = key < n ? key : n - 1;
 			kf[u] = *(const FragT*)(Kc + (int64_t)key * HD + 8 * dg);
 			vf[u] = *(const FragT*)(Vc + (int64_t)key * HD + 8 * dg);
 		}
 #pragma unroll
 		for (int u = 0; u < UN; ++u) {
-			const int key = (gb + u) * 8 + slot;
+			const int key = (gb + u * NW) * 8 + slot;
 			float sdot = 0.f;
 #pragma unroll
 			for (int j = 0; j < 8; ++j) sdot += q[j] * (float)kf[u][j];
 			sdot = dpp_add<0xB1>(sdot);    // the 8 lanes of a key: quad swaps + row_half_mirror, all DPP
 			sdot = dpp_add<0x4E>(sdot);
 			sdot = dpp_add<0x141>(sdot);
-			const bool valid = (gb + u) < g1 && key < n;
-			if (valid) {
+			if (key < n) {
 				const float m_new = fmaxf(m, sdot);
 				const float alpha = __builtin_amdgcn_exp2f(m - m_new), pv = __builtin_amdgcn_exp2f(sdot - m_new);
 				l = l * alpha + pv;
@@ -339,30 +342,59 @@ __global__ __launch_bounds__(256) void k_attn_decode(AttnDecodeParams p) {
 			}
 		}
 	}
-	// merge the 32 (wave, key-slot) partial softmaxes through LDS: one barrier and a 32-term loop per output element instead
-	// of ~30 dependent cross-lane permutes
-	__shared__ float sm[32], sl[32], sacc[32][HD + 1];
+	// merge the NP partial softmaxes through LDS: L1 groups of 32 in parallel, then the L1 results
+	__shared__ float sm[NP], sl[NP], sacc[NP][HD + 1];
+	__shared__ float sm2[L1], sl2[L1], so2[L1][HD];
 	const int ps = wave * 8 + slot;
 	if (dg == 0) { sm[ps] = m; sl[ps] = l; }
 #pragma unroll
 	for (int j = 0; j < 8; ++j) sacc[ps][8 * dg + j] = acc[j];
 	__syncthreads();
-	if (tid < HD) {
+	if (tid < HD * L1) {
+		const int part = tid >> 6, e = tid & 63;
 		float mn = NEG_BIG;
 #pragma unroll
-		for (int i = 0; i < 32; ++i) mn = fmaxf(mn, sm[i]);
+		for (int i = 0; i < 32; ++i) mn = fmaxf(mn, sm[part * 32 + i]);
 		float lt = 0.f, ot = 0.f;
 #pragma unroll
-		for (int i = 0; i < 32; ++i) { const float a = __builtin_amdgcn_exp2f(sm[i] - mn); lt += sl[i] * a; ot += sacc[i][tid] * a; }
-		((T*)p.out)[((int64_t)b * p.H + h) * HD + tid] = cvt<T>(ot / lt);
+		for (int i = 0; i < 32; ++i) { const float a = __builtin_amdgcn_exp2f(sm[part * 32 + i] - mn); lt += sl[part * 32 + i] * a; ot += sacc[part * 32 + i][e] * a; }
+		if (L1 == 1) {
+			((T*)p.out)[((int64_t)b * p.H + h) * HD + e] = cvt<T>(ot / lt);
+		} else {
+			if (e == 0) { sm2[part] = mn; sl2[part] = lt; }
+			so2[part][e] = ot;
+		}
+	}
+	if (L1 > 1) {
+		__syncthreads();
+		if (tid < HD) {
+			float mn = NEG_BIG;
+#pragma unroll
+			for (int i = 0; i < L1; ++i) mn = fmaxf(mn, sm2[i]);
+			float lt = 0.f, ot = 0.f;
+#pragma unroll
+			for (int i = 0; i < L1; ++i) { const float a = __builtin_amdgcn_exp2f(sm2[i] - mn); lt += sl2[i] * a; ot += so2[i][tid] * a; }
+			((T*)p.out)[((int64_t)b * p.H + h) * HD + tid] = cvt<T>(ot / lt);
+		}
 	}
 }
 
+template <typename T, int NW, int UN>
+static void launch_attn_decode_t(const AttnDecodeParams& p, hipStream_t s) {
+	hipLaunchKernelGGL((k_attn_decode<T, NW, UN>), dim3(p.H, p.B), dim3(64 * NW), 0, s, p);
+}
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {
 	ProfScope prof(PROF_ATTN_DECODE, 2.0 * p.B * p.H * (double)p.ctx_hint * HD * dtype_size(dt), s);
-	dim3 grid(p.H, p.B);
-	if (dt == DT_BF16) hipLaunchKernelGGL((k_attn_decode<bf16>), grid, dim3(256), 0, s, p);
-	else hipLaunchKernelGGL((k_attn_decode<float>), grid, dim3(256), 0, s, p);
+	static const int variant = [] { const char* e = getenv("TTK_ATTN_DECODE"); return e ? atoi(e) : 0; }();   // tuning knob: 0 = default
+	if (dt == DT_BF16) {
+		// 250-token AR loop, B=16, one box: 4 waves x 4 groups (first version, 128 keys per round trip) 261.9 ms; 8 x 6 257.5 ms;
+		// 16 x 3 256.8 ms
+		if (variant == 1) launch_attn_decode_t<bf16, 4, 4>(p, s);
+		else if (variant == 2) launch_attn_decode_t<bf16, 8, 6>(p, s);
+		else launch_attn_decode_t<bf16, 16, 3>(p, s);
+	} else {
+		launch_attn_decode_t<float, 8, 6>(p, s);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------ prefill KV -> cache

@@ -46,7 +46,20 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	constexpr int ES = sizeof(T);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-	const int nt = blockIdx.x / p.ksplit, kslice = blockIdx.x - nt * p.ksplit;   // ksplit workgroups share one n-tile
+	// Plain mode: ksplit workgroups share one 16-column n-tile.  Narrow mode (p.narrow): FOUR workgroups share an n-tile, each owning 4
+	// of its columns over the whole of K -- 4x the workgroups streaming the matrix without any split-K combine.  The MFMA still runs
+	// 16 columns wide: lane (g, n) fetches the fragment of column 4*sub + (n & 3), so columns 4..15 of the product are copies that the
+	// epilogue ignores (matrix throughput is irrelevant here, the weight stream is the work).  The four workgroups of a tile read the
+	// same 128-byte lines, so they are given ids that are equal mod 8: round-robin dispatch then puts them on one XCD and its L2
+	// fetches every line once.
+	int nt, kslice = 0, sub = 0;
+	if (p.narrow) {
+		const int b = blockIdx.x, ntiles = (p.N + 15) / 16;
+		if ((ntiles & 7) == 0) { nt = (b >> 5) * 8 + (b & 7); sub = (b >> 3) & 3; }
+		else { nt = b >> 2; sub = b & 3; }
+	} else {
+		nt = blockIdx.x / p.ksplit; kslice = blockIdx.x - nt * p.ksplit;
+	}
 	const int KS = p.K / 32;
 	const int RS = p.K * ES + 16;                       // padded LDS row stride (bytes), LN mode only
 	char* a_lds = smem;
@@ -146,15 +159,38 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		}
 	};
 	TTK_STAMP(0);
+	// Epilogue role of the first 256 threads: element (row 4*(l2>>4)+r of each m-tile, column l2&15) of the 16-wide output tile.  Its
+	// bias and, for the residual modes, the current value of the output are requested now, ahead of everything else, so the epilogue
+	// finds them in registers instead of paying one more dependent L2 round trip after the reduction.
+	const int l2 = tid & 63, r = tid >> 6;
+	const int n = p.narrow ? nt * 16 + 4 * sub + (l2 & 3) : nt * 16 + (l2 & 15);
+	const bool mine = tid < 256 && (!p.narrow || (l2 & 15) < 4) && n < p.N;
+	float bias = 0.f, res[MT];
+	{
+		const int nn = n < p.N ? n : p.N - 1;
+		if (p.bias) bias = p.bias[nn];
+#pragma unroll
+		for (int mt = 0; mt < MT; ++mt) {
+			res[mt] = 0.f;
+			if (p.mode == SK_RESIDUAL) {
+				int m = mt * 16 + 4 * (l2 >> 4) + (r & 3);
+				m = m < p.M ? m : p.M - 1;
+				res[mt] = p.out_f32[(int64_t)m * p.ldc + nn];
+			}
+		}
+	}
 	if (LN) { ln_load(wave); ln_load_affine(); }
 
 	// ---- this wave's K slice of the weights; the first PRE fragments are requested now
 	const int kw0 = (KS * kslice) / p.ksplit, kw1 = (KS * (kslice + 1)) / p.ksplit;   // this workgroup's k-steps
 	const int ks0 = kw0 + ((kw1 - kw0) * wave) / nw, ks1 = kw0 + ((kw1 - kw0) * (wave + 1)) / nw;
-	const FragT* wp = (const FragT*)p.Wp + ((int64_t)nt * KS) * 64 + lane;
+	const FragT* wp = (const FragT*)p.Wp + ((int64_t)nt * KS) * 64 + (p.narrow ? ((lane & ~15) | (4 * sub + (lane & 3))) : lane);
 	constexpr int PRE = 8;   // 8 x 1 KiB (bf16) in flight per wave
 	FragT bpre[PRE];
 	const int npre = min(ks1 - ks0, PRE);
+	// (Requesting the plain-mode A fragments of this batch up front as well, before or after the weights, measured 5-7 ms per
+	// utterance SLOWER than letting them be fetched next to their MFMA.)
+	const int arow = lane & 15, ag = lane >> 4;
 #pragma unroll
 	for (int u = 0; u < PRE; ++u)   // unconditional: slots beyond npre re-read the last fragment (never multiplied)
 		bpre[u] = TTK_WLOAD(wp + (int64_t)(ks0 + (u < npre ? u : npre - 1)) * 64);
@@ -170,7 +206,6 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	f32x4 acc[MT];
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-	const int arow = lane & 15, ag = lane >> 4;
 	auto load_a = [&](int mt, int ks) -> FragT {
 		if (LN) {
 			union { FragT v; uint4 q[ES / 2]; } u;
@@ -213,8 +248,6 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	for (int mt = 0; mt < MT; ++mt) *(f32x4*)(red + ((wave * MT + mt) * 64 + lane) * 4) = acc[mt];
 	__syncthreads();
 	TTK_STAMP(4);
-	const int l2 = tid & 63, r = tid >> 6;
-	const int n = nt * 16 + (l2 & 15);
 	float vsum[MT];
 	if (tid < 256) {
 #pragma unroll
@@ -255,9 +288,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			}
 		}
 	}
-	if (tid >= 256) return;
-	if (n >= p.N) return;
-	const float bias = p.bias ? p.bias[n] : 0.f;
+	if (!mine) return;
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) {
 		const int m = mt * 16 + 4 * (l2 >> 4) + r;
@@ -266,7 +297,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		if (p.mode == SK_STORE_F32) {
 			p.out_f32[(int64_t)m * p.ldc + n] = v;
 		} else if (p.mode == SK_RESIDUAL) {
-			p.out_f32[(int64_t)m * p.ldc + n] += v;
+			p.out_f32[(int64_t)m * p.ldc + n] = res[mt] + v;
 		} else if (p.mode == SK_ACT_T) {
 			((T*)p.out_T)[(int64_t)m * p.N + n] = cvt<T>(apply_act(v, p.act));
 		} else {   // SK_QKV
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 
 template <typename T, int MT>
 static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
-	const int grid = ((p.N + 15) / 16) * p.ksplit;
+	const int grid = p.narrow ? ((p.N + 15) / 16) * 4 : ((p.N + 15) / 16) * p.ksplit;
 	const size_t red = (size_t)waves * MT * 64 * 4 * sizeof(float);
 	if (p.ln_count > 0) {
 		if (waves > 8) waves = 8;
@@ -314,6 +345,8 @@ static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s) {
 void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
 	SkinnyParams p = p_in;
 	if (p.ksplit < 1 || !p.slab || !p.tickets) p.ksplit = 1;
+	if (p.ln_count > 0 || p.mode == SK_QKV) p.narrow = 0;      // every workgroup of an LN kernel normalises all rows: more of them only adds work
+	if (p.narrow) p.ksplit = 1;
 	if (waves < 4) waves = 4;
 	// algorithmic bytes: the weight matrix once + bias + the M activation rows in and out
 	ProfScope prof(PROF_SKINNY, (double)p.N * p.K * dtype_size(dt) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, s);

@@ -79,6 +79,8 @@ struct SkinnyParams {
 	float* qbuf; void* kcache; void* vcache; const int* d_pos; int max_ctx, H; float q_scale;
 	// optional split-K over workgroups: slab f32 [n_tiles][ksplit][MT][256], tickets int [n_tiles] (zero between launches)
 	int ksplit; float* slab; int* tickets;
+	// narrow mode (plain A only, excludes ksplit): N/4 workgroups of 4 columns each instead of N/16 of 16 -- for the N = d projections
+	int narrow;
 #ifdef TTK_STAMPS
 	unsigned long long* stamps;   // diagnostic build only
 #endif
