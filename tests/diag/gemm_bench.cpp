@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
+#include <stdlib.h>
 #include "../../tortoise_tts_amd/csrc/gemm.hip"
 bool ttk::g_prof_on = false;
 void ttk::prof_start(int, double, hipStream_t) {}
@@ -30,34 +31,45 @@ int main(int argc, char** argv) {
 	};
 	hipStream_t s; CK(hipStreamCreate(&s));
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	// cold = 1 (default): every launch reads a different copy of A and W out of pools larger than L2 + MALL, which is what the diffusion
+	// network does (320 MB of weights per evaluation, activations just written by another kernel); cold = 0 re-reads one copy (L2-hot).
+	const int cold = argc > 1 ? atoi(argv[1]) : 1;
+	const int only_tile = argc > 2 ? atoi(argv[2]) : -1;
 	for (auto& sh : shapes) {
 		const int Npad = (sh.N + 127) / 128 * 128;
-		void *A, *W, *Cb; float *bias, *Cf;
 		const size_t an = (size_t)sh.M * sh.K * (sh.nseg == 2 ? 2 : 1), wn = (size_t)sh.nseg * Npad * sh.K;
-		CK(hipMalloc(&A, an * 2)); CK(hipMalloc(&W, wn * 2)); CK(hipMalloc(&Cb, (size_t)sh.M * sh.N * 2)); CK(hipMalloc(&Cf, (size_t)sh.M * sh.N * 4)); CK(hipMalloc(&bias, sh.N * 4));
-		fill<<<(an + 255) / 256, 256, 0, s>>>((unsigned short*)A, an, 1); fill<<<(wn + 255) / 256, 256, 0, s>>>((unsigned short*)W, wn, 2);
+		int nset = cold ? (int)((size_t)640e6 / ((an + wn) * 2)) + 1 : 1;
+		nset = nset < 1 ? 1 : (nset > 256 ? 256 : nset);
+		char *A, *W; void* Cb; float *bias, *Cf;
+		CK(hipMalloc(&A, an * 2 * nset)); CK(hipMalloc(&W, wn * 2 * nset)); CK(hipMalloc(&Cb, (size_t)sh.M * sh.N * 2)); CK(hipMalloc(&Cf, (size_t)sh.M * sh.N * 4)); CK(hipMalloc(&bias, sh.N * 4));
+		fill<<<(unsigned)((an * nset + 255) / 256), 256, 0, s>>>((unsigned short*)A, an * nset, 1); fill<<<(unsigned)((wn * nset + 255) / 256), 256, 0, s>>>((unsigned short*)W, wn * nset, 2);
 		CK(hipMemsetAsync(bias, 0, sh.N * 4, s)); CK(hipMemsetAsync(Cf, 0, (size_t)sh.M * sh.N * 4, s));
-		GemmParams g = {};
-		g.nseg = sh.nseg;
-		for (int j = 0; j < sh.nseg; ++j) {
-			if (sh.nseg == 3) g.seg[j] = {A, sh.K, j - 1, (int64_t)j * Npad * sh.K};
-			else if (sh.nseg == 2) g.seg[j] = {(char*)A + (size_t)j * sh.M * sh.K * 2, sh.K, 0, (int64_t)j * sh.K};
-			else g.seg[j] = {A, sh.K, 0, 0};
-		}
-		g.W = W; g.ldw = sh.nseg == 2 ? 2 * sh.K : sh.K; g.M = sh.M; g.N = sh.N; g.K = sh.K; g.rows_per_batch = sh.T; g.bias = bias;
-		if (sh.resid) { g.residual = Cf; g.ldr = sh.N; g.C = Cf; g.ldc = sh.N; g.out_f32 = 1; } else { g.C = Cb; g.ldc = sh.N; }
-		for (int tile = 0; tile < 4; ++tile) {
+		auto params = [&](int set) {
+			GemmParams g = {};
+			char* a = A + (size_t)set * an * 2;
+			g.nseg = sh.nseg;
+			for (int j = 0; j < sh.nseg; ++j) {
+				if (sh.nseg == 3) g.seg[j] = {a, sh.K, j - 1, (int64_t)j * Npad * sh.K};
+				else if (sh.nseg == 2) g.seg[j] = {a + (size_t)j * sh.M * sh.K * 2, sh.K, 0, (int64_t)j * sh.K};
+				else g.seg[j] = {a, sh.K, 0, 0};
+			}
+			g.W = W + (size_t)set * wn * 2; g.ldw = sh.nseg == 2 ? 2 * sh.K : sh.K; g.M = sh.M; g.N = sh.N; g.K = sh.K; g.rows_per_batch = sh.T; g.bias = bias;
+			if (sh.resid) { g.residual = Cf; g.ldr = sh.N; g.C = Cf; g.ldc = sh.N; g.out_f32 = 1; } else { g.C = Cb; g.ldc = sh.N; }
+			return g;
+		};
+		for (int tile = 0; tile < 5; ++tile) {
+			if (only_tile >= 0 && tile != only_tile) continue;
 			g_force_tile = 100 + tile;
-			for (int i = 0; i < 5; ++i) launch_gemm(DT_BF16, g, s);
+			for (int i = 0; i < 5; ++i) launch_gemm(DT_BF16, params(i % nset), s);
 			CK(hipStreamSynchronize(s));
-			const int reps = 50;
+			const int reps = 100;
 			CK(hipEventRecord(e0, s));
-			for (int i = 0; i < reps; ++i) launch_gemm(DT_BF16, g, s);
+			for (int i = 0; i < reps; ++i) launch_gemm(DT_BF16, params((i + 5) % nset), s);
 			CK(hipEventRecord(e1, s));
 			CK(hipEventSynchronize(e1));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 			const double us = ms * 1e3 / reps, tf = 2.0 * sh.M * sh.N * (double)sh.K * sh.nseg / (us * 1e-6) / 1e12;
-			printf("%-30s tile %s  %8.2f us  %7.1f TF/s\n", sh.name, tile == 0 ? "128x128 8w" : tile == 1 ? "128x64  4w" : tile == 3 ? "128x128 4w" : "64x64   4w", us, tf);
+			printf("%-38s %s tile %s  %8.2f us  %7.1f TF/s\n", sh.name, cold ? "cold" : "hot ", tile == 0 ? "128x128 8w" : tile == 1 ? "128x64  4w" : tile == 3 ? "128x128 8w 4st" : tile == 4 ? "128x64 4w 5st" : "64x64   4w", us, tf);
 		}
 		CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(Cb)); CK(hipFree(Cf)); CK(hipFree(bias));
 	}

@@ -143,7 +143,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 }
 
 // NWM x NWN waves per workgroup; 8 waves (2 per SIMD) let one wave's MFMAs run under another's LDS reads and DMA issue.
-template <typename T, int BM, int BN, int NWM, int NWN>
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	constexpr int ES = sizeof(T);
 	constexpr int BKE = 128 / ES;      // K elements per tile row
@@ -156,7 +156,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	static_assert(A_PC >= 1 && B_PC >= 1 && A_PC * 8 * NW == BM && B_PC * 8 * NW == BN, "tile does not split into 1-KiB pieces per wave");
 	constexpr int PER_TILE = A_PC + B_PC;                  // glds instructions per wave per tile
 	constexpr int STAGE = (BM + BN) * 128;
-	constexpr int NSTAGE = 3;
 	typedef typename Frag<T>::type FragT;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -279,36 +278,53 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 					acc[i][j] = mma16<T>(ua.v, ub.v, acc[i][j]);
 				}
 	};
-	// One pipeline step for tile kt whose fragments are already in `cur`:
+	// One pipeline step for tile kt (not the last) whose fragments are already in `cur`:
 	//   wait until tile kt+1 has landed for this wave (tile kt+2 may stay in flight) and this wave's reads of tile kt are done;
-	//   barrier: now tile kt+1 has landed for every wave and stage kt%3 is free everywhere;
-	//   request tile kt+3 into stage kt%3, start reading tile kt+1's fragments, multiply tile kt.
+	//   barrier: now tile kt+1 has landed for every wave and stage kt%NSTAGE is free everywhere;
+	//   request tile kt+NSTAGE into stage kt%NSTAGE, start reading tile kt+1's fragments, multiply tile kt.
+	// The fragment reads must NOT sit under a condition: the compiler does not see the hand-written waits, so it protects the
+	// MFMAs' operands itself, and with the reads of the next tile in a conditional block it can only do that with lgkmcnt(0) --
+	// i.e. the MFMAs of tile kt waited for the reads of tile kt+1 and nothing overlapped (what the first version of this loop
+	// did: ~1050 cycles per k-tile for 256 cycles of MFMA and 384 of LDS reads).  Hence the peeled last tile below.
+	// wait until at most `tiles` of this wave's requested tiles are still in flight (vmcnt takes an immediate: uniform branch chain)
+	auto wait_tiles = [&](int tiles) {
+		if (tiles <= 0) wait_vmcnt<0>();
+		else if (tiles == 1) wait_vmcnt<PER_TILE>();
+		else if (tiles == 2 || NSTAGE <= 4) wait_vmcnt<2 * PER_TILE>();
+		else if (tiles == 3 || NSTAGE <= 5) wait_vmcnt<3 * PER_TILE>();
+		else wait_vmcnt<4 * PER_TILE>();
+	};
 	auto step = [&](int kt, const Frags& cur, Frags& nxt) {
-		if (kt + 1 < NTILES) { if (kt + 2 < NTILES) wait_vmcnt<PER_TILE>(); else wait_vmcnt<0>(); }
+		wait_tiles(min(NSTAGE - 2, NTILES - 2 - kt));          // tile kt+1 has landed; up to NSTAGE-2 younger ones stay in flight
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
-		if (kt + 3 < NTILES) issue(kt % 3);
 #ifdef TTK_DIAG_SKIP
-		if ((TTK_DIAG_SKIP & 4) && kt > 0) { mfma_tile(cur); return; }   // diagnostic: no LDS fragment reads (stale registers)
-		if ((TTK_DIAG_SKIP & 8) && kt > 0) { if (kt + 1 < NTILES) read_frags(nxt, (kt + 1) % 3); return; }   // diagnostic: no MFMAs
+		if ((TTK_DIAG_SKIP & 4) && kt > 0) { if (kt + NSTAGE < NTILES) issue(kt % NSTAGE); mfma_tile(cur); return; }   // diagnostic: no LDS fragment reads (stale registers)
+		if ((TTK_DIAG_SKIP & 8) && kt > 0) { if (kt + NSTAGE < NTILES) issue(kt % NSTAGE); read_frags(nxt, (kt + 1) % NSTAGE); return; }   // diagnostic: no MFMAs
 #endif
-		if (kt + 1 < NTILES) read_frags(nxt, (kt + 1) % 3);
+		// (Pinning the order with sched_barriers -- all reads first, DMA issue between the two k-steps' MFMAs -- won 10% in an L2-hot
+		// microbenchmark and LOST 2% in the diffusion loop, where activations and weights arrive cold: tests/diag/ddim_ab.py.)
+		if (kt + NSTAGE < NTILES) issue(kt % NSTAGE);
+		read_frags(nxt, (kt + 1) % NSTAGE);
 		mfma_tile(cur);
 	};
 
-	issue(0);
-	if (NTILES > 1) issue(1);
-	if (NTILES > 2) issue(2);
-	if (NTILES > 2) wait_vmcnt<2 * PER_TILE>(); else if (NTILES > 1) wait_vmcnt<PER_TILE>(); else wait_vmcnt<0>();
+#pragma unroll
+	for (int st = 0; st < NSTAGE; ++st)
+		if (st < NTILES) issue(st);
+	wait_tiles(min(NSTAGE, NTILES) - 1);                       // tile 0 has landed
 	__builtin_amdgcn_s_barrier();
 	asm volatile("" ::: "memory");
 	Frags f0, f1;
 	read_frags(f0, 0);
-	for (int kt = 0; kt < NTILES; kt += 2) {
+	int kt = 0;
+	for (; kt + 2 < NTILES; kt += 2) {      // both tiles of a round have a successor
 		step(kt, f0, f1);
-		if (kt + 1 < NTILES) step(kt + 1, f1, f0);
+		step(kt + 1, f1, f0);
 	}
+	if (kt + 2 == NTILES) { step(kt, f0, f1); mfma_tile(f1); }
+	else mfma_tile(f0);
 
 	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
 	const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
@@ -317,16 +333,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	else { if (full) epilogue<T, 0, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 0, true, MI, NI>(p, acc, row0, col0, lane); }
 }
 
-template <typename T, int BM, int BN, int NWM, int NWN>
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
 static void launch_tile(const GemmParams& p, hipStream_t s) {
-	constexpr int LDS = 3 * (BM + BN) * 128;
+	constexpr int LDS = NSTAGE * (BM + BN) * 128;
 	static bool attr_set = false;
 	if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_set = true;
 	}
 	const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-	hipLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN>), dim3(grid), dim3(64 * NWM * NWN), LDS, s, p);
+	hipLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE>), dim3(grid), dim3(64 * NWM * NWN), LDS, s, p);
 }
 
 int g_force_tile = -1;   // TTK_GEMM_TILE=0|1|2 (tuning only)
@@ -352,10 +368,11 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
 	else {
 		tile = pick_tile(p.M, p.N);
 	}
-	if (tile == 0) launch_tile<T, 128, 128, 2, 4>(p, s);       // 8 waves, wave block 64 x 32
-	else if (tile == 1) launch_tile<T, 128, 64, 2, 2>(p, s);   // 4 waves, wave block 64 x 32, two workgroups per CU
-	else if (tile == 3) launch_tile<T, 128, 128, 2, 2>(p, s);  // 4 waves, wave block 64 x 64 (tuning only)
-	else launch_tile<T, 64, 64, 2, 2>(p, s);
+	if (tile == 0) launch_tile<T, 128, 128, 2, 4, 3>(p, s);       // 8 waves, wave block 64 x 32, two workgroups per CU
+	else if (tile == 1) launch_tile<T, 128, 64, 2, 2, 3>(p, s);   // 4 waves, wave block 64 x 32, two workgroups per CU
+	else if (tile == 3) launch_tile<T, 128, 128, 2, 4, 4>(p, s);  // as 0 with a 4-stage ring (128 KiB: one workgroup per CU)
+	else if (tile == 4) launch_tile<T, 128, 64, 2, 2, 5>(p, s);   // as 1 with a 5-stage ring (120 KiB: one workgroup per CU)
+	else launch_tile<T, 64, 64, 2, 2, 3>(p, s);
 }
 
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
