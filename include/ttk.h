@@ -82,10 +82,15 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
  * Exp(1) noise [B, V] (torch `exponential_`, so the generator stream is the reference's); finished rows get `stop_token`;
  * tok[b] = next; ids[b, col[b]] = next (skipped when col[b] >= ids_cols); history[b, hist_off + col[b]] = next (optional);
  * col[b] += 1; unfinished[b] &= next != stop_token.  suppress (optional) is a [V] byte mask of ids forced to -inf before the
- * temperature (SuppressTokensLogitsProcessor); any other warper is applied by the caller, who then passes temperature 1.  All pointers are device memory; only enqueues one kernel, so it may be captured in a HIP graph.              */
+ * temperature (SuppressTokensLogitsProcessor); any other warper is applied by the caller, who then passes temperature 1.
+ * live_rows / all_done (optional): *live_rows (device int, caller sets it to the number of unfinished rows) is decremented when a
+ * row finishes, and the row that brings it to 0 stores 1 to *all_done (device or pinned host int) -- HF's
+ * `unfinished_sequences.max() == 0` stopping test without a host round trip per token.  Pointers are device memory unless said
+ * otherwise; only enqueues one kernel, so it may be captured in a HIP graph.                                               */
 int ttk_sample_step(const float* scores, int64_t ld, int B, int V, const float* q, int64_t ldq,
 					const unsigned char* suppress, float temperature, int64_t stop_token, int64_t* unfinished, int64_t* tok, int64_t* ids, int64_t ids_ld, int64_t ids_cols,
-					int64_t* col, int64_t* history, int64_t hist_ld, int64_t hist_off, void* stream);
+					int64_t* col, int64_t* history, int64_t hist_ld, int64_t hist_off, int* live_rows, int* all_done,
+					void* stream);
 
 /* UnifiedVoice.forward(..., return_latent=True, clip_inputs=False) (unified_voice.py:544-599, get_logits :508-522):
  *   cond [B, D] f32, text [B, Tt] int64, codes [B, M] int64  ->  latents_out [B, M, D] f32 (= mel_logits[:, :-2]).  */

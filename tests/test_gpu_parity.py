@@ -251,18 +251,51 @@ def test_fused_sample_step_is_the_reference_sampling_chain():
 		col = torch.zeros(B, dtype=torch.long, device=DEV)
 		hist = torch.full((B, 3 + steps), -7, dtype=torch.long, device=DEV)
 		q = torch.empty((B, V), device=DEV)
-		toks = []
+		live = torch.full((1,), B, dtype=torch.int32, device=DEV)
+		done = torch.zeros(1, dtype=torch.int32).pin_memory()          # the flag may live in pinned host memory
+		toks, done_at = [], []
 		for lg in logits:
 			q.exponential_(1)
 			_lib.check(lib.ttk_sample_step(lg.data_ptr(), lg.stride(0), B, V, q.data_ptr(), q.stride(0), _lib.ptr(mask), temp, stop_id, unf2.data_ptr(),
 										   tok.data_ptr(), ids.data_ptr(), ids.stride(0), ids.shape[1], col.data_ptr(), hist.data_ptr(),
-										   hist.stride(0), 3, _lib.stream_ptr()), "ttk_sample_step")
+										   hist.stride(0), 3, live.data_ptr(), done.data_ptr(), _lib.stream_ptr()), "ttk_sample_step")
+			torch.cuda.synchronize()
+			done_at.append(int(done.item()))
 			toks.append(tok.clone())
 		after = torch.rand(4, device=DEV)
 		toks = torch.stack(toks, 1)
 		assert torch.equal(toks, ref_ids), (B, V, temp)
 		assert torch.equal(ids, ref_ids[:, :steps - 1]) and torch.equal(hist[:, 3:], ref_ids) and bool((hist[:, :3] == -7).all())
 		assert torch.equal(unf2, unf) and bool((col == steps).all()) and torch.equal(after, after_ref)
+		# the all-done flag rises exactly at the step after which HF's `unfinished_sequences.max() == 0` holds
+		ref_done = [int(((ref_ids[:, :k + 1] == stop_id).any(dim=1)).all()) for k in range(steps)]
+		assert done_at == ref_done and int(live.item()) == int(unf.sum())
 	# argument checking: a null pointer / bad temperature is an error code with a message, not a crash
-	assert lib.ttk_sample_step(None, 0, 1, 1, None, 0, None, 1.0, 0, None, None, None, 0, 0, None, None, 0, 0, None) != 0
+	assert lib.ttk_sample_step(None, 0, 1, 1, None, 0, None, 1.0, 0, None, None, None, 0, 0, None, None, 0, 0, None, None, None) != 0
 	assert b"ttk_sample_step" in lib.ttk_last_error()
+
+
+@pytest.mark.parametrize("bias", [2.0, 4.5, 9.0])
+def test_early_stop_without_per_token_sync_keeps_ids_and_rng_stream(lib, bias):
+	"""Graph mode looks at the all-finished flag a few tokens late; the tokens generated past the true end must be cut off and the
+	generator offset they consumed handed back, so that ids AND the next draw (the diffusion noise, inference.py:404) equal the
+	reference loop's, which tests `unfinished_sequences.max() == 0` after every token."""
+	cfg = W.AR_SMALL
+	sd = W.synth_state_dict(W.ar_shapes(cfg), 11)
+	sd["mel_head.bias"] = sd["mel_head.bias"].clone()
+	sd["mel_head.bias"][cfg.stop_mel_token] = bias          # rows stop after a few to a few dozen tokens, at different steps
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	text = torch.randint(1, 255, (1, 7), generator=torch.Generator().manual_seed(5))
+	cond = torch.randn(1, cfg.model_dim, generator=torch.Generator().manual_seed(6))
+	kw = dict(num_return_sequences=4, max_generate_length=60, temperature=0.8)
+	with torch.inference_mode():
+		ref = O.inference_speech(O.AROracle(sd, cfg), cond, text, sample_device="cuda", **kw)
+		after_ref = torch.rand(8, device=DEV)
+		outs = []
+		for use_graph in (False, True):
+			model = UnifiedVoice(sd, cfg, dtype="f32", device=DEV, max_batch=4, max_ctx=96, use_graph=use_graph)
+			for _ in range(2):                       # second call replays the cached graph from the start
+				got = model.inference_speech(cond.to(DEV), text.to(DEV), do_sample=True, **kw)
+				after = torch.rand(8, device=DEV)
+				assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (use_graph, got.shape, ref.shape)
+				assert torch.equal(after, after_ref), use_graph

@@ -189,14 +189,26 @@ class UnifiedVoice:
 				# tokens 1 and 2 eagerly (the second pass also warms every kernel before a capture), then one HIP-graph
 				# replay per token: {ttk_ar_decode; warp; multinomial; bookkeeping}.  Every position-dependent quantity
 				# (cache length, mel position, output column) lives in device memory, so one graph serves all tokens.
+				# HF's stopping test (`unfinished_sequences.max() == 0` after every token, a host round trip that idles the GPU)
+				# becomes a flag the sampling kernel raises in pinned memory; the host looks at it LAG replays late, so the GPU
+				# always has work queued.  The <= LAG tokens generated past the true end are all padding; they are cut off below
+				# and the generator offset they consumed is handed back, so ids AND the RNG stream equal the reference's.
+				LAG = 2
+				gen = torch.cuda.default_generators[self.device.index or 0]
+				off0 = gen.get_offset()
 				st.sample(0)
+				if st.rng_step is None:
+					st.rng_step = gen.get_offset() - off0
 				n = 1
-				while n < max_new and not (can_stop and int(st.unfinished.max()) == 0):
+				events = []
+				stopped = can_stop and int(st.unfinished.max()) == 0
+				while n < max_new and not stopped:
 					if st.graph is None:
 						self._decode(st.tok, st.logits)
 						st.sample(n)
 						n += 1
-						if n < max_new:
+						stopped = can_stop and int(st.unfinished.max()) == 0
+						if n < max_new and not stopped:
 							torch.cuda.synchronize(self.device)
 							g = torch.cuda.CUDAGraph()
 							with torch.cuda.graph(g):
@@ -206,6 +218,23 @@ class UnifiedVoice:
 						continue
 					st.graph.replay()
 					n += 1
+					if can_stop:
+						ev = torch.cuda.Event()
+						ev.record()
+						events.append(ev)
+						if len(events) > LAG:
+							events.pop(0).synchronize()          # the replay LAG tokens back is complete: its flag is visible
+							stopped = int(st.done[0]) != 0
+				if can_stop:
+					# exact end: HF stops right after the token with which the last row finishes
+					torch.cuda.synchronize(self.device)
+					ids = st.ids[:, :n]
+					is_stop = ids == c.stop_mel_token
+					if bool(is_stop.any(dim=1).all()):
+						n_true = int(is_stop.float().argmax(dim=1).max()) + 1
+						if n_true < n:
+							gen.set_offset(gen.get_offset() - (n - n_true) * st.rng_step)
+							n = n_true
 			return st.ids[:, :n].clone(), None
 
 	def _gen_state(self, B, max_new, trunc_index, pipe_key):
@@ -253,6 +282,9 @@ class _GenState:
 		self.unfinished = torch.ones(B, dtype=torch.long, device=dev)
 		self.col = torch.zeros(B, dtype=torch.long, device=dev)         # per-row output column (all rows move together)
 		self.q = torch.empty((B, c.number_mel_codes), device=dev, dtype=torch.float32)   # Exp(1) noise of multinomial
+		self.live = torch.zeros(1, dtype=torch.int32, device=dev)        # unfinished rows, decremented on the device
+		self.done = torch.zeros(1, dtype=torch.int32).pin_memory()       # raised by the row that finishes last; polled by the host
+		self.rng_step = None                                             # generator offset consumed by one sample() call
 		self.history = torch.ones((B, trunc_index + max_new), dtype=torch.long, device=dev) if self.pipe.needs_history else None
 		# suppress_tokens and temperature are folded into the fused kernel (the common case); any other warper runs as torch ops
 		# first and the kernel then sees finished scores
@@ -265,6 +297,8 @@ class _GenState:
 		self.ids.fill_(self.stop)
 		self.unfinished.fill_(1)
 		self.col.zero_()
+		self.live.fill_(self.B)
+		self.done.zero_()
 		if self.history is not None:
 			self.history.fill_(1)
 			self.history[:, self.trunc_index - 1] = c.start_mel_token
@@ -285,4 +319,5 @@ class _GenState:
 											   _lib.ptr(suppress), float(temperature), self.stop, self.unfinished.data_ptr(), self.tok.data_ptr(),
 											   self.ids.data_ptr(), self.ids.stride(0), self.ids.shape[1], self.col.data_ptr(),
 											   _lib.ptr(self.history), 0 if self.history is None else self.history.stride(0),
-											   self.trunc_index, _lib.stream_ptr()), "ttk_sample_step")
+											   self.trunc_index, self.live.data_ptr(), self.done.data_ptr(), _lib.stream_ptr()),
+				   "ttk_sample_step")

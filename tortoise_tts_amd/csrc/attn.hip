@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
 
 template <typename T>
 static void launch_attn_fwd_t(const AttnParams& p, hipStream_t s) {
-	const bool big = (int64_t)((p.T + 127) / 128) * p.H * p.nb >= 512;   // enough 128-query blocks for 2 waves per SIMD
+	static const int force_qt = [] { const char* e = getenv("TTK_ATTN_QT"); return e ? atoi(e) : 0; }();   // tuning knob
+	const bool big = force_qt ? force_qt == 2 : (int64_t)((p.T + 127) / 128) * p.H * p.nb >= 512;   // enough 128-query blocks for 2 waves per SIMD
 	if (big) {
 		dim3 grid((p.T + 127) / 128, p.H, p.nb);
 		if (p.causal) hipLaunchKernelGGL((k_attn_fwd<T, true, false, 2>), grid, dim3(256), 0, s, p);

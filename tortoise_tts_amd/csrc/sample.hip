@@ -39,7 +39,7 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 // grid = B rows, 1024 threads.  Three passes over the row (32 KB, L2-resident after the first): max, sum of exp, argmax of p / q.
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* scores, int64_t ld, int V, const float* q, int64_t ldq, const unsigned char* suppress, float inv_t,
 		int64_t stop_token, int64_t* unfinished, int64_t* tok, int64_t* ids, int64_t ids_ld, int64_t ids_cols, int64_t* col, int64_t* history,
-		int64_t hist_ld, int64_t hist_off) {
+		int64_t hist_ld, int64_t hist_off, int* live_rows, int* all_done) {
 	__shared__ float red[SAMPLE_THREADS / 64];
 	__shared__ int redi[SAMPLE_THREADS / 64];
 	const int b = blockIdx.x, tid = threadIdx.x;
@@ -82,7 +82,14 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* sco
 		if (c < ids_cols) ids[(int64_t)b * ids_ld + c] = nxt;
 		if (history) history[(int64_t)b * hist_ld + hist_off + c] = nxt;
 		col[b] = c + 1;
-		unfinished[b] = live * (nxt != stop_token ? 1 : 0);
+		const int64_t still = live * (nxt != stop_token ? 1 : 0);
+		unfinished[b] = still;
+		// stopping criterion without a host round trip per token: the row that finishes last raises a flag the host can poll (the
+		// flag may live in pinned host memory; it only ever goes 0 -> 1 within a generation, so a late read is merely late)
+		if (live_rows && live != 0 && still == 0) {
+			if (__hip_atomic_fetch_add(live_rows, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1 && all_done)
+				__hip_atomic_store(all_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 }
 
@@ -90,13 +97,13 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* sco
 
 extern "C" int ttk_sample_step(const float* scores, int64_t ld, int B, int V, const float* q, int64_t ldq, const unsigned char* suppress, float temperature,
 		int64_t stop_token, int64_t* unfinished, int64_t* tok, int64_t* ids, int64_t ids_ld, int64_t ids_cols, int64_t* col, int64_t* history, int64_t hist_ld,
-		int64_t hist_off, void* stream) {
+		int64_t hist_off, int* live_rows, int* all_done, void* stream) {
 	using namespace ttk;
 	TTK_REQUIRE(scores && q && unfinished && tok && ids && col, TTK_E_ARG, "ttk_sample_step: null argument");
 	TTK_REQUIRE(B >= 1 && V >= 1 && ld >= V && ldq >= V, TTK_E_ARG, "ttk_sample_step: bad shape (B %d, V %d)", B, V);
 	TTK_REQUIRE(temperature > 0.f, TTK_E_ARG, "ttk_sample_step: temperature must be positive");
 	hipLaunchKernelGGL(k_sample_step, dim3(B), dim3(SAMPLE_THREADS), 0, (hipStream_t)stream, scores, ld, V, q, ldq, suppress, 1.0f / temperature, stop_token, unfinished, tok,
-					   ids, ids_ld, ids_cols, col, history, hist_ld, hist_off);
+					   ids, ids_ld, ids_cols, col, history, hist_ld, hist_off, live_rows, all_done);
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }
