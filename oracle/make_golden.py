@@ -160,6 +160,19 @@ def lora_case(uv_mod, cfg, seed, rank, alpha):
 	return out
 
 
+def hf_sample_loop_case():
+	"""ids of the INSTALLED HuggingFace generate() on the model-free stub of oracle/stub_lm.py (CPU generator), one entry per case"""
+	import json
+	import stub_lm
+	import transformers
+	out = dict(transformers_version=np.array(transformers.__version__))
+	for name, seed, bias, B, N, kw in stub_lm.CASES:
+		ids = stub_lm.hf_generate(stub_lm.make_table(seed, bias), B, N, kw)
+		out["ids::" + name] = ids.numpy()
+		out["kw::" + name] = np.array(json.dumps(kw))
+	return out
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -171,6 +184,7 @@ def main():
 		("ar_full", lambda: ar_case(uv_mod, W.AR_FULL, 12, B=1, Tt=8, n_dec=2, M=6, full=True)),
 		("diff_full", lambda: diff_case(d_mod, W.DIFF_FULL, 22, b=1, M=6, full=True)),
 		("lora_small", lambda: lora_case(uv_mod, W.AR_SMALL, 13, rank=4, alpha=8)),
+		("hf_sample_loop", hf_sample_loop_case),
 	]
 	only = set(sys.argv[1:])
 	for name, fn in jobs:

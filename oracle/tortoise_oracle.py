@@ -216,12 +216,15 @@ def process_logits(input_ids: Tensor, logits: Tensor, *, temperature=1.0, top_k=
 
 
 def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return_sequences=1,
-					max_generate_length=None, temperature=1.0, top_k=0, top_p=1.0, repetition_penalty=1.0,
+					max_generate_length=None, temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0,
 					suppress_tokens=None, sample_device="cpu", seed=0, return_logits=False, forced_tokens=None):
 	"""unified_voice.py:632-668 + stream_generator.py:213-639 (sample branch) + HF `_sample`
 	HF:generation/utils.py:2894-2937.
 
 	* RNG: `setup_seed(seed)` with seed=0 is unconditional (stream_generator.py:223,296).
+	* Keyword defaults are HF `GenerationConfig`'s, which is what an omitted `**hf_generate_kwargs` entry means in the reference
+	  (stream_generator.py:262-276): temperature 1, **top_k 50**, top_p 1, repetition_penalty 1.  `TTS.inference` always passes
+	  top_k explicitly (0 by default, inference.py:157,334-346).  Pinned against the installed HF loop: oracle/stub_lm.py.
 	* fake prefix ids are 1, last = start_mel (unified_voice.py:647-649); the repetition penalty sees them.
 	* max_length = trunc_index + max_generate_length (:660); loop stops when every row hit EOS or at max_length.
 	* finished rows emit pad (= stop_mel_token).

@@ -12,7 +12,7 @@ ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtyp
 g = torch.Generator().manual_seed(1234)
 text = torch.randint(1, 255, (1, 64), generator=g).to(dev)
 cond = torch.randn(1, 1024, generator=g).to(dev)
-run = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, num_return_sequences=16, max_generate_length=250, suppress_tokens=[8193])
+run = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16, max_generate_length=250, suppress_tokens=[8193])
 with torch.inference_mode():
 	run(); run(); torch.cuda.synchronize()
 	ts = []

@@ -12,6 +12,6 @@ g = torch.Generator().manual_seed(1234)
 text = torch.randint(1, 255, (1, 64), generator=g).to(dev)
 cond = torch.randn(1, 1024, generator=g).to(dev)
 with torch.inference_mode():
-	ar.inference_speech(cond, text, do_sample=True, temperature=0.8, num_return_sequences=16, max_generate_length=n, suppress_tokens=[8193])
+	ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16, max_generate_length=n, suppress_tokens=[8193])
 torch.cuda.synchronize()
 print("done")

@@ -12,7 +12,7 @@ for layers in (4, 8, 30):
 	g = torch.Generator().manual_seed(1234)
 	text = torch.randint(1, 255, (1, 64), generator=g).to(dev)
 	cond = torch.randn(1, 1024, generator=g).to(dev)
-	f = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, num_return_sequences=16, max_generate_length=250, suppress_tokens=[8193])
+	f = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16, max_generate_length=250, suppress_tokens=[8193])
 	with torch.inference_mode():
 		f(); torch.cuda.synchronize()
 		t0 = time.perf_counter(); f(); torch.cuda.synchronize()

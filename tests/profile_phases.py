@@ -28,10 +28,10 @@ def timed(name, fn, n=3):
 
 
 with torch.inference_mode():
-	codes = timed("inference_speech (graph)", lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, num_return_sequences=16,
+	codes = timed("inference_speech (graph)", lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16,
 																		 max_generate_length=250, suppress_tokens=[8193]))
 	ar.use_graph = False
-	timed("inference_speech (eager)", lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, num_return_sequences=16,
+	timed("inference_speech (eager)", lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16,
 																 max_generate_length=250, suppress_tokens=[8193]), n=1)
 	ar.use_graph = True
 	lat = timed("latent pass B=16", lambda: ar.forward(cond.expand(16, -1), text.expand(16, -1), torch.tensor([64] * 16), codes, torch.tensor([250 * 1024] * 16),

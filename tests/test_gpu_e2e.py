@@ -37,7 +37,7 @@ def test_inference_matches_oracle_stage_by_stage(small, candidates, steps, Tt):
 		mels, seconds, aux = tts.inference(text, al.to(DEV), dl.to(DEV), max_ar_steps=max_ar, max_diffusion_steps=steps, candidates=candidates,
 										   suppress_tokens=[W.AR_SMALL.stop_mel_token], return_all=True)
 		# oracle, same stages; sampling on the device so both consume the same Philox stream (generate reseeds to 0)
-		ref_ids = O.inference_speech(aro, al, text, num_return_sequences=candidates, max_generate_length=max_ar, temperature=0.8,
+		ref_ids = O.inference_speech(aro, al, text, num_return_sequences=candidates, max_generate_length=max_ar, temperature=0.8, top_k=0,
 									 sample_device="cuda", suppress_tokens=[W.AR_SMALL.stop_mel_token])
 		noise_ref = torch.randn((1, 100, aux["noise"].shape[-1]), device=DEV)       # the draw TTS.inference makes next (inference.py:404)
 		ref_codes = O.fix_stop_tokens(ref_ids, W.AR_SMALL.stop_mel_token)

@@ -134,7 +134,7 @@ def test_full_size_bf16_properties():
 	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtype="bf16", device=DEV, max_batch=16, max_ctx=64 + 4 + 40 + 8)
 	text = torch.randint(1, 255, (1, 64), generator=gen(1)).to(DEV)
 	cond = torch.randn(1, 1024, generator=gen(2)).to(DEV)
-	kw = dict(do_sample=True, temperature=0.8, num_return_sequences=16, max_generate_length=40, suppress_tokens=[8193])
+	kw = dict(do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16, max_generate_length=40, suppress_tokens=[8193])
 	a = ar.inference_speech(cond, text, **kw)
 	b = ar.inference_speech(cond, text, **kw)
 	ar.use_graph = False

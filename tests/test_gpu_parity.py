@@ -287,7 +287,7 @@ def test_early_stop_without_per_token_sync_keeps_ids_and_rng_stream(lib, bias):
 	from tortoise_tts_amd.autoregressive import UnifiedVoice
 	text = torch.randint(1, 255, (1, 7), generator=torch.Generator().manual_seed(5))
 	cond = torch.randn(1, cfg.model_dim, generator=torch.Generator().manual_seed(6))
-	kw = dict(num_return_sequences=4, max_generate_length=60, temperature=0.8)
+	kw = dict(num_return_sequences=4, max_generate_length=60, temperature=0.8, top_k=0)
 	with torch.inference_mode():
 		ref = O.inference_speech(O.AROracle(sd, cfg), cond, text, sample_device="cuda", **kw)
 		after_ref = torch.rand(8, device=DEV)

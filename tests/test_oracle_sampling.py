@@ -1,6 +1,8 @@
-"""The restated generate() loop pieces (a5).  The reference's own loop cannot run on transformers 5.15
-(SURVEY.md 8c), so the warpers are pinned against the installed HF classes the reference instantiates
-(stream_generator.py:80-85) and the loop's control flow is checked by its stated invariants."""
+"""The restated generate() loop (a5).  The reference's own fork of the loop cannot run on transformers 5.15, so
+it is pinned against what it forks: the warpers against the installed HF classes the reference instantiates
+(stream_generator.py:80-85), and the loop itself -- processor order, softmax + multinomial and its generator consumption,
+pad-after-EOS, stopping, max_length, GenerationConfig defaults -- against the installed `GenerationMixin.generate` driving a
+model-free stub (oracle/stub_lm.py): ids stored in tests/golden/hf_sample_loop.npz and, when transformers is importable, live."""
 import pytest
 import torch
 
@@ -58,3 +60,44 @@ def test_stop_and_calm_postprocessing():
 	c = torch.tensor([[1] + [83] * 12])
 	lat = torch.zeros(1, 13, 4)
 	assert O.trim_calm_tokens(c, lat).shape[1] == 9
+
+
+def _stub_ids(name):
+	import stub_lm
+	name_, seed, bias, B, N, kw = next(c for c in stub_lm.CASES if c[0] == name)
+	ar = stub_lm.StubAR(W.AR_SMALL, stub_lm.make_table(seed, bias))
+	with torch.inference_mode():
+		ids = O.inference_speech(ar, torch.zeros(1, 1), torch.zeros(1, stub_lm.PREFIX - 3, dtype=torch.long), num_return_sequences=B,
+								 max_generate_length=N, **kw)
+	return ids, (seed, bias, B, N, kw)
+
+
+@pytest.mark.parametrize("name", ["plain", "stops_early", "all_warpers", "suppress", "top_p_only", "hf_defaults", "sixteen_candidates"])
+def test_loop_equals_huggingface_generate_on_stub_model(golden, name):
+	import json
+	import stub_lm
+	g = golden("hf_sample_loop")
+	ids, (seed, bias, B, N, kw) = _stub_ids(name)
+	assert json.loads(str(g["kw::" + name])) == json.loads(json.dumps(kw))          # the fixture was made with these arguments
+	want = torch.from_numpy(g["ids::" + name])
+	assert ids.shape == want.shape and torch.equal(ids, want)
+	if name == "stops_early":
+		assert want.shape[1] < N and (want == stub_lm.STOP).any(dim=1).all()          # the case does stop early, on different steps
+		assert len({int((r == stub_lm.STOP).float().argmax()) for r in want}) > 1
+	if name == "suppress":
+		assert not (want == 5).any() and not (want == 17).any() and not (want == stub_lm.STOP).any()
+	# live, against the transformers installed next to this test (same loop the fixture came from)
+	pytest.importorskip("transformers")
+	live = stub_lm.hf_generate(stub_lm.make_table(seed, bias), B, N, kw)
+	assert torch.equal(live, want)
+
+
+def test_omitted_top_k_means_generation_config_default():
+	"""`hf_defaults` passes nothing: HF applies top_k = 50; the same call with top_k=0 must differ (so the default is not a no-op)."""
+	a, _ = _stub_ids("hf_defaults")
+	import stub_lm
+	ar = stub_lm.StubAR(W.AR_SMALL, stub_lm.make_table(6, 5.0))
+	with torch.inference_mode():
+		b = O.inference_speech(ar, torch.zeros(1, 1), torch.zeros(1, stub_lm.PREFIX - 3, dtype=torch.long), num_return_sequences=3, max_generate_length=25, top_k=0)
+		c = O.inference_speech(ar, torch.zeros(1, 1), torch.zeros(1, stub_lm.PREFIX - 3, dtype=torch.long), num_return_sequences=3, max_generate_length=25, top_k=50)
+	assert torch.equal(a, c) and not (a.shape == b.shape and torch.equal(a, b))

@@ -128,8 +128,10 @@ class UnifiedVoice:
 			raise NotImplementedError("input_tokens (prompted continuation) is not on the inference hot path")
 		if text_inputs.shape[0] != 1:
 			raise NotImplementedError("one text line per call, as inference.py:244-246 does")
-		if hf_generate_kwargs.get("num_beams", 1) not in (None, 1) or not hf_generate_kwargs.get("do_sample", True):
-			raise NotImplementedError("only the sampling branch (do_sample=True, num_beams=1) is implemented")
+		# omitted keywords mean HF GenerationConfig defaults in the reference (stream_generator.py:262-276): do_sample False (greedy
+		# search, not on the hot path: TTS.inference always samples, inference.py:336), top_k 50, temperature / top_p / penalty 1
+		if hf_generate_kwargs.get("num_beams", 1) not in (None, 1) or not hf_generate_kwargs.get("do_sample", False):
+			raise NotImplementedError("only the sampling branch (do_sample=True, num_beams=1) is implemented; pass do_sample=True")
 		gen, _ = self._generate(speech_conditioning_latent, text_inputs, num_return_sequences, max_generate_length,
 								typical_mass if typical_sampling else None, hf_generate_kwargs, stream=False)
 		return gen
@@ -165,7 +167,7 @@ class UnifiedVoice:
 			raise _lib.TTKError(f"prefix {trunc_index} + {max_new} new tokens exceed max_ctx={self.max_ctx} "
 								f"or the mel position table ({c.max_mel_seq_len})")
 		suppress = tuple(kw.get("suppress_tokens") or ())
-		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 0), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0),
+		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 50), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0),
 					suppress, typical_mass)
 		if stream:
 			pipe = LogitsPipeline(temperature=pipe_key[0], top_k=pipe_key[1], top_p=pipe_key[2], repetition_penalty=pipe_key[3],
