@@ -18,11 +18,15 @@ Pinning: the reference has no tests or golden vectors of its own (SURVEY.md sect
 is pinned against the reference itself run in the build container: `oracle/make_golden.py` imports
 the reference modules by path (`oracle/ref_shim.py`), loads the same seeded synthetic weights into
 them and stores inputs + outputs under `tests/golden/`; `tests/test_oracle_golden.py` checks this file
-against those vectors.  The one part with no runnable reference is the `generate()` loop (a5): it
-raises AttributeError on transformers 5.15, so the loop is restated from the
-source and its warpers are pinned against the installed HF classes -- "parity unpinned" applies to the
-loop's control flow only (seeding, processor order, pad-after-EOS, max_length), and is said so in
-DESIGN.md.
+against those vectors.  The one part whose reference code cannot run here is the `generate()` loop (a5): the
+reference's fork of HuggingFace's loop raises AttributeError on transformers 5.15.  It is
+pinned against what it forks instead: the warpers against the installed HF classes the reference instantiates,
+and the loop (processor order, softmax + multinomial and the generator stream it consumes, pad-after-EOS,
+stopping, max_length, GenerationConfig defaults) against the installed `GenerationMixin.generate` driving a
+model-free stub (`oracle/stub_lm.py`, fixture `tests/golden/hf_sample_loop.npz`, `tests/test_oracle_sampling.py`).
+What stays restated from source only -- "parity unpinned", said so in DESIGN.md -- is the thin wrapper the
+reference puts around that loop: the unconditional `setup_seed(0)` (stream_generator.py:223,296) and the
+fake-prefix construction of `inference_speech` (unified_voice.py:639-660).
 
 Arithmetic is plain torch fp32 on the CPU (a floating-point path: the torch reference the task
 keeps for floating-point kernels); schedule tables are numpy float64 exactly as the reference.
