@@ -173,6 +173,28 @@ def hf_sample_loop_case():
 	return out
 
 
+def wrapper_case(uv_mod):
+	"""The thin wrapper around the sampling loop: what the reference's `setup_seed(0)` leaves in the three host generators, and the fake
+	id row `compute_embeddings` hands to generate()."""
+	import importlib
+	import random
+	sg = importlib.import_module("tortoise_tts.models.stream_generator")
+	out = {}
+	for seed in (0, 7):
+		sg.setup_seed(seed)
+		out[f"torch_{seed}"] = torch.rand(4).numpy()
+		out[f"numpy_{seed}"] = np.random.rand(4)
+		out[f"python_{seed}"] = np.array([random.random() for _ in range(4)])
+	torch.manual_seed(123); np.random.seed(123); random.seed(123)
+	sg.setup_seed(-1)                                          # -1 leaves the generators alone
+	out["torch_keep"] = torch.rand(4).numpy()
+	cfg = W.AR_SMALL
+	m = uv_mod.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, checkpointing=False)
+	with torch.inference_mode():
+		out["fake_ids"] = m.compute_embeddings(torch.zeros(2, cfg.model_dim), torch.randint(1, 255, (2, 5), generator=gen(1))).numpy()
+	return out
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -185,6 +207,7 @@ def main():
 		("diff_full", lambda: diff_case(d_mod, W.DIFF_FULL, 22, b=1, M=6, full=True)),
 		("lora_small", lambda: lora_case(uv_mod, W.AR_SMALL, 13, rank=4, alpha=8)),
 		("hf_sample_loop", hf_sample_loop_case),
+		("wrapper", lambda: wrapper_case(uv_mod)),
 	]
 	only = set(sys.argv[1:])
 	for name, fn in jobs:

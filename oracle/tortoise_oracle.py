@@ -24,9 +24,10 @@ pinned against what it forks instead: the warpers against the installed HF class
 and the loop (processor order, softmax + multinomial and the generator stream it consumes, pad-after-EOS,
 stopping, max_length, GenerationConfig defaults) against the installed `GenerationMixin.generate` driving a
 model-free stub (`oracle/stub_lm.py`, fixture `tests/golden/hf_sample_loop.npz`, `tests/test_oracle_sampling.py`).
-What stays restated from source only -- "parity unpinned", said so in DESIGN.md -- is the thin wrapper the
-reference puts around that loop: the unconditional `setup_seed(0)` (stream_generator.py:223,296) and the
-fake-prefix construction of `inference_speech` (unified_voice.py:639-660).
+`setup_seed` and the fake id row handed to generate() are pinned against the reference run here
+(`tests/golden/wrapper.npz`).  What stays restated from source only, and is said so in DESIGN.md, are two lines of
+`inference_speech`: `max_length = trunc_index + max_generate_length` (unified_voice.py:660) and the final slice
+`gen[:, trunc_index:]` (:668).
 
 Arithmetic is plain torch fp32 on the CPU (a floating-point path: the torch reference the task
 keeps for floating-point kernels); schedule tables are numpy float64 exactly as the reference.

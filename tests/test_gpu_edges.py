@@ -173,3 +173,12 @@ def test_full_size_fused_groupnorm_stats_match_oracle_and_unfused(monkeypatch):
 	with torch.inference_mode():
 		ref = O.DiffusionOracle(sd, W.DIFF_FULL).forward(x, t, E)
 	assert maxerr(a, ref) < 1e-3
+
+
+def test_compute_embeddings_fake_id_row_equals_reference(small_ar, golden):
+	"""the id row handed to generate(): ones with start_mel last, prefix + 1 long (unified_voice.py:614-630), from the reference itself"""
+	model = small_ar[0] if isinstance(small_ar, tuple) else small_ar
+	want = torch.from_numpy(golden("wrapper")["fake_ids"])
+	text = torch.randint(1, 255, (2, 5), generator=gen(1)).to(DEV)
+	got = model.compute_embeddings(torch.zeros(2, W.AR_SMALL.model_dim, device=DEV), text)
+	assert got.dtype == torch.long and torch.equal(got.cpu(), want)

@@ -101,3 +101,22 @@ def test_omitted_top_k_means_generation_config_default():
 		b = O.inference_speech(ar, torch.zeros(1, 1), torch.zeros(1, stub_lm.PREFIX - 3, dtype=torch.long), num_return_sequences=3, max_generate_length=25, top_k=0)
 		c = O.inference_speech(ar, torch.zeros(1, 1), torch.zeros(1, stub_lm.PREFIX - 3, dtype=torch.long), num_return_sequences=3, max_generate_length=25, top_k=50)
 	assert torch.equal(a, c) and not (a.shape == b.shape and torch.equal(a, b))
+
+
+def test_setup_seed_equals_reference(golden):
+	"""the product's `setup_seed` (sampling.py) and the oracle's seeding leave the generators where the reference's setup_seed does"""
+	import random
+
+	import numpy as np
+
+	from tortoise_tts_amd.sampling import setup_seed
+	g = golden("wrapper")
+	for seed in (0, 7):
+		setup_seed(seed)
+		assert np.array_equal(torch.rand(4).numpy(), g[f"torch_{seed}"])
+		assert np.array_equal(np.random.rand(4), g[f"numpy_{seed}"])
+		assert np.array_equal(np.array([random.random() for _ in range(4)]), g[f"python_{seed}"])
+	torch.manual_seed(123)
+	setup_seed(-1)
+	assert np.array_equal(torch.rand(4).numpy(), g["torch_keep"])
+	assert g["fake_ids"].shape == (2, 5 + 4) and (g["fake_ids"][:, :-1] == 1).all() and (g["fake_ids"][:, -1] == W.AR_SMALL.start_mel_token).all()
