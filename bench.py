@@ -34,7 +34,7 @@ def parse():
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
-	ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+	ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w"], help="fp8w = BASELINE config 5: bf16 arithmetic, block GEMM weights in fp8-e4m3")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-roofline", action="store_true")
 	ap.add_argument("--small", action="store_true", help="tiny models (plumbing check only; the number is NOT the metric)")

@@ -26,7 +26,10 @@ extern "C" {
 #define TTK_VERSION 1
 
 enum { TTK_OK = 0, TTK_E_ARG = -1, TTK_E_HIP = -2, TTK_E_WEIGHT = -3, TTK_E_STATE = -4 };
-enum { TTK_F32 = 0, TTK_BF16 = 1 };   /* arithmetic mode: storage/MFMA operand type (accumulation is always f32) */
+/* arithmetic mode: storage/MFMA operand type (accumulation is always f32).  TTK_FP8W (BASELINE config 5) = TTK_BF16 arithmetic with
+ * the GEMM weights of the GPT-2 blocks / ResBlocks / AttentionBlocks rounded to fp8-e4m3 (OCP, round to nearest even) times a
+ * power-of-two per-tensor scale; the KV-cached decode streams them as fp8 bytes, the dense GEMMs hold the same values in bf16. */
+enum { TTK_F32 = 0, TTK_BF16 = 1, TTK_FP8W = 2 };
 
 typedef struct {
 	const char* name;     /* reference state_dict key, e.g. "gpt.h.0.attn.c_attn.weight" */
@@ -56,7 +59,7 @@ typedef struct {
 	int max_mel_seq_len, max_text_seq_len;    /* rows of the two learned position tables (:405-406) */
 	int number_text_tokens_p1, number_mel_codes;
 	int start_text_token, stop_text_token, start_mel_token, stop_mel_token;
-	int dtype;                                /* TTK_F32 | TTK_BF16 */
+	int dtype;                                /* TTK_F32 | TTK_BF16 | TTK_FP8W */
 	int max_batch;                            /* candidates decoded together (<= 64; <= 32 in TTK_F32) */
 	int max_ctx;                              /* KV-cache rows per sequence: prefix + generated tokens */
 } ttk_ar_config;
@@ -91,6 +94,11 @@ int ttk_sample_step(const float* scores, int64_t ld, int B, int V, const float* 
 					const unsigned char* suppress, float temperature, int64_t stop_token, int64_t* unfinished, int64_t* tok, int64_t* ids, int64_t ids_ld, int64_t ids_cols,
 					int64_t* col, int64_t* history, int64_t hist_ld, int64_t hist_off, int* live_rows, int* all_done,
 					void* stream);
+
+/* The weight rounding of TTK_FP8W applied in place to a device f32 array: x <- fp8_e4m3(x / s) * s with s = the smallest power of
+ * two >= max|x| / 448, returned in *scale_out (host).  This is exactly what ttk_*_create does to a TTK_FP8W matrix, exposed so that a
+ * caller (and the parity tests) can build the equivalent TTK_BF16 model.                                                     */
+int ttk_fp8_round_weights(float* x, int64_t n, float* scale_out, void* stream);
 
 /* UnifiedVoice.forward(..., return_latent=True, clip_inputs=False) (unified_voice.py:544-599, get_logits :508-522):
  *   cond [B, D] f32, text [B, Tt] int64, codes [B, M] int64  ->  latents_out [B, M, D] f32 (= mel_logits[:, :-2]).  */

@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTK_LIB") or os.path.join(HERE, "libttk.so")   # TTK_LIB: A/B runs of an experimental build
 
 TTK_F32, TTK_BF16 = 0, 1
-DTYPES = {"f32": TTK_F32, "fp32": TTK_F32, "float32": TTK_F32, "bf16": TTK_BF16, "bfloat16": TTK_BF16}
+TTK_FP8W = 2
+DTYPES = {"f32": TTK_F32, "fp32": TTK_F32, "float32": TTK_F32, "bf16": TTK_BF16, "bfloat16": TTK_BF16, "fp8w": TTK_FP8W, "fp8": TTK_FP8W}
 
 
 class TTKError(RuntimeError):
@@ -57,6 +58,7 @@ SYMBOLS = {
 	"ttk_ar_prefill": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
 	"ttk_ar_decode": (_I, [_P, _P, _P, _P, _P]),
 	"ttk_ar_latents": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P]),
+	"ttk_fp8_round_weights": (_I, [_P, _L, C.POINTER(C.c_float), _P]),
 	"ttk_sample_step": (_I, [_P, _L, _I, _I, _P, _L, _P, C.c_float, _L, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P]),
 	"ttk_diff_create": (_I, [C.POINTER(_P), C.POINTER(DiffConfigC), C.POINTER(WeightView), _I]),
 	"ttk_diff_destroy": (_I, [_P]),

@@ -74,7 +74,8 @@ __global__ void k_build_latent_emb(const float* cond, const int64_t* text, int T
 
 struct ttk_ar {
 	ttk_ar_config cfg;
-	int dt;
+	int dt;                 // arithmetic type the kernels run in (DT_F32 / DT_BF16)
+	int wdt;                // storage type of the GPT-2 block matrices (== dt, or DT_FP8W)
 	size_t es;
 	Arena arena;
 	std::vector<ARLayer> L;
@@ -167,7 +168,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
 		char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
 		SkinnyParams p = {};
-		p.Wp = L.attn.wfrag; p.N = 3 * d; p.K = d; p.M = nrows; p.bias = L.attn.bias;
+		p.Wp = L.attn.wfrag; p.w8 = L.attn.w8; p.wscale = L.attn.wscale; p.N = 3 * d; p.K = d; p.M = nrows; p.bias = L.attn.bias;
 		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b;
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
 		launch_skinny(dt, p, wv_small, s);
@@ -175,16 +176,16 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out;
 		launch_attn_decode(dt, a, s);
 		p = {};
-		p.Wp = L.proj.wfrag; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d;
+		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.narrow = h->narrow;
 		launch_skinny(dt, p, d >= 1024 ? h->wv_proj : 4, s);
 		p = {};
-		p.Wp = L.fc.wfrag; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
+		p.Wp = L.fc.wfrag; p.w8 = L.fc.w8; p.wscale = L.fc.wscale; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
 		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b;
 		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf;
 		launch_skinny(dt, p, wv_small, s);
 		p = {};
-		p.Wp = L.proj2.wfrag; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d;
+		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
 		p.narrow = h->narrow;
 		if (d >= 1024 && !h->narrow) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
@@ -207,13 +208,14 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	TTK_REQUIRE(cfg->model_dim % 64 == 0 && cfg->heads * 64 == cfg->model_dim, TTK_E_ARG,
 				"ttk_ar_create: head_dim must be 64 (model_dim %d, heads %d)", cfg->model_dim, cfg->heads);
 	TTK_REQUIRE(cfg->model_dim <= 2048, TTK_E_ARG, "ttk_ar_create: model_dim %d > 2048 unsupported", cfg->model_dim);
-	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16, TTK_E_ARG, "ttk_ar_create: bad dtype %d", cfg->dtype);
+	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_FP8W, TTK_E_ARG, "ttk_ar_create: bad dtype %d", cfg->dtype);
 	TTK_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= (cfg->dtype == TTK_F32 ? 32 : 64), TTK_E_ARG,
 				"ttk_ar_create: max_batch %d out of range", cfg->max_batch);
 	TTK_REQUIRE(cfg->max_ctx >= 8, TTK_E_ARG, "ttk_ar_create: max_ctx %d too small", cfg->max_ctx);
 	ttk_ar* h = new ttk_ar();
 	h->cfg = *cfg;
-	h->dt = cfg->dtype;
+	h->wdt = cfg->dtype;
+	h->dt = kernel_dtype(cfg->dtype);
 	h->es = dtype_size(h->dt);
 	WeightMap wm(w, n_w);
 	const int d = cfg->model_dim;
@@ -228,10 +230,10 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 		AR_TRY(upload_f32(h->arena, wm, p + "ln_1.bias", d, &L.ln1_b));
 		AR_TRY(upload_f32(h->arena, wm, p + "ln_2.weight", d, &L.ln2_g));
 		AR_TRY(upload_f32(h->arena, wm, p + "ln_2.bias", d, &L.ln2_b));
-		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "attn.c_attn.weight", p + "attn.c_attn.bias", PK_KN, 3 * d, d, true, &L.attn));
-		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "attn.c_proj.weight", p + "attn.c_proj.bias", PK_KN, d, d, true, &L.proj));
-		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", PK_KN, 4 * d, d, true, &L.fc));
-		AR_TRY(upload_mat(h->arena, wm, h->dt, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", PK_KN, d, 4 * d, true, &L.proj2));
+		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "attn.c_attn.weight", p + "attn.c_attn.bias", PK_KN, 3 * d, d, true, &L.attn));
+		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "attn.c_proj.weight", p + "attn.c_proj.bias", PK_KN, d, d, true, &L.proj));
+		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", PK_KN, 4 * d, d, true, &L.fc));
+		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", PK_KN, d, 4 * d, true, &L.proj2));
 	}
 	AR_TRY(upload_f32(h->arena, wm, "gpt.ln_f.weight", d, &h->lnf_g));
 	AR_TRY(upload_f32(h->arena, wm, "gpt.ln_f.bias", d, &h->lnf_b));

@@ -20,7 +20,7 @@ struct DLayer { ResBlk res; AttnBlk attn; };
 
 struct ttk_diff {
 	ttk_diff_config cfg;
-	int dt;
+	int dt, wdt;            // kernel arithmetic type / storage type of the block GEMM weights (== dt, or DT_FP8W)
 	size_t es;
 	Arena arena;
 	AttnBlk lat_attn[4];
@@ -163,8 +163,8 @@ static int load_attn(ttk_diff* h, const WeightMap& wm, const std::string& p, Att
 	const int C = h->cfg.model_channels;
 	TTK_TRY(upload_f32(h->arena, wm, p + "norm.weight", C, &A->gn_g));
 	TTK_TRY(upload_f32(h->arena, wm, p + "norm.bias", C, &A->gn_b));
-	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "qkv.weight", p + "qkv.bias", PK_NK, 3 * C, C, false, &A->qkv));
-	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "proj_out.weight", p + "proj_out.bias", PK_NK, C, C, false, &A->proj));
+	TTK_TRY(upload_mat(h->arena, wm, h->wdt, p + "qkv.weight", p + "qkv.bias", PK_NK, 3 * C, C, false, &A->qkv));
+	TTK_TRY(upload_mat(h->arena, wm, h->wdt, p + "proj_out.weight", p + "proj_out.bias", PK_NK, C, C, false, &A->proj));
 	TTK_TRY(upload_f32(h->arena, wm, p + "__relbias", (int64_t)h->cfg.num_heads * 129, &A->relbias));
 	return TTK_OK;
 }
@@ -174,8 +174,8 @@ static int load_res(ttk_diff* h, const WeightMap& wm, const std::string& p, ResB
 	TTK_TRY(upload_f32(h->arena, wm, p + "in_layers.0.bias", C, &R->gn1_b));
 	TTK_TRY(upload_f32(h->arena, wm, p + "out_layers.0.weight", C, &R->gn2_g));
 	TTK_TRY(upload_f32(h->arena, wm, p + "out_layers.0.bias", C, &R->gn2_b));
-	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "in_layers.2.weight", p + "in_layers.2.bias", PK_NK, C, C, false, &R->in));
-	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "out_layers.3.weight", p + "out_layers.3.bias", PK_CONV3, C, C, false, &R->out3));
+	TTK_TRY(upload_mat(h->arena, wm, h->wdt, p + "in_layers.2.weight", p + "in_layers.2.bias", PK_NK, C, C, false, &R->in));
+	TTK_TRY(upload_mat(h->arena, wm, h->wdt, p + "out_layers.3.weight", p + "out_layers.3.bias", PK_CONV3, C, C, false, &R->out3));
 	R->emb_slot = slot;
 	return TTK_OK;
 }
@@ -189,10 +189,11 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	TTK_REQUIRE(cfg->in_latent_channels % 64 == 0, TTK_E_ARG, "ttk_diff_create: in_latent_channels %% 64 != 0");
 	TTK_REQUIRE(cfg->model_channels % 128 == 0 && cfg->model_channels <= 1024 && 1024 % cfg->model_channels == 0, TTK_E_ARG,
 				"ttk_diff_create: model_channels %d unsupported (128, 256, 512 or 1024)", cfg->model_channels);
-	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
+	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_FP8W, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
 	ttk_diff* h = new ttk_diff();
 	h->cfg = *cfg;
-	h->dt = cfg->dtype;
+	h->wdt = cfg->dtype;              // ResBlock / AttentionBlock GEMM weights: rounded to fp8-e4m3 in DT_FP8W (held exactly in bf16)
+	h->dt = kernel_dtype(cfg->dtype);
 	h->es = dtype_size(h->dt);
 	h->in_pad = round_up(cfg->in_channels, 64);
 	h->fuse_stats = getenv("TTK_NO_FUSED_GN") ? 0 : 1;

@@ -1,5 +1,8 @@
 // Weight packing, run once in ttk_*_create: f32 reference-layout tensors -> T-typed, padded, K-contiguous matrices
 // (and the MFMA-fragment order of the decode path).
+#include <math.h>
+#include <string.h>
+
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -49,6 +52,65 @@ void launch_pack_frag(int dt, const void* src, int Npad, int K, void* dst, hipSt
 	const unsigned grid = (unsigned)((total + 255) / 256);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_pack_frag<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, Npad, K, (bf16*)dst);
 	else hipLaunchKernelGGL((k_pack_frag<float>), dim3(grid), dim3(256), 0, s, (const float*)src, Npad, K, (float*)dst);
+}
+
+// ------------------------------------------------------------------------------------------------ fp8-e4m3 weights
+// Quantisation is done BY the hardware conversion instructions (v_cvt_pk_fp8_f32 / v_cvt_pk_f32_fp8: OCP e4m3, round to nearest
+// even, finite range +-448), so what the decode kernels decode is by construction what was encoded here; tests pin the format against
+// torch.float8_e4m3fn.  The per-tensor scale is a power of two >= absmax / 448: dividing and multiplying by it is exact, and every
+// dequantised weight (3 mantissa bits) is exactly representable in bf16, so "fp8 weights" is bit-for-bit "bf16 kernels on rounded weights".
+__global__ void k_absmax(const float* x, int64_t n, unsigned* out) {
+	float m = 0.f;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+	m = wave_max(m);
+	if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
+}
+int device_absmax(const float* x, int64_t n, float* out_host) {
+	unsigned* d = nullptr;
+	if (hipMalloc((void**)&d, 4) != hipSuccess) return -1;
+	(void)hipMemset(d, 0, 4);
+	hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, 0, x, n, d);
+	unsigned bits = 0;
+	const hipError_t e = hipMemcpy(&bits, d, 4, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
+	if (e != hipSuccess) return -1;
+	memcpy(out_host, &bits, 4);
+	return 0;
+}
+float fp8_scale_for(float absmax) {
+	if (!(absmax > 0.f) || !isfinite(absmax)) return 1.f;
+	int e;
+	const float fr = frexpf(absmax / 448.0f, &e);         // absmax / 448 = fr * 2^e, fr in [0.5, 1)
+	return ldexpf(1.0f, fr == 0.5f ? e - 1 : e);          // smallest power of two >= absmax / 448
+}
+__device__ __forceinline__ float fp8_round(float v) {
+	typedef float f2 __attribute__((ext_vector_type(2)));
+	const int q = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
+	const f2 r = __builtin_amdgcn_cvt_pk_f32_fp8(q, false);
+	return r[0];
+}
+__global__ void k_fp8_roundtrip(float* x, int64_t n, float scale, float inv) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) x[i] = fp8_round(x[i] * inv) * scale;
+}
+void launch_fp8_roundtrip(float* x, int64_t n, float scale, hipStream_t s) {
+	hipLaunchKernelGGL(k_fp8_roundtrip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, scale, 1.0f / scale);
+}
+// [Npad][K] bf16 (values = fp8 grid * scale) -> Wp8[n_tile][k_step][lane][8 bytes], same element order as k_pack_frag
+__global__ void k_pack_frag_fp8(const bf16* src, int Npad, int K, float inv, unsigned char* dst) {
+	const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;      // two elements (one 16-bit half) per thread
+	if (idx >= (int64_t)Npad * K) return;
+	const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+	const int64_t t = idx >> 9;
+	const int KS = K / 32;
+	const int ks = (int)(t % KS), nt = (int)(t / KS);
+	const bf16* p = src + (int64_t)(16 * nt + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4) + j;
+	const int q = __builtin_amdgcn_cvt_pk_fp8_f32((float)p[0] * inv, (float)p[1] * inv, 0, false);
+	*(unsigned short*)(dst + idx) = (unsigned short)(q & 0xffff);
+}
+void launch_pack_frag_fp8(const void* src, int Npad, int K, float scale, void* dst, hipStream_t s) {
+	const int64_t total = (int64_t)Npad * K / 2;
+	hipLaunchKernelGGL(k_pack_frag_fp8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16*)src, Npad, K, 1.0f / scale, (unsigned char*)dst);
 }
 
 }  // namespace ttk

@@ -38,11 +38,29 @@ namespace ttk {
 #define TTK_STAMP(i) do {} while (0)
 #endif
 
+// Weight fragment as it sits in memory: the MFMA operand itself, or (W8, bf16 arithmetic only) 8 fp8-e4m3 bytes that are widened to
+// bf16 -- exactly, e4m3 has 3 mantissa bits -- next to their MFMA; the power-of-two tensor scale is applied to the f32 sums.
+template <typename T, bool W8> struct WFrag {
+	typedef typename Frag<T>::type raw;
+	static __device__ __forceinline__ typename Frag<T>::type dec(raw r) { return r; }
+};
+template <> struct WFrag<bf16, true> {
+	typedef unsigned raw __attribute__((ext_vector_type(2)));      // a clang vector: the non-temporal load builtin takes no HIP struct types
+	static __device__ __forceinline__ bf16x8 dec(raw r) {
+		typedef float f2 __attribute__((ext_vector_type(2)));
+		const f2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[0], true);
+		const f2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)r[1], true);
+		return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)b[0], (bf16)b[1], (bf16)c[0], (bf16)c[1], (bf16)d[0], (bf16)d[1]};
+	}
+};
+
 // KC = float4 chunks of a row per lane in the LayerNorm prologue (K <= 256 * KC); LN kernels run <= 8 waves (2 per SIMD,
 // 256 VGPRs), plain ones up to 16.
-template <typename T, int MT, bool LN, int KC>
+template <typename T, int MT, bool LN, int KC, bool W8>
 __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	typedef typename Frag<T>::type FragT;
+	typedef WFrag<T, W8> WF;
+	typedef typename WF::raw WRaw;
 	constexpr int ES = sizeof(T);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -184,9 +202,9 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	// ---- this wave's K slice of the weights; the first PRE fragments are requested now
 	const int kw0 = (KS * kslice) / p.ksplit, kw1 = (KS * (kslice + 1)) / p.ksplit;   // this workgroup's k-steps
 	const int ks0 = kw0 + ((kw1 - kw0) * wave) / nw, ks1 = kw0 + ((kw1 - kw0) * (wave + 1)) / nw;
-	const FragT* wp = (const FragT*)p.Wp + ((int64_t)nt * KS) * 64 + (p.narrow ? ((lane & ~15) | (4 * sub + (lane & 3))) : lane);
+	const WRaw* wp = (const WRaw*)p.Wp + ((int64_t)nt * KS) * 64 + (p.narrow ? ((lane & ~15) | (4 * sub + (lane & 3))) : lane);
 	constexpr int PRE = 8;   // 8 x 1 KiB (bf16) in flight per wave
-	FragT bpre[PRE];
+	WRaw bpre[PRE];
 	const int npre = min(ks1 - ks0, PRE);
 	// (Requesting the plain-mode A fragments of this batch up front as well, before or after the weights, measured 5-7 ms per
 	// utterance SLOWER than letting them be fetched next to their MFMA.)
@@ -223,23 +241,23 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	for (int u = 0; u < PRE; ++u)
 		if (u < npre) {
 #pragma unroll
-			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks0 + u), bpre[u], acc[mt]);
+			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks0 + u), WF::dec(bpre[u]), acc[mt]);
 		}
 	constexpr int UN = 8;
 	int ks = ks0 + npre;
 	for (; ks + UN <= ks1; ks += UN) {
-		FragT b[UN];
+		WRaw b[UN];
 #pragma unroll
 		for (int u = 0; u < UN; ++u) b[u] = TTK_WLOAD(wp + (int64_t)(ks + u) * 64);
 #pragma unroll
 		for (int u = 0; u < UN; ++u)
 #pragma unroll
-			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks + u), b[u], acc[mt]);
+			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks + u), WF::dec(b[u]), acc[mt]);
 	}
 	for (; ks < ks1; ++ks) {
-		const FragT b = TTK_WLOAD(wp + (int64_t)ks * 64);
+		const WRaw b = TTK_WLOAD(wp + (int64_t)ks * 64);
 #pragma unroll
-		for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks), b, acc[mt]);
+		for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks), WF::dec(b), acc[mt]);
 	}
 
 	TTK_STAMP(3);
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	for (int mt = 0; mt < MT; ++mt) {
 		const int m = mt * 16 + 4 * (l2 >> 4) + r;
 		if (m >= p.M) continue;
-		const float v = vsum[mt] + bias;
+		const float v = (W8 ? vsum[mt] * p.wscale : vsum[mt]) + bias;
 		if (p.mode == SK_STORE_F32) {
 			p.out_f32[(int64_t)m * p.ldc + n] = v;
 		} else if (p.mode == SK_RESIDUAL) {
@@ -316,7 +334,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	TTK_STAMP(5);
 }
 
-template <typename T, int MT>
+template <typename T, int MT, bool W8>
 static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
 	const int grid = p.narrow ? ((p.N + 15) / 16) * 4 : ((p.N + 15) / 16) * p.ksplit;
 	const size_t red = (size_t)waves * MT * 64 * 4 * sizeof(float);
@@ -324,22 +342,22 @@ static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
 		if (waves > 8) waves = 8;
 		const size_t lds = (size_t)16 * MT * (p.K * sizeof(T) + 16) + (size_t)waves * MT * 64 * 4 * sizeof(float);
 		if (p.K <= 1024) {
-			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL((k_skinny<T, MT, true, 4>), dim3(grid), dim3(64 * waves), lds, s, p);
+			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 4, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL((k_skinny<T, MT, true, 4, W8>), dim3(grid), dim3(64 * waves), lds, s, p);
 		} else {
-			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL((k_skinny<T, MT, true, 8>), dim3(grid), dim3(64 * waves), lds, s, p);
+			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 8, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL((k_skinny<T, MT, true, 8, W8>), dim3(grid), dim3(64 * waves), lds, s, p);
 		}
 	} else {
-		hipLaunchKernelGGL((k_skinny<T, MT, false, 1>), dim3(grid), dim3(64 * waves), red, s, p);
+		hipLaunchKernelGGL((k_skinny<T, MT, false, 1, W8>), dim3(grid), dim3(64 * waves), red, s, p);
 	}
 }
 
-template <typename T>
+template <typename T, bool W8>
 static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s) {
-	if (p.M <= 16) launch_skinny_mt<T, 1>(p, waves, s);
-	else if (p.M <= 32) launch_skinny_mt<T, 2>(p, waves, s);
-	else launch_skinny_mt<T, 4>(p, waves, s);
+	if (p.M <= 16) launch_skinny_mt<T, 1, W8>(p, waves, s);
+	else if (p.M <= 32) launch_skinny_mt<T, 2, W8>(p, waves, s);
+	else launch_skinny_mt<T, 4, W8>(p, waves, s);
 }
 
 void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
@@ -349,9 +367,10 @@ void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
 	if (p.narrow) p.ksplit = 1;
 	if (waves < 4) waves = 4;
 	// algorithmic bytes: the weight matrix once + bias + the M activation rows in and out
-	ProfScope prof(PROF_SKINNY, (double)p.N * p.K * dtype_size(dt) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, s);
-	if (dt == DT_BF16) launch_skinny_t<bf16>(p, waves, s);
-	else launch_skinny_t<float>(p, waves, s);
+	if (dt != DT_BF16) p.w8 = 0;                                // fp8 weights exist for the bf16 arithmetic only
+	ProfScope prof(PROF_SKINNY, (double)p.N * p.K * (p.w8 ? 1 : dtype_size(dt)) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, s);
+	if (dt == DT_BF16) { if (p.w8) launch_skinny_t<bf16, true>(p, waves, s); else launch_skinny_t<bf16, false>(p, waves, s); }
+	else launch_skinny_t<float, false>(p, waves, s);
 }
 
 }  // namespace ttk

@@ -83,7 +83,9 @@ int upload_f32(Arena& ar, const WeightMap& wm, const std::string& name, int64_t 
 // a GEMM operand: T-typed [ntap][Npad][Kpad] (+ optional MFMA-fragment copy) and its f32 bias
 struct Mat {
 	void* w = nullptr;      // [ntap][Npad][Kpad]
-	void* wfrag = nullptr;  // [Npad/16][Kpad/32][64][8], decode path only
+	void* wfrag = nullptr;  // [Npad/16][Kpad/32][64][8], decode path only (one byte per element when w8)
+	bool w8 = false;        // DT_FP8W: weights rounded to fp8-e4m3 * wscale; `w` holds them exactly in bf16, `wfrag` as fp8 bytes
+	float wscale = 1.f;
 	float* bias = nullptr;
 	int N = 0, K = 0, Npad = 0, Kpad = 0, ntap = 1;
 };

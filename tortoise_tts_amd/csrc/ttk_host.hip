@@ -33,18 +33,30 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 	out->N = N; out->K = K; out->ntap = ntap;
 	out->Npad = round_up(N, 128);
 	out->Kpad = round_up(K, 64);
-	const size_t es = dtype_size(dt);
+	const bool w8 = dt == DT_FP8W;
+	const int kdt = kernel_dtype(dt);
+	const size_t es = dtype_size(kdt);
 	float* tmp = nullptr;
 	TTK_HIP(hipMalloc((void**)&tmp, (size_t)numel(v) * sizeof(float)));
 	hipError_t e = hipMemcpy(tmp, v->data, (size_t)numel(v) * sizeof(float), hipMemcpyDefault);
 	if (e != hipSuccess) { (void)hipFree(tmp); set_error("hipMemcpy of '%s' failed: %s", wname.c_str(), hipGetErrorString(e)); return TTK_E_HIP; }
+	if (w8) {   // round the weights to the fp8 grid first: every copy made below then holds the same values
+		float amax = 0.f;
+		if (device_absmax(tmp, numel(v), &amax) != 0) { (void)hipFree(tmp); set_error("absmax of '%s' failed", wname.c_str()); return TTK_E_HIP; }
+		out->w8 = true;
+		out->wscale = fp8_scale_for(amax);
+		launch_fp8_roundtrip(tmp, numel(v), out->wscale, 0);
+	}
 	const size_t wbytes = (size_t)ntap * out->Npad * out->Kpad * es;
 	int rc = ar.alloc(&out->w, wbytes);
 	if (rc == TTK_OK) {
-		launch_pack_nk(dt, tmp, layout, N, K, out->Npad, out->Kpad, out->w, 0);
+		launch_pack_nk(kdt, tmp, layout, N, K, out->Npad, out->Kpad, out->w, 0);
 		if (frag && ntap == 1) {
-			rc = ar.alloc(&out->wfrag, wbytes);
-			if (rc == TTK_OK) launch_pack_frag(dt, out->w, out->Npad, out->Kpad, out->wfrag, 0);
+			rc = ar.alloc(&out->wfrag, w8 ? wbytes / 2 : wbytes);
+			if (rc == TTK_OK) {
+				if (w8) launch_pack_frag_fp8(out->w, out->Npad, out->Kpad, out->wscale, out->wfrag, 0);
+				else launch_pack_frag(kdt, out->w, out->Npad, out->Kpad, out->wfrag, 0);
+			}
 		}
 	}
 	e = hipDeviceSynchronize();
@@ -97,4 +109,17 @@ int ttk_prof_end(ttk_prof_result* out, int n_kinds) {
 }
 int ttk_version(void) { return TTK_VERSION; }
 const char* ttk_last_error(void) { return ttk::get_error(); }
+}
+
+extern "C" int ttk_fp8_round_weights(float* x, int64_t n, float* scale_out, void* stream) {
+	using namespace ttk;
+	TTK_REQUIRE(x && n > 0, TTK_E_ARG, "ttk_fp8_round_weights: null or empty array");
+	TTK_HIP(hipStreamSynchronize((hipStream_t)stream));
+	float amax = 0.f;
+	TTK_REQUIRE(device_absmax(x, n, &amax) == 0, TTK_E_HIP, "ttk_fp8_round_weights: absmax reduction failed");
+	const float s = fp8_scale_for(amax);
+	launch_fp8_roundtrip(x, n, s, (hipStream_t)stream);
+	TTK_HIP(hipGetLastError());
+	if (scale_out) *scale_out = s;
+	return TTK_OK;
 }

@@ -7,8 +7,11 @@
 
 namespace ttk {
 
-enum DType { DT_F32 = 0, DT_BF16 = 1 };
-inline size_t dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+// DT_FP8W (handles only): bf16 activations and arithmetic, GEMM weights rounded to fp8-e4m3 with a power-of-two per-tensor scale; the
+// decode GEMVs stream the weights as fp8 bytes.  Kernels are launched with DT_BF16 plus a per-matrix flag.
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_FP8W = 2 };
+inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+inline int kernel_dtype(int dt) { return dt == DT_FP8W ? DT_BF16 : dt; }
 
 // ---------------------------------------------------------------- per-kernel timing (ttk_host.hip)
 // When enabled (ttk_prof_begin) every launcher brackets its launch with two HIP events on the launch stream and adds its
@@ -81,6 +84,8 @@ struct SkinnyParams {
 	int ksplit; float* slab; int* tickets;
 	// narrow mode (plain A only, excludes ksplit): N/4 workgroups of 4 columns each instead of N/16 of 16 -- for the N = d projections
 	int narrow;
+	// fp8 weights: Wp holds one byte per element in the same fragment order; the accumulated product is multiplied by wscale (a power of two)
+	int w8; float wscale;
 #ifdef TTK_STAMPS
 	unsigned long long* stamps;   // diagnostic build only
 #endif
@@ -157,6 +162,12 @@ void launch_diffusion_step(const float* out_c, const float* out_u, float* x, con
 
 // ---------------------------------------------------------------- packing (pack.hip)
 enum PackLayout { PK_NK = 0, PK_KN = 1, PK_CONV3 = 2 };
+// fp8-e4m3 weights (pack.hip): |x| maximum of a device array; in-place x <- dequant(quant(x / s)) * s; fragment-order fp8 bytes of a
+// bf16 [Npad][K] matrix whose values are already on the fp8 grid times s
+int device_absmax(const float* x, int64_t n, float* out_host);
+void launch_fp8_roundtrip(float* x, int64_t n, float scale, hipStream_t s);
+void launch_pack_frag_fp8(const void* src_bf16, int Npad, int K, float scale, void* dst, hipStream_t s);
+float fp8_scale_for(float absmax);
 // src f32 -> dst T [ntap][Npad][Kpad] (zero padded)
 void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s);
 // T [Npad][K] -> fragment order [Npad/16][K/32][64][8]
