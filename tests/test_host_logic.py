@@ -18,7 +18,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 	_lib.build()
 	lib = ctypes.CDLL(_lib.LIB_PATH)
 	header = open(os.path.join(ROOT, "include", "ttk.h")).read()
-	declared = set(re.findall(r"\b(ttk_[a-z_]+)\s*\(", header))
+	declared = set(re.findall(r"\b(ttk_[a-z0-9_]+)\s*\(", header))
 	assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
 	for name in declared:
 		assert hasattr(lib, name), name
