@@ -13,6 +13,7 @@
 namespace ttk {
 
 constexpr int SAMPLE_THREADS = 1024;
+constexpr int SAMPLE_NPT = 9;          // elements per thread held in registers on the fast path
 
 __device__ __forceinline__ float block_max(float v, float* red, int tid) {
 	v = wave_max(v);
@@ -36,7 +37,8 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 	return s;
 }
 
-// grid = B rows, 1024 threads.  Three passes over the row (32 KB, L2-resident after the first): max, sum of exp, argmax of p / q.
+// grid = B rows, 1024 threads.  max, sum of exp, argmax of p / q over the row; rows up to 9216 wide stay in registers between the
+// three reductions, wider ones are re-read (32 KB, L2-resident after the first pass).
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* scores, int64_t ld, int V, const float* q, int64_t ldq, const unsigned char* suppress, float inv_t,
 		int64_t stop_token, int64_t* unfinished, int64_t* tok, int64_t* ids, int64_t ids_ld, int64_t ids_cols, int64_t* col, int64_t* history,
 		int64_t hist_ld, int64_t hist_off, int* live_rows, int* all_done) {
@@ -48,18 +50,47 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* sco
 	// ATen divides a tensor by a host scalar as `x * (1 / t)` with the reciprocal rounded to f32 (BinaryDivTrueKernel.cu), and that
 	// is what TemperatureLogitsWarper's `scores / temperature` runs on the GPU; inv_t is that reciprocal.
 	const bool scale = inv_t != 1.0f;
-	float m = -INFINITY;
-	for (int i = tid; i < V; i += SAMPLE_THREADS) { float v = (suppress && suppress[i]) ? -INFINITY : s[i]; v = scale ? v * inv_t : v; m = fmaxf(m, v); }
-	m = block_max(m, red, tid);
-	float sum = 0.f;
-	for (int i = tid; i < V; i += SAMPLE_THREADS) { float v = (suppress && suppress[i]) ? -INFINITY : s[i]; v = scale ? v * inv_t : v; sum += expf(v - m); }
-	sum = block_sum(sum, red, tid);
 	float best = -INFINITY;
 	int besti = 0x7fffffff;
-	for (int i = tid; i < V; i += SAMPLE_THREADS) {
-		float v = (suppress && suppress[i]) ? -INFINITY : s[i]; v = scale ? v * inv_t : v;
-		const float r = (expf(v - m) / sum) / qq[i];
-		if (r > best) { best = r; besti = i; }          // strict: the lowest index wins a tie, as in ATen's argmax
+	if (V <= SAMPLE_NPT * SAMPLE_THREADS) {
+		// the row fits in registers (8194 mel codes = 9 per thread): one trip to memory for scores and noise, everything else on chip
+		float v[SAMPLE_NPT], qv[SAMPLE_NPT];
+#pragma unroll
+		for (int j = 0; j < SAMPLE_NPT; ++j) {       // unconditional clamped loads: all 18 requests leave before the first use
+			const int i = tid + j * SAMPLE_THREADS, ic = i < V ? i : V - 1;
+			const float x = s[ic];
+			qv[j] = qq[ic];
+			const bool sup = suppress && suppress[ic];
+			float t = sup ? -INFINITY : x;
+			t = scale ? t * inv_t : t;
+			v[j] = i < V ? t : -INFINITY;
+		}
+		float m = -INFINITY;
+#pragma unroll
+		for (int j = 0; j < SAMPLE_NPT; ++j) m = fmaxf(m, v[j]);
+		m = block_max(m, red, tid);
+		float sum = 0.f;
+#pragma unroll
+		for (int j = 0; j < SAMPLE_NPT; ++j) { v[j] = expf(v[j] - m); sum += v[j]; }      // exp(-inf) = 0 for the padding lanes
+		sum = block_sum(sum, red, tid);
+#pragma unroll
+		for (int j = 0; j < SAMPLE_NPT; ++j) {
+			const int i = tid + j * SAMPLE_THREADS;
+			const float r = (v[j] / sum) / qv[j];
+			if (i < V && r > best) { best = r; besti = i; }          // strict: the lowest index wins a tie, as in ATen's argmax
+		}
+	} else {
+		float m = -INFINITY;
+		for (int i = tid; i < V; i += SAMPLE_THREADS) { float v = (suppress && suppress[i]) ? -INFINITY : s[i]; v = scale ? v * inv_t : v; m = fmaxf(m, v); }
+		m = block_max(m, red, tid);
+		float sum = 0.f;
+		for (int i = tid; i < V; i += SAMPLE_THREADS) { float v = (suppress && suppress[i]) ? -INFINITY : s[i]; v = scale ? v * inv_t : v; sum += expf(v - m); }
+		sum = block_sum(sum, red, tid);
+		for (int i = tid; i < V; i += SAMPLE_THREADS) {
+			float v = (suppress && suppress[i]) ? -INFINITY : s[i]; v = scale ? v * inv_t : v;
+			const float r = (expf(v - m) / sum) / qq[i];
+			if (r > best) { best = r; besti = i; }
+		}
 	}
 	// wave then block reduction of (value, index) with the same tie rule
 #pragma unroll
