@@ -89,7 +89,8 @@ struct ttk_ar {
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
 	int wv_proj = 8, wv_proj2 = 16;   // waves per workgroup of the two plain decode GEMVs (TTK_AR_WV_PROJ / TTK_AR_WV_PROJ2)
-	int narrow = 1;               // c_proj / mlp.c_proj decode GEMVs as 4-column workgroups without split-K (TTK_AR_NARROW=0: 16-column + split-K)
+	int narrow2 = 4;              // same for mlp.c_proj (TTK_AR_NARROW2)
+	int narrow = 4;               // c_proj / mlp.c_proj decode GEMVs as 4-column workgroups without split-K (TTK_AR_NARROW=0: 16-column + split-K)
 	int nsplit = 1;               // row groups decoded concurrently (TTK_AR_SPLIT; measured slower: 283 -> 340 ms at 2, see below)
 	hipStream_t side[3] = {nullptr, nullptr, nullptr};
 	hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -187,8 +188,8 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		p = {};
 		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
-		p.narrow = h->narrow;
-		if (d >= 1024 && !h->narrow) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
+		p.narrow = h->narrow2;
+		if (d >= 1024 && !h->narrow2) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
 			p.ksplit = 4; p.slab = h->slab + (size_t)gi * (d / 16) * 4 * 4 * 256; p.tickets = h->tickets + (size_t)gi * (d / 16);
 		}
 		launch_skinny(dt, p, d >= 1024 ? h->wv_proj2 : 4, s);
@@ -257,11 +258,13 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	if (hipMemset(h->tickets, 0, (size_t)4 * (d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	{
 		const char* en = getenv("TTK_AR_NARROW");
-		h->narrow = en ? (atoi(en) != 0) : 1;
+		h->narrow = en ? atoi(en) : 4;                    // 0 = 16-column workgroups (+ split-K for mlp.c_proj), 2 / 4 = workgroups per tile
+		const char* en2 = getenv("TTK_AR_NARROW2");
+		h->narrow2 = en2 ? atoi(en2) : h->narrow;
 		const char* e1 = getenv("TTK_AR_WV_PROJ");
 		const char* e2 = getenv("TTK_AR_WV_PROJ2");
 		if (e1 && atoi(e1) >= 4 && atoi(e1) <= 16) h->wv_proj = atoi(e1);
-		h->wv_proj2 = h->narrow ? 16 : 8;
+		h->wv_proj2 = h->narrow2 ? 16 : 8;
 		if (e2 && atoi(e2) >= 4 && atoi(e2) <= 16) h->wv_proj2 = atoi(e2);
 		const char* e = getenv("TTK_AR_SPLIT");
 		h->nsplit = e ? atoi(e) : 1;

@@ -64,17 +64,19 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	constexpr int ES = sizeof(T);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-	// Plain mode: ksplit workgroups share one 16-column n-tile.  Narrow mode (p.narrow): FOUR workgroups share an n-tile, each owning 4
-	// of its columns over the whole of K -- 4x the workgroups streaming the matrix without any split-K combine.  The MFMA still runs
+	// Plain mode: ksplit workgroups share one 16-column n-tile.  Narrow mode (p.narrow = 4, or 2): that many workgroups share an n-tile, each
+	// owning 4 (8) of its columns over the whole of K -- 4x (2x) the workgroups streaming the matrix without any split-K combine.  The MFMA still runs
 	// 16 columns wide: lane (g, n) fetches the fragment of column 4*sub + (n & 3), so columns 4..15 of the product are copies that the
 	// epilogue ignores (matrix throughput is irrelevant here, the weight stream is the work).  The four workgroups of a tile read the
 	// same 128-byte lines, so they are given ids that are equal mod 8: round-robin dispatch then puts them on one XCD and its L2
 	// fetches every line once.
 	int nt, kslice = 0, sub = 0;
+	const int G = p.narrow > 1 ? p.narrow : 1;          // workgroups per 16-column tile (narrow mode: 2 or 4), 16 / G columns each
+	const int NC = 16 / G;
 	if (p.narrow) {
 		const int b = blockIdx.x, ntiles = (p.N + 15) / 16;
-		if ((ntiles & 7) == 0) { nt = (b >> 5) * 8 + (b & 7); sub = (b >> 3) & 3; }
-		else { nt = b >> 2; sub = b & 3; }
+		if ((ntiles & 7) == 0) { nt = (b / (8 * G)) * 8 + (b & 7); sub = (b >> 3) % G; }
+		else { nt = b / G; sub = b % G; }
 	} else {
 		nt = blockIdx.x / p.ksplit; kslice = blockIdx.x - nt * p.ksplit;
 	}
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	// bias and, for the residual modes, the current value of the output are requested now, ahead of everything else, so the epilogue
 	// finds them in registers instead of paying one more dependent L2 round trip after the reduction.
 	const int l2 = tid & 63, r = tid >> 6;
-	const int n = p.narrow ? nt * 16 + 4 * sub + (l2 & 3) : nt * 16 + (l2 & 15);
-	const bool mine = tid < 256 && (!p.narrow || (l2 & 15) < 4) && n < p.N;
+	const int n = p.narrow ? nt * 16 + NC * sub + (l2 & (NC - 1)) : nt * 16 + (l2 & 15);
+	const bool mine = tid < 256 && (!p.narrow || (l2 & 15) < NC) && n < p.N;
 	float bias = 0.f, res[MT];
 	{
 		const int nn = n < p.N ? n : p.N - 1;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	// ---- this wave's K slice of the weights; the first PRE fragments are requested now
 	const int kw0 = (KS * kslice) / p.ksplit, kw1 = (KS * (kslice + 1)) / p.ksplit;   // this workgroup's k-steps
 	const int ks0 = kw0 + ((kw1 - kw0) * wave) / nw, ks1 = kw0 + ((kw1 - kw0) * (wave + 1)) / nw;
-	const WRaw* wp = (const WRaw*)p.Wp + ((int64_t)nt * KS) * 64 + (p.narrow ? ((lane & ~15) | (4 * sub + (lane & 3))) : lane);
+	const WRaw* wp = (const WRaw*)p.Wp + ((int64_t)nt * KS) * 64 + (p.narrow ? ((lane & ~15) | (NC * sub + (lane & (NC - 1)))) : lane);
 	constexpr int PRE = 8;   // 8 x 1 KiB (bf16) in flight per wave
 	WRaw bpre[PRE];
 	const int npre = min(ks1 - ks0, PRE);
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 
 template <typename T, int MT, bool W8>
 static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
-	const int grid = p.narrow ? ((p.N + 15) / 16) * 4 : ((p.N + 15) / 16) * p.ksplit;
+	const int grid = p.narrow ? ((p.N + 15) / 16) * p.narrow : ((p.N + 15) / 16) * p.ksplit;
 	const size_t red = (size_t)waves * MT * 64 * 4 * sizeof(float);
 	if (p.ln_count > 0) {
 		if (waves > 8) waves = 8;
@@ -364,7 +366,7 @@ void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
 	SkinnyParams p = p_in;
 	if (p.ksplit < 1 || !p.slab || !p.tickets) p.ksplit = 1;
 	if (p.ln_count > 0 || p.mode == SK_QKV) p.narrow = 0;      // every workgroup of an LN kernel normalises all rows: more of them only adds work
-	if (p.narrow) p.ksplit = 1;
+	if (p.narrow) { p.ksplit = 1; p.narrow = p.narrow == 2 ? 2 : 4; }
 	if (waves < 4) waves = 4;
 	// algorithmic bytes: the weight matrix once + bias + the M activation rows in and out
 	if (dt != DT_BF16) p.w8 = 0;                                // fp8 weights exist for the bf16 arithmetic only
