@@ -195,6 +195,43 @@ def wrapper_case(uv_mod):
 	return out
 
 
+def vocoder_case(cfg, seed, T):
+	"""The reference BigVGAN generator (models/bigvgan.py) on synthetic weights: the anti-aliasing filter it builds, the weight-normed
+	state_dict key names, one AMP block, `forward` internals and `inference` (waveform)."""
+	import importlib
+	bv = importlib.import_module("tortoise_tts.models.bigvgan")
+	sd = W.synth_state_dict(W.vocoder_shapes(cfg), seed)
+	m = bv.BigVGAN(data=cfg.as_json())
+	out = dict(seed=np.int64(seed), wn_keys=np.array(sorted(k for k in m.state_dict().keys() if "filter" not in k)),
+			   filter_up=m.activation_post.upsample.filter.reshape(-1).numpy().copy(),
+			   filter_down=m.activation_post.downsample.lowpass.filter.reshape(-1).numpy().copy())
+	# a weight-normed tensor pair for the ingest test (g, v and the weight they produce), before the norm is removed
+	with torch.no_grad():
+		m.conv_pre.weight_g.copy_(torch.rand_like(m.conv_pre.weight_g, generator=None) + 0.5)
+		m.ups[0][0].weight_g.copy_(torch.rand_like(m.ups[0][0].weight_g) + 0.5)
+	out["wn_conv_pre_g"], out["wn_conv_pre_v"] = m.conv_pre.weight_g.detach().numpy().copy(), m.conv_pre.weight_v.detach().numpy().copy()
+	out["wn_conv_pre_w"] = m.conv_pre.weight.detach().numpy().copy() if hasattr(m.conv_pre, "weight") else None
+	out["wn_ups0_g"], out["wn_ups0_v"] = m.ups[0][0].weight_g.detach().numpy().copy(), m.ups[0][0].weight_v.detach().numpy().copy()
+	m.remove_weight_norm()
+	out["wn_conv_pre_w"] = m.conv_pre.weight.detach().numpy().copy()
+	out["wn_ups0_w"] = m.ups[0][0].weight.detach().numpy().copy()
+	missing, unexpected = m.load_state_dict(sd, strict=False)
+	assert not unexpected and all("filter" in k for k in missing), (missing, unexpected)
+	m.eval()
+	mel = torch.randn(2, cfg.num_mels, T, generator=gen(seed + 1)) * 2.0 - 5.0
+	out["mel"] = mel.numpy()
+	with torch.inference_mode():
+		x = m.conv_pre(mel)
+		out["conv_pre"] = x.numpy().copy()
+		x = m.ups[0][0](x)
+		out["ups0"] = x.numpy().copy()
+		out["act0"] = m.resblocks[0].activations[0](x).numpy().copy()
+		out["amp0"] = m.resblocks[0](x).numpy().copy()
+		out["forward"] = m.forward(mel, None).numpy().copy()
+		out["audio"] = m.inference(mel).numpy().copy()
+	return out
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -208,6 +245,7 @@ def main():
 		("lora_small", lambda: lora_case(uv_mod, W.AR_SMALL, 13, rank=4, alpha=8)),
 		("hf_sample_loop", hf_sample_loop_case),
 		("wrapper", lambda: wrapper_case(uv_mod)),
+		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
 	]
 	only = set(sys.argv[1:])
 	for name, fn in jobs:

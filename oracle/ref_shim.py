@@ -14,6 +14,7 @@ touch at import time are stubbed:
   tortoise_tts/models/xtransformers.py  (RelativePositionBias)
   tortoise_tts/models/unified_voice.py  (UnifiedVoice, GPT2InferenceModel)
   tortoise_tts/models/stream_generator.py
+  tortoise_tts/models/lora.py, tortoise_tts/models/bigvgan.py   (imported on demand by make_golden.py)
 
 No reference source is copied: the modules are executed where they lie.
 """
@@ -42,9 +43,11 @@ def load():
 	from transformers import GPT2Config, GPT2Model  # noqa: F401  (resolve lazies before stubbing)
 	import transformers.generation.utils as gu
 
-	for name in ("torchaudio", "torchaudio.transforms", "librosa", "librosa.filters"):
+	for name in ("torchaudio", "torchaudio.transforms", "librosa"):
 		if name not in sys.modules:
 			_stub(name)
+	if "librosa.filters" not in sys.modules:
+		_stub("librosa.filters", mel=None)        # models/bigvgan.py:14 imports the name; only its training-side mel_spectrogram() calls it
 	if "librosa.util" not in sys.modules:
 		_stub("librosa.util", pad_center=None, tiny=None)
 	if "transformers.utils.model_parallel_utils" not in sys.modules:

@@ -62,7 +62,44 @@ class DiffusionConfig:
 		return self.model_channels // self.num_heads
 
 
+@dataclasses.dataclass(frozen=True)
+class VocoderConfig:
+	"""BigVGAN generator hyper-parameters (`BigVGAN.__init__`, models/bigvgan.py:419-486, reads them from a JSON that the reference
+	downloads, models/__init__.py:129-137).  The JSON is not available offline: these are the published `bigvgan_24khz_100band`
+	values entered by hand -- an ASSUMPTION; their product of upsample rates (256) matches the hop the
+	reference's mel length formula implies (inference.py:400)."""
+	num_mels: int = 100
+	upsample_rates: Tuple[int, ...] = (4, 4, 2, 2, 2, 2)
+	upsample_kernel_sizes: Tuple[int, ...] = (8, 8, 4, 4, 4, 4)
+	upsample_initial_channel: int = 1536
+	resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+	resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+	snake_logscale: bool = True
+	sampling_rate: int = 24000
+
+	@property
+	def hop_size(self):
+		h = 1
+		for u in self.upsample_rates:
+			h *= u
+		return h
+
+	def stage_channels(self, i):   # channels after upsampler i
+		return self.upsample_initial_channel // (2 ** (i + 1))
+
+	def as_json(self):
+		"""the dict `BigVGAN(data=...)` takes (only the generator's keys)"""
+		return dict(resblock="1", num_mels=self.num_mels, upsample_rates=list(self.upsample_rates),
+					upsample_kernel_sizes=list(self.upsample_kernel_sizes), upsample_initial_channel=self.upsample_initial_channel,
+					resblock_kernel_sizes=list(self.resblock_kernel_sizes), resblock_dilation_sizes=[list(d) for d in self.resblock_dilation_sizes],
+					activation="snakebeta", snake_logscale=self.snake_logscale, n_fft=1024, hop_size=self.hop_size,
+					sampling_rate=self.sampling_rate)
+
+
 AR_SMALL = ARConfig(layers=2, model_dim=128, heads=2)
+VOC_SMALL = VocoderConfig(upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4), upsample_initial_channel=128,
+						  resblock_kernel_sizes=(3, 7), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5)))
+VOC_FULL = VocoderConfig()
 AR_FULL = ARConfig()
 DIFF_SMALL = DiffusionConfig(model_channels=128, num_layers=2, in_latent_channels=128, num_heads=2)
 DIFF_FULL = DiffusionConfig()
@@ -141,12 +178,41 @@ def diffusion_shapes(c: DiffusionConfig) -> Dict[str, Tuple[int, ...]]:
 	return s
 
 
+def vocoder_shapes(c: VocoderConfig) -> Dict[str, Tuple[int, ...]]:
+	"""`BigVGAN.state_dict()` with weight norm folded (plain `weight` instead of `weight_g` / `weight_v`) and without the constant
+	anti-aliasing filter buffers (identical for every Activation1d; recomputed, `vocoder.aa_filter`)."""
+	ch0 = c.upsample_initial_channel
+	s: Dict[str, Tuple[int, ...]] = {"conv_pre.weight": (ch0, c.num_mels, 7), "conv_pre.bias": (ch0,)}
+	nk = len(c.resblock_kernel_sizes)
+	ch = ch0
+	for i, (u, k) in enumerate(zip(c.upsample_rates, c.upsample_kernel_sizes)):
+		cin, ch = ch0 // (2 ** i), ch0 // (2 ** (i + 1))
+		s[f"ups.{i}.0.weight"] = (cin, ch, k)                 # ConvTranspose1d: [in, out, k]
+		s[f"ups.{i}.0.bias"] = (ch,)
+		for j, kk in enumerate(c.resblock_kernel_sizes):
+			p = f"resblocks.{i * nk + j}."
+			for m in range(3):
+				s[p + f"convs1.{m}.weight"] = (ch, ch, kk); s[p + f"convs1.{m}.bias"] = (ch,)
+				s[p + f"convs2.{m}.weight"] = (ch, ch, kk); s[p + f"convs2.{m}.bias"] = (ch,)
+			for m in range(6):
+				s[p + f"activations.{m}.act.alpha"] = (ch,); s[p + f"activations.{m}.act.beta"] = (ch,)
+	s["activation_post.act.alpha"] = (ch,); s["activation_post.act.beta"] = (ch,)
+	s["conv_post.weight"] = (1, ch, 7); s["conv_post.bias"] = (1,)
+	return s
+
+
 def _gain_for(name: str, shape: Tuple[int, ...]) -> Tuple[str, float]:
 	"""(kind, std) of the synthetic draw for a key.  Chosen so that every op on the path is exercised
 	with O(1) activations: norm scales near 1, matrices fan-in scaled, residual-branch outputs damped.
 	The reference zero-initialises `proj_out` (models/arch_utils.py:172); a zero matrix would leave
 	the attention untested, so it is drawn like every other matrix."""
 	leaf = name.rsplit(".", 1)[-1]
+	if leaf in ("alpha", "beta"):     # snake parameters, log scale: exp(.) stays within ~[0.5, 2]
+		return "normal", 0.3
+	if name.startswith("ups.") and leaf == "weight":   # ConvTranspose1d [in, out, k]: each output sample sees in * k / stride taps
+		return "normal", 1.0 / (shape[0] * 2) ** 0.5
+	if ".convs2." in name and leaf == "weight":
+		return "normal", 0.5 / (shape[1] * shape[2]) ** 0.5
 	if name == "unconditioned_embedding":
 		return "normal", 1.0
 	if "relative_attention_bias" in name:
