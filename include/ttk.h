@@ -149,6 +149,28 @@ int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise,
 /* Whole DDIM loop: steps[n-1], ..., steps[0] applied in that order (ddim_sample_loop_progressive :794-810). */
 int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream);
 
+/* ------------------------------------------------------------------ BigVGAN vocoder
+ * The generator of models/bigvgan.py (BigVGAN.__init__ :419-486) on the hot path's kernels.  Weights: the generator's state_dict
+ * with weight norm folded into plain `weight` tensors (tortoise_tts_amd/vocoder.py does that), plus "__aa_filter" [12], the Kaiser
+ * low-pass every Activation1d builds (kaiser_sinc_filter1d(0.25, 0.3, 12), :40-69).                                        */
+typedef struct ttk_voc ttk_voc;
+typedef struct {
+	int num_mels;                             /* 100 */
+	int n_ups;                                /* <= 8 */
+	int up_rate[8], up_kernel[8];             /* kernel % rate == 0, (kernel - rate) even */
+	int ch0;                                  /* upsample_initial_channel; halves per stage, every stage a multiple of 8 */
+	int n_kernels;                            /* AMP blocks per stage, 2..4 */
+	int rb_kernel[4];                         /* odd, <= 11 */
+	int rb_dil[4][3];
+	int snake_logscale;
+	int dtype;                                /* TTK_F32 | TTK_BF16 */
+} ttk_voc_config;
+int ttk_voc_create(ttk_voc** out, const ttk_voc_config* cfg, const ttk_weight_view* weights, int n_weights);
+int ttk_voc_destroy(ttk_voc* h);
+/* BigVGAN.inference(c) :522-534: mel [B, num_mels, T] f32 (denormalised log-mel) -> audio [B, 1, T * hop] f32 in [-1, 1]; the 10
+ * padding frames of -11.5129 and the trimming of their 10 hops happen inside.                                             */
+int ttk_voc_inference(ttk_voc* h, const float* mel, int B, int T, float* audio, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,6 +251,19 @@ def load_diffusion(path, *, dtype="bf16", device="cuda", **kw):
 	return DiffusionTTS(sd, cfg, dtype=dtype, device=device)
 
 
+def load_bigvgan(path, *, cfg=None, dtype="bf16", device="cuda", state_dict_key: Optional[str] = "generator"):
+	"""`load_model("bigvgan")` (models/__init__.py:128-140): the generator's tensors sit under 'generator' in the upstream file; weight norm
+	is folded and the config defaults to the published bigvgan_24khz_100band values (weights.VocoderConfig: an assumption, the JSON is a
+	download)."""
+	from .vocoder import BigVGAN
+	from .weights import VocoderConfig
+	obj = read_checkpoint(path)
+	if state_dict_key is not None and not (isinstance(obj, Mapping) and state_dict_key in obj):
+		state_dict_key = None                      # a bare generator state_dict
+	sd = unwrap_state_dict(obj, state_dict_key)
+	return BigVGAN(sd, cfg or VocoderConfig(), dtype=dtype, device=device)
+
+
 def save_state_dict(state_dict: Mapping[str, torch.Tensor], path, metadata: Optional[Mapping[str, object]] = None):
 	"""`torch_save` (utils/io.py:92-104) for a plain tensor dict: safetensors (metadata JSON-encoded) or `.pth` by extension."""
 	path = os.fspath(path)

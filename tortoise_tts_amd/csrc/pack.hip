@@ -12,10 +12,11 @@ namespace ttk {
 //   PK_NK    src[n][k]          nn.Linear [out,in], nn.Conv1d k=1 [out,in,1]
 //   PK_KN    src[k][n]          HF Conv1D [in,out]   (HF:pytorch_utils.py:95-120)
 //   PK_CONV3 src[n][k][3]       nn.Conv1d k=3 [out,in,3] -> 3 tap matrices, tap 0 multiplies row t-1
+//   PK_CONVK src[n][k][ntap]    nn.Conv1d of any odd kernel size
+//   PK_CONVT src[k][n][ntap]    nn.ConvTranspose1d [in,out,taps]
 template <typename T>
-__global__ void k_pack_nk(const float* src, int layout, int N, int K, int Npad, int Kpad, T* dst) {
+__global__ void k_pack_nk(const float* src, int layout, int N, int K, int Npad, int Kpad, int ntap, T* dst) {
 	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	const int ntap = layout == PK_CONV3 ? 3 : 1;
 	const int64_t per = (int64_t)Npad * Kpad;
 	if (idx >= ntap * per) return;
 	const int tap = (int)(idx / per);
@@ -25,15 +26,17 @@ __global__ void k_pack_nk(const float* src, int layout, int N, int K, int Npad, 
 	if (n < N && k < K) {
 		if (layout == PK_NK) v = src[(int64_t)n * K + k];
 		else if (layout == PK_KN) v = src[(int64_t)k * N + n];
-		else v = src[((int64_t)n * K + k) * 3 + tap];
+		else if (layout == PK_CONVT) v = src[((int64_t)k * N + n) * ntap + tap];       // ConvTranspose1d [in][out][taps]
+		else v = src[((int64_t)n * K + k) * ntap + tap];                               // Conv1d [out][in][taps]
 	}
 	dst[idx] = cvt<T>(v);
 }
-void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s) {
-	const int64_t total = (int64_t)(layout == PK_CONV3 ? 3 : 1) * Npad * Kpad;
+void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s, int ntap) {
+	if (ntap <= 0) ntap = layout == PK_CONV3 ? 3 : 1;
+	const int64_t total = (int64_t)ntap * Npad * Kpad;
 	const unsigned grid = (unsigned)((total + 255) / 256);
-	if (dt == DT_BF16) hipLaunchKernelGGL((k_pack_nk<bf16>), dim3(grid), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, (bf16*)dst);
-	else hipLaunchKernelGGL((k_pack_nk<float>), dim3(grid), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, (float*)dst);
+	if (dt == DT_BF16) hipLaunchKernelGGL((k_pack_nk<bf16>), dim3(grid), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, ntap, (bf16*)dst);
+	else hipLaunchKernelGGL((k_pack_nk<float>), dim3(grid), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, ntap, (float*)dst);
 }
 
 // [Npad][K] -> Wp[n_tile][k_step][lane][8]: lane l holds W[16nt + (l&15)][32ks + 8(l>>4) + j]

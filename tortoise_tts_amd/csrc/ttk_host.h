@@ -91,7 +91,7 @@ struct Mat {
 };
 // layout: PK_NK / PK_KN / PK_CONV3 ; N, K are the logical sizes checked against the tensor
 int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, int layout,
-			   int N, int K, bool frag, Mat* out);
+			   int N, int K, bool frag, Mat* out, int ntap = 0);   // ntap: kernel size for PK_CONVK / PK_CONVT
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

@@ -24,10 +24,10 @@ int upload_f32(Arena& ar, const WeightMap& wm, const std::string& name, int64_t 
 }
 
 int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, int layout,
-			   int N, int K, bool frag, Mat* out) {
+			   int N, int K, bool frag, Mat* out, int ntap_in) {
 	const ttk_weight_view* v = wm.find(wname);
 	TTK_REQUIRE(v != nullptr, TTK_E_WEIGHT, "missing weight '%s'", wname.c_str());
-	const int ntap = layout == PK_CONV3 ? 3 : 1;
+	const int ntap = ntap_in > 0 ? ntap_in : (layout == PK_CONV3 ? 3 : 1);
 	TTK_REQUIRE(numel(v) == (int64_t)N * K * ntap, TTK_E_WEIGHT, "weight '%s' has %lld elements, expected %lld", wname.c_str(),
 				(long long)numel(v), (long long)N * K * ntap);
 	out->N = N; out->K = K; out->ntap = ntap;
@@ -50,7 +50,7 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 	const size_t wbytes = (size_t)ntap * out->Npad * out->Kpad * es;
 	int rc = ar.alloc(&out->w, wbytes);
 	if (rc == TTK_OK) {
-		launch_pack_nk(kdt, tmp, layout, N, K, out->Npad, out->Kpad, out->w, 0);
+		launch_pack_nk(kdt, tmp, layout, N, K, out->Npad, out->Kpad, out->w, 0, ntap);
 		if (frag && ntap == 1) {
 			rc = ar.alloc(&out->wfrag, w8 ? wbytes / 2 : wbytes);
 			if (rc == TTK_OK) {

@@ -30,8 +30,9 @@ struct ProfScope {
 
 // ---------------------------------------------------------------- dense GEMM (gemm.hip)
 // C[M,N] = epilogue( sum_seg  shift(A_seg)[M,K] * W_seg[N,K]^T )      ("NT": both operands K-contiguous)
-// Segments express (a) the 3 taps of a k=3 'same' convolution over rows (row shift -1,0,+1 inside each
-// batch element of `rows_per_batch` rows, zero outside) and (b) channel concatenation (two A sources).
+// Segments express (a) the taps of a 'same' convolution over rows (row shift (tap - (k-1)/2) * dilation inside each batch element
+// of `rows_per_batch` rows, zero outside), (b) channel concatenation (two A sources) and (c) the taps one output phase of a
+// transposed convolution sees (output rows interleaved through ldc).
 struct GemmSeg {
 	const void* A;      // T [M][lda]
 	int64_t lda;
@@ -39,7 +40,7 @@ struct GemmSeg {
 	int64_t w_off;      // element offset of this segment's [Npad][K] matrix inside W
 };
 struct GemmParams {
-	GemmSeg seg[3];
+	GemmSeg seg[12];    // up to 11 taps of a dilated convolution (BigVGAN AMP blocks), 3 for the diffusion convs, 2 for a concat
 	int nseg;
 	const void* W;      // T, each segment matrix [Npad][ldw] row-major (first K columns used), Npad % 128 == 0
 	int64_t ldw;
@@ -161,7 +162,7 @@ void launch_diffusion_step(const float* out_c, const float* out_u, float* x, con
 						   StepCoefs c, hipStream_t s);
 
 // ---------------------------------------------------------------- packing (pack.hip)
-enum PackLayout { PK_NK = 0, PK_KN = 1, PK_CONV3 = 2 };
+enum PackLayout { PK_NK = 0, PK_KN = 1, PK_CONV3 = 2, PK_CONVK = 3, PK_CONVT = 4 };   // CONVK: src[n][k][ntap]; CONVT: src[k][n][ntap]
 // fp8-e4m3 weights (pack.hip): |x| maximum of a device array; in-place x <- dequant(quant(x / s)) * s; fragment-order fp8 bytes of a
 // bf16 [Npad][K] matrix whose values are already on the fp8 grid times s
 int device_absmax(const float* x, int64_t n, float* out_host);
@@ -169,7 +170,7 @@ void launch_fp8_roundtrip(float* x, int64_t n, float scale, hipStream_t s);
 void launch_pack_frag_fp8(const void* src_bf16, int Npad, int K, float scale, void* dst, hipStream_t s);
 float fp8_scale_for(float absmax);
 // src f32 -> dst T [ntap][Npad][Kpad] (zero padded)
-void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s);
+void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s, int ntap = 0);
 // T [Npad][K] -> fragment order [Npad/16][K/32][64][8]
 void launch_pack_frag(int dt, const void* src, int Npad, int K, void* dst, hipStream_t s);
 
