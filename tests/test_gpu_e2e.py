@@ -85,3 +85,23 @@ def test_pipelined_lines_equal_sequential_calls(small):
 	assert len(pipe) == len(seq)
 	for (m0, s0), (m1, s1, _codes) in zip(seq, pipe):
 		assert s0 == s1 and torch.equal(m0, m1)           # same kernels, same inputs, same RNG draws => identical bits
+
+
+def test_tokens_to_waveform_with_the_vocoder(small):
+	"""text tokens + latents -> mel (hot path) -> waveform (BigVGAN on libttk), against the same chain through the two oracles"""
+	import bigvgan_oracle as BO
+	from tortoise_tts_amd.inference import TTSHotPath
+	from tortoise_tts_amd.vocoder import BigVGAN
+	tts, aro, dor = small
+	vsd = W.synth_state_dict(W.vocoder_shapes(W.VOC_SMALL), 33)
+	full = TTSHotPath(tts.autoregressive, tts.diffusion, BigVGAN(vsd, W.VOC_SMALL, dtype="f32", device=DEV))
+	text, al, dl = _inputs(400, 6)
+	kw = dict(max_ar_steps=12, max_diffusion_steps=3, candidates=2, suppress_tokens=[W.AR_SMALL.stop_mel_token])
+	with torch.inference_mode():
+		wav, sr = full.inference_to_wav(text, al.to(DEV), dl.to(DEV), **kw)
+		mels, _ = full.inference(text, al.to(DEV), dl.to(DEV), **kw)
+		ref = BO.BigVGANOracle(vsd, W.VOC_SMALL).inference(mels.cpu())
+	T = O.mel_frames_for(12)
+	assert sr == 24000 and wav.shape == (1, 1, T * W.VOC_SMALL.hop_size) and (wav.cpu() - ref).abs().max() < 1e-4
+	with pytest.raises(ValueError):
+		tts.inference_to_wav(text, al.to(DEV), dl.to(DEV), **kw)

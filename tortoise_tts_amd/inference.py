@@ -46,8 +46,16 @@ def trim_calm_tokens(codes: torch.Tensor, latents: torch.Tensor) -> torch.Tensor
 
 
 class TTSHotPath:
-	def __init__(self, autoregressive: UnifiedVoice, diffusion: DiffusionTTS):
-		self.autoregressive, self.diffusion = autoregressive, diffusion
+	def __init__(self, autoregressive: UnifiedVoice, diffusion: DiffusionTTS, vocoder=None):
+		self.autoregressive, self.diffusion, self.vocoder = autoregressive, diffusion, vocoder
+
+	@torch.inference_mode()
+	def inference_to_wav(self, text_tokens, autoregressive_latents, diffusion_latents, **kw):
+		"""`inference` followed by the vocoder pass of inference.py:415-425 (`vocoder.inference(mels)`): returns (wav [1, 1, T * hop], 24000)."""
+		if self.vocoder is None:
+			raise ValueError("TTSHotPath was built without a vocoder (tortoise_tts_amd.BigVGAN)")
+		mels, _ = self.inference(text_tokens, autoregressive_latents, diffusion_latents, **kw)
+		return self.vocoder.inference(mels), SAMPLE_RATE
 
 	@torch.inference_mode()
 	def inference(self, text_tokens: torch.Tensor, autoregressive_latents: torch.Tensor, diffusion_latents: torch.Tensor, *,
