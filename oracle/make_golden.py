@@ -232,6 +232,27 @@ def vocoder_case(cfg, seed, T):
 	return out
 
 
+def clvp_case(cfg, seed):
+	"""The reference CLVP (x-transformers branch) on synthetic weights: state_dict key names, one encoder's latent, the scores."""
+	import importlib
+	cl = importlib.import_module("tortoise_tts.models.clvp")
+	sd = W.synth_state_dict(W.clvp_shapes(cfg), seed)
+	m = cl.CLVP(dim_text=cfg.dim, dim_speech=cfg.dim, dim_latent=cfg.dim, num_text_tokens=cfg.num_text_tokens, text_enc_depth=cfg.depth,
+				text_heads=cfg.heads, num_speech_tokens=cfg.num_speech_tokens, speech_enc_depth=cfg.depth, speech_heads=cfg.heads, use_xformers=True)
+	missing, unexpected = m.load_state_dict(sd, strict=False)
+	assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+	m.eval()
+	B, Tt, M = 5, 9, 23
+	text = torch.randint(1, cfg.num_text_tokens, (1, Tt), generator=gen(seed + 1))
+	codes = torch.randint(0, cfg.num_speech_tokens, (B, M), generator=gen(seed + 2))
+	out = dict(seed=np.int64(seed), keys=np.array(sorted(k for k in m.state_dict().keys() if "inv_freq" not in k)), text=text.numpy(), codes=codes.numpy())
+	with torch.inference_mode():
+		out["scores"] = m(text.repeat(B, 1), codes, return_loss=False).numpy()
+		enc = m.speech_transformer(m.speech_emb(codes), mask=torch.ones_like(codes).bool())
+		out["speech_enc"] = enc.numpy()
+	return out
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -246,6 +267,7 @@ def main():
 		("hf_sample_loop", hf_sample_loop_case),
 		("wrapper", lambda: wrapper_case(uv_mod)),
 		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
+		("clvp_small", lambda: clvp_case(W.CLVP_SMALL, 61)),
 	]
 	only = set(sys.argv[1:])
 	for name, fn in jobs:

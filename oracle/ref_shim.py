@@ -14,7 +14,7 @@ touch at import time are stubbed:
   tortoise_tts/models/xtransformers.py  (RelativePositionBias)
   tortoise_tts/models/unified_voice.py  (UnifiedVoice, GPT2InferenceModel)
   tortoise_tts/models/stream_generator.py
-  tortoise_tts/models/lora.py, tortoise_tts/models/bigvgan.py   (imported on demand by make_golden.py)
+  tortoise_tts/models/lora.py, bigvgan.py, clvp.py              (imported on demand by make_golden.py)
 
 No reference source is copied: the modules are executed where they lie.
 """
@@ -46,6 +46,8 @@ def load():
 	for name in ("torchaudio", "torchaudio.transforms", "librosa"):
 		if name not in sys.modules:
 			_stub(name)
+	if "rotary_embedding_torch" not in sys.modules:   # models/transformer.py:10 (the non-x-transformers CLVP branch, never instantiated here)
+		_stub("rotary_embedding_torch", RotaryEmbedding=None, broadcat=None)
 	if "librosa.filters" not in sys.modules:
 		_stub("librosa.filters", mel=None)        # models/bigvgan.py:14 imports the name; only its training-side mel_spectrogram() calls it
 	if "librosa.util" not in sys.modules:

@@ -96,7 +96,24 @@ class VocoderConfig:
 					sampling_rate=self.sampling_rate)
 
 
+@dataclasses.dataclass(frozen=True)
+class CLVPConfig:
+	"""`CLVP.__init__` defaults, models/clvp.py:29-46 (the x-transformers branch, `use_xformers=True`)."""
+	dim: int = 768                      # dim_text = dim_speech = dim_latent
+	num_text_tokens: int = 256
+	num_speech_tokens: int = 8192
+	depth: int = 20                     # text_enc_depth = speech_enc_depth
+	heads: int = 12                     # head width is x-transformers' DEFAULT_DIM_HEAD = 64
+	ff_mult: int = 2
+
+	@property
+	def inner(self):
+		return self.dim * self.ff_mult
+
+
 AR_SMALL = ARConfig(layers=2, model_dim=128, heads=2)
+CLVP_SMALL = CLVPConfig(dim=128, depth=2, heads=2)
+CLVP_FULL = CLVPConfig()
 VOC_SMALL = VocoderConfig(upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4), upsample_initial_channel=128,
 						  resblock_kernel_sizes=(3, 7), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5)))
 VOC_FULL = VocoderConfig()
@@ -201,12 +218,37 @@ def vocoder_shapes(c: VocoderConfig) -> Dict[str, Tuple[int, ...]]:
 	return s
 
 
+def clvp_shapes(c: CLVPConfig) -> Dict[str, Tuple[int, ...]]:
+	"""`CLVP.state_dict()` without the constant rotary `inv_freq` buffers.  Layer 2i is attention, 2i+1 feed-forward; index `.0.0` is the
+	pre-branch RMSNorm, `.1.wrap` the block inside arch_utils.CheckpointedLayer."""
+	d, qk = c.dim, c.heads * 64
+	s: Dict[str, Tuple[int, ...]] = {"temperature": (), "text_emb.weight": (c.num_text_tokens, d), "speech_emb.weight": (c.num_speech_tokens, d),
+									 "to_text_latent.weight": (d, d), "to_speech_latent.weight": (d, d)}
+	for enc in ("text_transformer", "speech_transformer"):
+		p = enc + ".transformer."
+		for i in range(c.depth):
+			a, f = p + f"attn_layers.layers.{2 * i}.", p + f"attn_layers.layers.{2 * i + 1}."
+			s[a + "0.0.g"] = (d,)
+			for w in ("to_q", "to_k", "to_v"):
+				s[a + f"1.wrap.{w}.weight"] = (qk, d)
+			s[a + "1.wrap.to_out.weight"] = (d, qk); s[a + "1.wrap.to_out.bias"] = (d,)
+			s[f + "0.0.g"] = (d,)
+			s[f + "1.wrap.net.0.proj.weight"] = (2 * c.inner, d); s[f + "1.wrap.net.0.proj.bias"] = (2 * c.inner,)
+			s[f + "1.wrap.net.3.weight"] = (d, c.inner); s[f + "1.wrap.net.3.bias"] = (d,)
+		s[p + "norm.weight"] = (d,); s[p + "norm.bias"] = (d,)
+	return s
+
+
 def _gain_for(name: str, shape: Tuple[int, ...]) -> Tuple[str, float]:
 	"""(kind, std) of the synthetic draw for a key.  Chosen so that every op on the path is exercised
 	with O(1) activations: norm scales near 1, matrices fan-in scaled, residual-branch outputs damped.
 	The reference zero-initialises `proj_out` (models/arch_utils.py:172); a zero matrix would leave
 	the attention untested, so it is drawn like every other matrix."""
 	leaf = name.rsplit(".", 1)[-1]
+	if name == "temperature":
+		return "normal", 0.3
+	if leaf == "g":                     # RMSNorm gain
+		return "norm_scale", 0.1
 	if leaf in ("alpha", "beta"):     # snake parameters, log scale: exp(.) stays within ~[0.5, 2]
 		return "normal", 0.3
 	if name.startswith("ups.") and leaf == "weight":   # ConvTranspose1d [in, out, k]: each output sample sees in * k / stride taps
