@@ -171,6 +171,24 @@ int ttk_voc_destroy(ttk_voc* h);
  * padding frames of -11.5129 and the trimming of their 10 hops happen inside.                                             */
 int ttk_voc_inference(ttk_voc* h, const float* mel, int B, int T, float* audio, void* stream);
 
+/* ------------------------------------------------------------------ CLVP candidate scoring
+ * models/clvp.py:21-136 (x-transformers branch): weights = CLVP.state_dict() with each attention's to_q / to_k / to_v stacked into
+ * "<attn>.__qkv.weight" [3 * dim, dim] and "__rotary_inv_freq" [16] (RotaryEmbedding(32).inv_freq), as tortoise_tts_amd/clvp.py packs. */
+typedef struct ttk_clvp ttk_clvp;
+typedef struct {
+	int dim;                                  /* 768; heads * 64 == dim */
+	int heads;                                /* 12 */
+	int depth;                                /* 20 attention + 20 feed-forward layers per encoder */
+	int inner;                                /* dim * ff_mult = 1536 */
+	int num_text_tokens, num_speech_tokens;   /* 256, 8192 */
+	int dtype;                                /* TTK_F32 | TTK_BF16 */
+} ttk_clvp_config;
+int ttk_clvp_create(ttk_clvp** out, const ttk_clvp_config* cfg, const ttk_weight_view* weights, int n_weights);
+int ttk_clvp_destroy(ttk_clvp* h);
+/* CLVP.forward(text, speech_tokens, return_loss=False) :100-131: text [Bt, Tt] int64 with Bt == 1 (one line scored against every
+ * candidate, what `text_tokens.repeat(B, 1)` at inference.py:394 amounts to) or Bt == B; codes [B, M] int64 -> scores [B] f32.  */
+int ttk_clvp_score(ttk_clvp* h, const int64_t* text, int Bt, int Tt, const int64_t* codes, int B, int M, float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,28 @@ def test_tokens_to_waveform_with_the_vocoder(small):
 	assert sr == 24000 and wav.shape == (1, 1, T * W.VOC_SMALL.hop_size) and (wav.cpu() - ref).abs().max() < 1e-4
 	with pytest.raises(ValueError):
 		tts.inference_to_wav(text, al.to(DEV), dl.to(DEV), **kw)
+
+
+def test_clvp_picks_the_candidate_that_is_diffused(small):
+	"""with a CLVP model the best-scoring candidate's latents go to the diffusion (trimmed by its own codes); scores equal the oracle's"""
+	import clvp_oracle as CO
+	from tortoise_tts_amd.clvp import CLVP
+	from tortoise_tts_amd.inference import TTSHotPath, trim_calm_tokens
+	tts, aro, dor = small
+	ccfg = W.CLVPConfig(dim=128, depth=2, heads=2, num_speech_tokens=8194)      # table wide enough for any sampled mel id
+	csd = W.synth_state_dict(W.clvp_shapes(ccfg), 34)
+	full = TTSHotPath(tts.autoregressive, tts.diffusion, clvp=CLVP(csd, ccfg, dtype="f32", device=DEV))
+	text, al, dl = _inputs(500, 7)
+	kw = dict(max_ar_steps=14, max_diffusion_steps=2, candidates=6, suppress_tokens=[W.AR_SMALL.stop_mel_token])
+	with torch.inference_mode():
+		mels, _, aux = full.inference(text, al.to(DEV), dl.to(DEV), return_all=True, **kw)
+		base_mels, _, base = tts.inference(text, al.to(DEV), dl.to(DEV), return_all=True, **kw)
+		ref_scores = CO.CLVPOracle(csd, ccfg).forward(text.repeat(6, 1), aux["codes"].cpu())
+	assert torch.equal(aux["codes"], base["codes"]) and base["best"] == 0 and base["scores"] is None
+	assert (aux["scores"].cpu() - ref_scores).abs().max() < 1e-4 and aux["best"] == int(ref_scores.argmax())
+	lat_all = tts.autoregressive.forward(al.to(DEV).expand(6, -1), text.to(DEV).expand(6, -1), torch.tensor([7] * 6), aux["codes"], torch.tensor([14 * 1024] * 6),
+										 return_latent=True, clip_inputs=False)
+	b = aux["best"]
+	assert torch.equal(aux["latents"], trim_calm_tokens(aux["codes"][b:b + 1], lat_all[b:b + 1]))
+	if b != 0:
+		assert not torch.equal(mels, base_mels)

@@ -1,10 +1,10 @@
 """tortoise_tts_amd: MI355X-native (gfx950) inference hot path of e-c-k-e-r/tortoise-tts -- the UnifiedVoice KV-cached
 mel-token decode and the DiffusionTTS DDIM mel decoder -- as hand-written HIP kernels behind a C ABI (include/ttk.h),
 exposed under the reference's own method names.  See DESIGN.md and INTEGRATION.md."""
-from .weights import ARConfig, DiffusionConfig, VocoderConfig  # noqa: F401
+from .weights import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig  # noqa: F401
 
 __all__ = ["ARConfig", "DiffusionConfig", "UnifiedVoice", "DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel",
-		   "load_autoregressive", "load_diffusion", "load_bigvgan", "BigVGAN", "VocoderConfig"]
+		   "load_autoregressive", "load_diffusion", "load_bigvgan", "load_clvp", "BigVGAN", "CLVP", "VocoderConfig", "CLVPConfig"]
 
 
 def __getattr__(name):   # lazy: importing the package must not need the built library (CPU-side tools, oracle, weights)
@@ -14,10 +14,13 @@ def __getattr__(name):   # lazy: importing the package must not need the built l
 	if name in ("DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel", "SpacedDiffusion"):
 		from . import diffusion
 		return getattr(diffusion, name)
+	if name == "CLVP":
+		from .clvp import CLVP
+		return CLVP
 	if name == "BigVGAN":
 		from .vocoder import BigVGAN
 		return BigVGAN
-	if name in ("load_autoregressive", "load_diffusion", "load_bigvgan"):
+	if name in ("load_autoregressive", "load_diffusion", "load_bigvgan", "load_clvp"):
 		from . import checkpoint
 		return getattr(checkpoint, name)
 	raise AttributeError(name)

@@ -61,6 +61,9 @@ SYMBOLS = {
 	"ttk_voc_create": (_I, [C.POINTER(_P), _P, C.POINTER(WeightView), _I]),
 	"ttk_voc_destroy": (_I, [_P]),
 	"ttk_voc_inference": (_I, [_P, _P, _I, _I, _P, _P]),
+	"ttk_clvp_create": (_I, [C.POINTER(_P), _P, C.POINTER(WeightView), _I]),
+	"ttk_clvp_destroy": (_I, [_P]),
+	"ttk_clvp_score": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P]),
 	"ttk_fp8_round_weights": (_I, [_P, _L, C.POINTER(C.c_float), _P]),
 	"ttk_sample_step": (_I, [_P, _L, _I, _I, _P, _L, _P, C.c_float, _L, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P]),
 	"ttk_diff_create": (_I, [C.POINTER(_P), C.POINTER(DiffConfigC), C.POINTER(WeightView), _I]),

@@ -264,6 +264,15 @@ def load_bigvgan(path, *, cfg=None, dtype="bf16", device="cuda", state_dict_key:
 	return BigVGAN(sd, cfg or VocoderConfig(), dtype=dtype, device=device)
 
 
+def load_clvp(path, *, cfg=None, dtype="bf16", device="cuda", state_dict_key: Optional[str] = None):
+	"""`load_model("clvp")` (models/__init__.py:111-113): `clvp2.pth` is a plain state_dict of the x-transformers CLVP."""
+	from .clvp import CLVP
+	from .weights import CLVPConfig, clvp_shapes
+	sd = unwrap_state_dict(read_checkpoint(path), state_dict_key)
+	cfg = cfg or CLVPConfig()
+	return CLVP(select_hot_path(sd, clvp_shapes(cfg), "clvp"), cfg, dtype=dtype, device=device)
+
+
 def save_state_dict(state_dict: Mapping[str, torch.Tensor], path, metadata: Optional[Mapping[str, object]] = None):
 	"""`torch_save` (utils/io.py:92-104) for a plain tensor dict: safetensors (metadata JSON-encoded) or `.pth` by extension."""
 	path = os.fspath(path)

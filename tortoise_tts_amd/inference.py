@@ -46,8 +46,8 @@ def trim_calm_tokens(codes: torch.Tensor, latents: torch.Tensor) -> torch.Tensor
 
 
 class TTSHotPath:
-	def __init__(self, autoregressive: UnifiedVoice, diffusion: DiffusionTTS, vocoder=None):
-		self.autoregressive, self.diffusion, self.vocoder = autoregressive, diffusion, vocoder
+	def __init__(self, autoregressive: UnifiedVoice, diffusion: DiffusionTTS, vocoder=None, clvp=None):
+		self.autoregressive, self.diffusion, self.vocoder, self.clvp = autoregressive, diffusion, vocoder, clvp
 
 	@torch.inference_mode()
 	def inference_to_wav(self, text_tokens, autoregressive_latents, diffusion_latents, **kw):
@@ -80,9 +80,15 @@ class TTSHotPath:
 		latents = ar.forward(autoregressive_latents.expand(B, -1) if autoregressive_latents.shape[0] != B else autoregressive_latents,
 							 text_tokens.expand(B, -1), text_lengths.expand(B), codes, wav_lengths.expand(B),
 							 return_latent=True, clip_inputs=False)
-		latents = trim_calm_tokens(codes, latents)
-		# CLVP scoring (reference path) would reorder candidates here (inference.py:392-396); off-path: candidate 0
-		latents = latents[:1]
+		# Candidate choice.  The reference scores the candidates with CLVP and reorders `codes` (inference.py:392-396) but diffuses the
+		# latents computed BEFORE that, in generation order (its own to-do at :370), trimmed where row 0 goes calm (:381-389).  Without
+		# a CLVP model this path keeps that observable behaviour for the first candidate: row 0, trimmed by row 0.  With one
+		# (`TTSHotPath(..., clvp=)`) it does what the to-do asks for: the best-scoring candidate's latents, trimmed by its own codes.
+		best, scores = 0, None
+		if self.clvp is not None and B > 1:
+			scores = self.clvp(text_tokens, codes, return_loss=False)
+			best = int(torch.argmax(scores))
+		latents = trim_calm_tokens(codes[best:best + 1], latents[best:best + 1])
 		T = latents.shape[1] * 4 * 24000 // 22050
 		E = diff.timestep_independent(latents, diffusion_latents, T, False)
 		noise = torch.randn((1, 100, T), device=dev) * diffusion_temp
@@ -91,7 +97,7 @@ class TTSHotPath:
 		mels = denormalize_tacotron_mel(mel)[:, :, :T]
 		seconds = T * HOP / SAMPLE_RATE
 		if return_all:
-			return mels, seconds, dict(codes=codes, latents=latents, E=E, noise=noise, mel=mel)
+			return mels, seconds, dict(codes=codes, latents=latents, E=E, noise=noise, mel=mel, scores=scores, best=best)
 		return mels, seconds
 
 	@torch.inference_mode()
