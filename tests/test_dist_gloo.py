@@ -33,6 +33,10 @@ def _worker(rank, world, port, q):
 		L = 4 + rank                                        # ragged lengths: ranks stop at different steps
 		local = torch.arange(lo, hi)[:, None] * 100 + torch.arange(L)[None, :]
 		ids = D.gather_candidate_ids(local, n, pad_token=8193)
+		# every rank scores its own shard; only the scores travel.  Candidate 3 (on rank 1) wins; a tie with candidate 4 goes to the first.
+		all_scores = torch.tensor([0.1, 0.7, -0.2, 0.9, 0.9])
+		owner, idx, gathered = D.pick_best_candidate(all_scores[lo:hi], n)
+		assert torch.equal(gathered, all_scores) and (owner, idx) == (1, 3 - D.candidate_shard(n, 1, world)[0])
 		q.put((rank, ids))
 	finally:
 		dist.destroy_process_group()

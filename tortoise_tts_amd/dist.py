@@ -1,6 +1,8 @@
 """Multi-GPU sharding of the hot path: one process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in CPU tests).  The path partitions by (utterance, candidate) with replicated weights and NO data-path collective; the one
-exchange is an all-gather of the sampled candidate ids so the candidate scorer (CLVP, reference path, one rank) sees them all.
+"gloo" in CPU tests).  The path partitions by (utterance, candidate) with replicated weights and NO data-path collective.  Two forms
+of the one exchange: `gather_candidate_ids` (an all-gather of the sampled ids, for a scorer that lives on one rank -- the reference
+path's CLVP) and `pick_best_candidate` (every rank scores its own shard with its CLVP replica -- scores are per candidate, so no ids
+need to travel -- and only the scores are all-gathered; the owner of the winner runs the diffusion).
 The reference itself has no multi-GPU inference ("Inference multi-GPU: none"): this is new design.
 """
 from __future__ import annotations
@@ -44,3 +46,28 @@ def gather_candidate_ids(local_ids: torch.Tensor, n_candidates: int, pad_token: 
 	ids = torch.cat(rows, dim=0)
 	assert ids.shape[0] == n_candidates, (ids.shape, n_candidates, rank)
 	return ids
+
+
+def pick_best_candidate(local_scores: torch.Tensor, n_candidates: int) -> Tuple[int, int, torch.Tensor]:
+	"""All-gather of per-rank score blocks [c_r] -> (owner rank, index inside the owner's shard, all scores [n_candidates] in candidate
+	order).  The winner is the first maximum in candidate order (`torch.argmax` on the gathered vector), identical on every rank."""
+	world = dist.get_world_size()
+	dev = local_scores.device
+	n = torch.tensor([local_scores.shape[0]], dtype=torch.long, device=dev)
+	counts = [torch.zeros_like(n) for _ in range(world)]
+	dist.all_gather(counts, n)
+	cmax = int(max(c[0] for c in counts))
+	buf = torch.full((cmax,), float("-inf"), dtype=torch.float32, device=dev)
+	buf[: local_scores.shape[0]] = local_scores.to(torch.float32)
+	out = [torch.empty_like(buf) for _ in range(world)]
+	dist.all_gather(out, buf)
+	scores = torch.cat([out[r][: int(counts[r][0])] for r in range(world)])
+	assert scores.shape[0] == n_candidates, (scores.shape, n_candidates)
+	best = int(torch.argmax(scores))
+	lo = 0
+	for r in range(world):
+		c = int(counts[r][0])
+		if best < lo + c:
+			return r, best - lo, scores
+		lo += c
+	raise AssertionError("unreachable")
