@@ -127,6 +127,16 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	const int strip = rpp * GN_PASSES;
 	const int strips = (p.Tout + strip - 1) / strip;
 	const int b = blockIdx.x / strips, t0 = (blockIdx.x - b * strips) * strip;
+	// the rows this thread normalises are requested FIRST: they do not depend on the statistics, and issued ahead of the chunk triples
+	// the two round trips overlap (the loads retire in order, so the triples arrive with or after the rows, never before they were asked)
+	const int c = (threadIdx.x % c4n) * 4, rr = threadIdx.x / c4n;
+	float4 xv[GN_PASSES];
+#pragma unroll
+	for (int i = 0; i < GN_PASSES; ++i) {
+		const int to = t0 + i * rpp + rr;
+		const int ti = to < p.Tout ? (p.row_idx ? p.row_idx[to] : to) : 0;
+		xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + ti) * p.C + c);
+	}
 	{   // merge: 8 lanes per group, every chunk triple requested up front (one L2 latency, not one per chunk), DPP sums
 		const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
 		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
@@ -151,7 +161,6 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 		if (sub == 0) { s_mean[g] = mean; s_rstd[g] = rsqrtf(m2 / nt + 1e-5f); }
 	}
 	__syncthreads();
-	const int c = (threadIdx.x % c4n) * 4, rr = threadIdx.x / c4n;
 	const int g = c / (p.C / 32);
 	const float mean = s_mean[g], rstd = s_rstd[g];
 	const float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
@@ -161,13 +170,6 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	const float a0 = rstd * ga.x * (1.f + sc.x), a1 = rstd * ga.y * (1.f + sc.y), a2 = rstd * ga.z * (1.f + sc.z), a3 = rstd * ga.w * (1.f + sc.w);
 	const float d0 = (be.x - mean * rstd * ga.x) * (1.f + sc.x) + sh.x, d1 = (be.y - mean * rstd * ga.y) * (1.f + sc.y) + sh.y;
 	const float d2 = (be.z - mean * rstd * ga.z) * (1.f + sc.z) + sh.z, d3 = (be.w - mean * rstd * ga.w) * (1.f + sc.w) + sh.w;
-	float4 xv[GN_PASSES];
-#pragma unroll
-	for (int i = 0; i < GN_PASSES; ++i) {
-		const int to = t0 + i * rpp + rr;
-		const int ti = to < p.Tout ? (p.row_idx ? p.row_idx[to] : to) : 0;
-		xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + ti) * p.C + c);
-	}
 #pragma unroll
 	for (int i = 0; i < GN_PASSES; ++i) {
 		const int to = t0 + i * rpp + rr;
