@@ -8,6 +8,7 @@
 bool ttk::g_prof_on = false;
 void ttk::prof_start(int, double, hipStream_t) {}
 void ttk::prof_stop(hipStream_t) {}
+void ttk::prof_pair(int, double, hipEvent_t* a, hipEvent_t* b) { *a = nullptr; *b = nullptr; }
 using namespace ttk;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 __global__ void fill(unsigned short* p, size_t n, unsigned seed) {

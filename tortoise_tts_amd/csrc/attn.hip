@@ -14,6 +14,8 @@
 // k_attn_decode: single-query KV-cached attention for the AR decode step (HBM-bound: streams the K/V cache once).
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -381,20 +383,21 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 }
 
 template <typename T, int NW, int UN>
-static void launch_attn_decode_t(const AttnDecodeParams& p, hipStream_t s) {
-	hipLaunchKernelGGL((k_attn_decode<T, NW, UN>), dim3(p.H, p.B), dim3(64 * NW), 0, s, p);
+static void launch_attn_decode_t(const AttnDecodeParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+	hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
 }
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {
-	ProfScope prof(PROF_ATTN_DECODE, 2.0 * p.B * p.H * (double)p.ctx_hint * HD * dtype_size(dt), s);
+	hipEvent_t ea = nullptr, eb = nullptr;      // kernel start / stop timestamps when profiling (prof_pair)
+	if (g_prof_on) prof_pair(PROF_ATTN_DECODE, 2.0 * p.B * p.H * (double)p.ctx_hint * HD * dtype_size(dt), &ea, &eb);
 	static const int variant = [] { const char* e = getenv("TTK_ATTN_DECODE"); return e ? atoi(e) : 0; }();   // tuning knob: 0 = default
 	if (dt == DT_BF16) {
 		// 250-token AR loop, B=16, one box: 4 waves x 4 groups (first version, 128 keys per round trip) 261.9 ms; 8 x 6 257.5 ms;
 		// 16 x 3 256.8 ms
-		if (variant == 1) launch_attn_decode_t<bf16, 4, 4>(p, s);
-		else if (variant == 2) launch_attn_decode_t<bf16, 8, 6>(p, s);
-		else launch_attn_decode_t<bf16, 16, 3>(p, s);
+		if (variant == 1) launch_attn_decode_t<bf16, 4, 4>(p, s, ea, eb);
+		else if (variant == 2) launch_attn_decode_t<bf16, 8, 6>(p, s, ea, eb);
+		else launch_attn_decode_t<bf16, 16, 3>(p, s, ea, eb);
 	} else {
-		launch_attn_decode_t<float, 8, 6>(p, s);
+		launch_attn_decode_t<float, 8, 6>(p, s, ea, eb);
 	}
 }
 

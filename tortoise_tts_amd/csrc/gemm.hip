@@ -17,6 +17,8 @@
 // Roofline: MFMA-bound for the diffusion shapes (M = b*T ~ 2k rows, N,K in 1k..3k); bytes/flop is tiny.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 }
 
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
-static void launch_tile(const GemmParams& p, hipStream_t s) {
+static void launch_tile(const GemmParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	constexpr int LDS = NSTAGE * (BM + BN) * 128;
 	static bool attr_set = false;
 	if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
@@ -342,7 +344,7 @@ static void launch_tile(const GemmParams& p, hipStream_t s) {
 		attr_set = true;
 	}
 	const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-	hipLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE>), dim3(grid), dim3(64 * NWM * NWN), LDS, s, p);
+	hipExtLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE>), dim3(grid), dim3(64 * NWM * NWN), (unsigned)LDS, s, ea, eb, 0, p);
 }
 
 int g_force_tile = -1;   // TTK_GEMM_TILE=0|1|2 (tuning only)
@@ -361,24 +363,25 @@ bool gemm_fuses_gn_stats(int M, int N, int C, int T) {
 // are >= 256 such tiles (575-600 TF/s at M = 5k), else 128x64 x 4 waves with two workgroups per CU (the 2k-row diffusion GEMMs,
 // 335-520 TF/s), 64x64 for tiny M.
 template <typename T>
-static void launch_gemm_t(const GemmParams& p, hipStream_t s) {
+static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	if (g_force_tile < 0) { const char* e = getenv("TTK_GEMM_TILE"); g_force_tile = e ? atoi(e) + 100 : 99; }
 	int tile;
 	if (g_force_tile >= 100) tile = g_force_tile - 100;
 	else {
 		tile = pick_tile(p.M, p.N);
 	}
-	if (tile == 0) launch_tile<T, 128, 128, 2, 4, 3>(p, s);       // 8 waves, wave block 64 x 32, two workgroups per CU
-	else if (tile == 1) launch_tile<T, 128, 64, 2, 2, 3>(p, s);   // 4 waves, wave block 64 x 32, two workgroups per CU
-	else if (tile == 3) launch_tile<T, 128, 128, 2, 4, 4>(p, s);  // as 0 with a 4-stage ring (128 KiB: one workgroup per CU)
-	else if (tile == 4) launch_tile<T, 128, 64, 2, 2, 5>(p, s);   // as 1 with a 5-stage ring (120 KiB: one workgroup per CU)
-	else launch_tile<T, 64, 64, 2, 2, 3>(p, s);
+	if (tile == 0) launch_tile<T, 128, 128, 2, 4, 3>(p, s, ea, eb);       // 8 waves, wave block 64 x 32, two workgroups per CU
+	else if (tile == 1) launch_tile<T, 128, 64, 2, 2, 3>(p, s, ea, eb);   // 4 waves, wave block 64 x 32, two workgroups per CU
+	else if (tile == 3) launch_tile<T, 128, 128, 2, 4, 4>(p, s, ea, eb);  // as 0 with a 4-stage ring (128 KiB: one workgroup per CU)
+	else if (tile == 4) launch_tile<T, 128, 64, 2, 2, 5>(p, s, ea, eb);   // as 1 with a 5-stage ring (120 KiB: one workgroup per CU)
+	else launch_tile<T, 64, 64, 2, 2, 3>(p, s, ea, eb);
 }
 
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
-	ProfScope prof(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, s);
-	if (dt == DT_BF16) launch_gemm_t<bf16>(p, s);
-	else launch_gemm_t<float>(p, s);
+	hipEvent_t ea = nullptr, eb = nullptr;      // kernel start / stop timestamps when profiling (prof_pair)
+	if (g_prof_on) prof_pair(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, &ea, &eb);
+	if (dt == DT_BF16) launch_gemm_t<bf16>(p, s, ea, eb);
+	else launch_gemm_t<float>(p, s, ea, eb);
 }
 
 }  // namespace ttk

@@ -15,6 +15,8 @@
 //   LN2 + c_fc + bias + gelu_new  (HF:activations.py:59-66)                            SK_ACT_T
 //   ln_f + final_norm + mel_head  (unified_voice.py:106,239)                           SK_STORE_F32, ln_count = 2
 // Algorithmic bytes per launch: N*K*sizeof(T) weight bytes (+ M*K*4 activations from L2).
+#include <hip/hip_ext.h>
+
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 }
 
 template <typename T, int MT, bool W8>
-static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
+static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	const int grid = p.narrow ? ((p.N + 15) / 16) * p.narrow : ((p.N + 15) / 16) * p.ksplit;
 	const size_t red = (size_t)waves * MT * 64 * 4 * sizeof(float);
 	if (p.ln_count > 0) {
@@ -345,21 +347,21 @@ static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s) {
 		const size_t lds = (size_t)16 * MT * (p.K * sizeof(T) + 16) + (size_t)waves * MT * 64 * 4 * sizeof(float);
 		if (p.K <= 1024) {
 			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 4, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL((k_skinny<T, MT, true, 4, W8>), dim3(grid), dim3(64 * waves), lds, s, p);
+			hipExtLaunchKernelGGL((k_skinny<T, MT, true, 4, W8>), dim3(grid), dim3(64 * waves), (unsigned)lds, s, ea, eb, 0, p);
 		} else {
 			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 8, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			hipLaunchKernelGGL((k_skinny<T, MT, true, 8, W8>), dim3(grid), dim3(64 * waves), lds, s, p);
+			hipExtLaunchKernelGGL((k_skinny<T, MT, true, 8, W8>), dim3(grid), dim3(64 * waves), (unsigned)lds, s, ea, eb, 0, p);
 		}
 	} else {
-		hipLaunchKernelGGL((k_skinny<T, MT, false, 1, W8>), dim3(grid), dim3(64 * waves), red, s, p);
+		hipExtLaunchKernelGGL((k_skinny<T, MT, false, 1, W8>), dim3(grid), dim3(64 * waves), (unsigned)red, s, ea, eb, 0, p);
 	}
 }
 
 template <typename T, bool W8>
-static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s) {
-	if (p.M <= 16) launch_skinny_mt<T, 1, W8>(p, waves, s);
-	else if (p.M <= 32) launch_skinny_mt<T, 2, W8>(p, waves, s);
-	else launch_skinny_mt<T, 4, W8>(p, waves, s);
+static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+	if (p.M <= 16) launch_skinny_mt<T, 1, W8>(p, waves, s, ea, eb);
+	else if (p.M <= 32) launch_skinny_mt<T, 2, W8>(p, waves, s, ea, eb);
+	else launch_skinny_mt<T, 4, W8>(p, waves, s, ea, eb);
 }
 
 void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
@@ -370,9 +372,11 @@ void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
 	if (waves < 4) waves = 4;
 	// algorithmic bytes: the weight matrix once + bias + the M activation rows in and out
 	if (dt != DT_BF16) p.w8 = 0;                                // fp8 weights exist for the bf16 arithmetic only
-	ProfScope prof(PROF_SKINNY, (double)p.N * p.K * (p.w8 ? 1 : dtype_size(dt)) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, s);
-	if (dt == DT_BF16) { if (p.w8) launch_skinny_t<bf16, true>(p, waves, s); else launch_skinny_t<bf16, false>(p, waves, s); }
-	else launch_skinny_t<float, false>(p, waves, s);
+	// profiling: the event pair travels with the dispatch packet (kernel start / stop timestamps), see prof_pair
+	hipEvent_t ea = nullptr, eb = nullptr;
+	if (g_prof_on) prof_pair(PROF_SKINNY, (double)p.N * p.K * (p.w8 ? 1 : dtype_size(dt)) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, &ea, &eb);
+	if (dt == DT_BF16) { if (p.w8) launch_skinny_t<bf16, true>(p, waves, s, ea, eb); else launch_skinny_t<bf16, false>(p, waves, s, ea, eb); }
+	else launch_skinny_t<float, false>(p, waves, s, ea, eb);
 }
 
 }  // namespace ttk

@@ -84,6 +84,11 @@ void prof_start(int kind, double work, hipStream_t s) {
 	g_recs.push_back(r);
 }
 void prof_stop(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); }
+void prof_pair(int kind, double work, hipEvent_t* start, hipEvent_t* stop) {
+	ProfRec r; r.a = pool_get(); r.b = pool_get(); r.kind = kind; r.work = work;
+	g_recs.push_back(r);
+	*start = r.a; *stop = r.b;
+}
 
 }  // namespace ttk
 

@@ -22,6 +22,9 @@ enum ProfKind { PROF_GEMM = 0, PROF_SKINNY = 1, PROF_ATTN_FWD = 2, PROF_ATTN_DEC
 extern bool g_prof_on;
 void prof_start(int kind, double work, hipStream_t s);
 void prof_stop(hipStream_t s);
+// For launchers that pass the pair to hipExtLaunchKernelGGL: the events then carry the kernel's own start / stop timestamps (what a
+// kernel trace reports) instead of bracketing the launch on the stream, which for a 5 us kernel also times the launch gap.
+void prof_pair(int kind, double work, hipEvent_t* start, hipEvent_t* stop);
 struct ProfScope {
 	hipStream_t s; bool on;
 	ProfScope(int kind, double work, hipStream_t s_) : s(s_), on(g_prof_on) { if (on) prof_start(kind, work, s); }
