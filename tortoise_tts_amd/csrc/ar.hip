@@ -89,6 +89,7 @@ struct ttk_ar {
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
 	int wv_proj = 8, wv_proj2 = 16;   // waves per workgroup of the two plain decode GEMVs (TTK_AR_WV_PROJ / TTK_AR_WV_PROJ2)
+	int hfrag = 1;                // MLP activations of the decode step in MFMA-fragment order (TTK_AR_HFRAG=0: row-major)
 	int narrow2 = 4;              // same for mlp.c_proj (TTK_AR_NARROW2)
 	int narrow = 4;               // c_proj / mlp.c_proj decode GEMVs as 4-column workgroups without split-K (TTK_AR_NARROW=0: 16-column + split-K)
 	int nsplit = 1;               // row groups decoded concurrently (TTK_AR_SPLIT; measured slower: 283 -> 340 ms at 2, see below)
@@ -174,19 +175,19 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
 		launch_skinny(dt, p, wv_small, s);
 		AttnDecodeParams a = {};
-		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out;
+		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		launch_attn_decode(dt, a, s);
 		p = {};
-		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d;
+		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.narrow = h->narrow;
 		launch_skinny(dt, p, d >= 1024 ? h->wv_proj : 4, s);
 		p = {};
 		p.Wp = L.fc.wfrag; p.w8 = L.fc.w8; p.wscale = L.fc.wscale; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
 		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b;
-		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf;
+		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf; p.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		launch_skinny(dt, p, wv_small, s);
 		p = {};
-		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d;
+		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
 		p.narrow = h->narrow2;
 		if (d >= 1024 && !h->narrow2) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
@@ -251,14 +252,19 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	AR_TRY(h->arena.alloc((void**)&h->d_pos, 16));
 	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
-	AR_TRY(h->arena.alloc(&h->attn_out, (size_t)cfg->max_batch * d * h->es));
-	AR_TRY(h->arena.alloc(&h->hbuf, (size_t)cfg->max_batch * 4 * d * h->es));
+	AR_TRY(h->arena.alloc(&h->attn_out, (size_t)round_up(cfg->max_batch, 16) * d * h->es));
+	if (hipMemset(h->attn_out, 0, (size_t)round_up(cfg->max_batch, 16) * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
+	// 16-row tiles: the decode path keeps the MLP activations in fragment order, whose padding rows must exist and hold zeros
+	AR_TRY(h->arena.alloc(&h->hbuf, (size_t)round_up(cfg->max_batch, 16) * 4 * d * h->es));
+	if (hipMemset(h->hbuf, 0, (size_t)round_up(cfg->max_batch, 16) * 4 * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->slab, (size_t)4 * (d / 16) * 4 * 4 * 256 * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)4 * (d / 16) * sizeof(int)));
 	if (hipMemset(h->tickets, 0, (size_t)4 * (d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	{
 		const char* en = getenv("TTK_AR_NARROW");
 		h->narrow = en ? atoi(en) : 4;                    // 0 = 16-column workgroups (+ split-K for mlp.c_proj), 2 / 4 = workgroups per tile
+		const char* ef = getenv("TTK_AR_HFRAG");
+		h->hfrag = ef ? (atoi(ef) != 0) : 1;
 		const char* en2 = getenv("TTK_AR_NARROW2");
 		h->narrow2 = en2 ? atoi(en2) : h->narrow;
 		const char* e1 = getenv("TTK_AR_WV_PROJ");

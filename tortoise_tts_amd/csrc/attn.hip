@@ -296,6 +296,14 @@ void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s) {
 // the whole cache slice of this (b, h) is in flight after ONE dependent step (the position scalar), instead of one round trip
 // per 128 keys.  Online softmax per (wave, slot), partials merged through LDS in two levels.
 // Algorithmic bytes: 2 * (pos+1) * 64 * sizeof(T) per (b, h).
+// where output element (candidate b, head h, dim e) goes: row-major [B][H*64], or the A-fragment order the skinny GEMV reads
+// ([m_tile][k_step][lane = k_group * 16 + row][8]), in which a wave instruction of the projection reads 1 KiB contiguous
+__device__ __forceinline__ int64_t decode_out_index(const AttnDecodeParams& p, int b, int h, int e) {
+	if (!p.out_frag) return ((int64_t)b * p.H + h) * HD + e;
+	const int n = h * HD + e;
+	return ((((int64_t)(b >> 4) * (p.H * HD / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (b & 15)) * 8 + (n & 7));
+}
+
 template <typename T, int NW, int UN>
 __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	typedef typename Frag<T>::type FragT;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 #pragma unroll
 		for (int i = 0; i < 32; ++i) { const float a = __builtin_amdgcn_exp2f(sm[part * 32 + i] - mn); lt += sl[part * 32 + i] * a; ot += sacc[part * 32 + i][e] * a; }
 		if (L1 == 1) {
-			((T*)p.out)[((int64_t)b * p.H + h) * HD + e] = cvt<T>(ot / lt);
+			((T*)p.out)[decode_out_index(p, b, h, e)] = cvt<T>(ot / lt);
 		} else {
 			if (e == 0) { sm2[part] = mn; sl2[part] = lt; }
 			so2[part][e] = ot;
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 			float lt = 0.f, ot = 0.f;
 #pragma unroll
 			for (int i = 0; i < L1; ++i) { const float a = __builtin_amdgcn_exp2f(sm2[i] - mn); lt += sl2[i] * a; ot += so2[i][tid] * a; }
-			((T*)p.out)[((int64_t)b * p.H + h) * HD + tid] = cvt<T>(ot / lt);
+			((T*)p.out)[decode_out_index(p, b, h, tid)] = cvt<T>(ot / lt);
 		}
 	}
 }

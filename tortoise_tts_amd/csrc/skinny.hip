@@ -236,6 +236,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			for (int f = 0; f < ES / 2; ++f) u.q[f] = *(const uint4*)(src + 16 * f);
 			return u.v;
 		} else {
+			if (p.a_frag) return *(const FragT*)((const T*)p.a + (((int64_t)mt * KS + ks) * 64 + lane) * 8);   // rows >= M hold zeros
 			int row = mt * 16 + arow;
 			row = row < p.M ? row : p.M - 1;
 			return *(const FragT*)((const T*)p.a + (int64_t)row * p.lda + 32 * ks + 8 * ag);
@@ -321,7 +322,8 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		} else if (p.mode == SK_RESIDUAL) {
 			p.out_f32[(int64_t)m * p.ldc + n] = res[mt] + v;
 		} else if (p.mode == SK_ACT_T) {
-			((T*)p.out_T)[(int64_t)m * p.N + n] = cvt<T>(apply_act(v, p.act));
+			const int64_t o = p.out_frag ? ((((int64_t)mt * (p.N / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (m & 15)) * 8 + (n & 7)) : (int64_t)m * p.N + n;
+			((T*)p.out_T)[o] = cvt<T>(apply_act(v, p.act));
 		} else {   // SK_QKV
 			const int d = p.N / 3;
 			const int which = n / d, c = n - which * d;

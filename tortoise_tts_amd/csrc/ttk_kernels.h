@@ -88,6 +88,9 @@ struct SkinnyParams {
 	int ksplit; float* slab; int* tickets;
 	// narrow mode (plain A only, excludes ksplit): N/4 workgroups of 4 columns each instead of N/16 of 16 -- for the N = d projections
 	int narrow;
+	// activations in MFMA-fragment order [m_tile][k_step][lane][8] (a wave reads 1 KiB contiguous instead of 16 row segments): a_frag = the
+	// plain-mode A operand is stored that way, out_frag = SK_ACT_T writes its output that way (for the next launch's a_frag)
+	int a_frag, out_frag;
 	// fp8 weights: Wp holds one byte per element in the same fragment order; the accumulated product is multiplied by wscale (a power of two)
 	int w8; float wscale;
 #ifdef TTK_STAMPS
@@ -129,7 +132,8 @@ struct AttnDecodeParams {
 	const int* d_pos;         // keys valid = *d_pos + 1
 	int B, H, max_ctx;
 	int ctx_hint;             // host-side copy of the key count (profiling only; stale under graph replay)
-	void* out;                // T [B][H*64]
+	void* out;                // T [B][H*64], or (out_frag) MFMA-fragment order [m_tile][H*2][lane][8] for the projection that follows
+	int out_frag;
 };
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s);
 
