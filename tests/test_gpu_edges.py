@@ -182,3 +182,35 @@ def test_compute_embeddings_fake_id_row_equals_reference(small_ar, golden):
 	text = torch.randint(1, 255, (2, 5), generator=gen(1)).to(DEV)
 	got = model.compute_embeddings(torch.zeros(2, W.AR_SMALL.model_dim, device=DEV), text)
 	assert got.dtype == torch.long and torch.equal(got.cpu(), want)
+
+
+def test_new_handles_reject_bad_arguments_with_messages():
+	"""vocoder / CLVP / fp8 helper: configuration and argument errors come back as codes + text, never as crashes"""
+	import ctypes as C
+	from tortoise_tts_amd import _lib
+	from tortoise_tts_amd.clvp import CLVP
+	from tortoise_tts_amd.vocoder import BigVGAN
+	lib = _lib.load()
+	# vocoder: kernel size not a multiple of the rate; odd channel halving; missing tensor; wrong dtype
+	bad = W.VocoderConfig(upsample_rates=(4, 2), upsample_kernel_sizes=(7, 4), upsample_initial_channel=128, resblock_kernel_sizes=(3, 7),
+						  resblock_dilation_sizes=((1, 3, 5), (1, 3, 5)))
+	with pytest.raises(_lib.TTKError, match="upsampler 0"):
+		BigVGAN(W.synth_state_dict(W.vocoder_shapes(bad), 1), bad, dtype="f32", device=DEV)
+	sd = W.synth_state_dict(W.vocoder_shapes(W.VOC_SMALL), 1)
+	with pytest.raises(_lib.TTKError, match="lacks"):
+		BigVGAN({k: v for k, v in sd.items() if k != "conv_post.bias"}, W.VOC_SMALL, dtype="f32", device=DEV)
+	with pytest.raises(_lib.TTKError, match="bf16"):
+		BigVGAN(sd, W.VOC_SMALL, dtype="fp8w", device=DEV)
+	assert lib.ttk_voc_inference(None, None, 1, 1, None, None) != 0 and b"ttk_voc_inference" in lib.ttk_last_error()
+	# CLVP: head width must be 64; shape errors on the text argument
+	with pytest.raises(_lib.TTKError, match="head width"):
+		c = W.CLVPConfig(dim=96, depth=1, heads=2)
+		CLVP(W.synth_state_dict(W.clvp_shapes(c), 1), c, dtype="f32", device=DEV)
+	m = CLVP(W.synth_state_dict(W.clvp_shapes(W.CLVP_SMALL), 1), W.CLVP_SMALL, dtype="f32", device=DEV)
+	with pytest.raises(_lib.TTKError, match="text must be"):
+		m(torch.zeros(2, 4, dtype=torch.long), torch.zeros(3, 5, dtype=torch.long))
+	assert lib.ttk_clvp_score(None, None, 1, 1, None, 1, 1, None, None) != 0 and b"ttk_clvp_score" in lib.ttk_last_error()
+	# fp8 rounding helper
+	assert lib.ttk_fp8_round_weights(None, 0, None, None) != 0 and b"ttk_fp8_round_weights" in lib.ttk_last_error()
+	# destroying null handles is a no-op
+	assert lib.ttk_voc_destroy(None) == 0 and lib.ttk_clvp_destroy(None) == 0
