@@ -12,7 +12,8 @@
  *  - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); calls only enqueue work and never
  *    synchronise, allocate or free (except the create and destroy calls and the first call that grows a workspace), so a decode
  *    step or a diffusion step can be captured into a HIP graph by the caller.
- *  - a handle owns packed weights, KV cache and workspaces; one handle per (process, device); not re-entrant.
+ *  - a handle owns packed weights, KV cache and workspaces; one handle per (process, device); not re-entrant.  Different handles may be
+ *    driven from different host threads on different streams (ttk_last_error is per thread).
  *  - weights are passed as f32 tensors (host or device memory) under the reference's state_dict key names and are copied.
  */
 #ifndef TTK_H

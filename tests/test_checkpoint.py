@@ -135,3 +135,34 @@ def test_gpu_handle_from_checkpoint_files_with_lora(golden, tmp_path):
 	with torch.inference_mode():
 		logits = ar._prefill(t(g["cond"]), t(g["text"]), int(g["B"]))
 	assert (logits.cpu() - t(g["prefill_logits"])).abs().max().item() <= 2e-4
+
+
+def test_vocoder_weight_norm_folding_equals_reference(golden):
+	"""product-side folding (tortoise_tts_amd/vocoder.py) of the checkpoint's weight_g / weight_v pairs, both spellings, against the weights
+	the reference's remove_weight_norm() produced (Conv1d: norm over [in, k] per output channel; ConvTranspose1d: over [out, k] per INPUT channel)"""
+	from tortoise_tts_amd.vocoder import aa_filter, fold_weight_norm
+	g = golden("vocoder_small")
+	sd = {"conv_pre.weight_g": t(g["wn_conv_pre_g"]), "conv_pre.weight_v": t(g["wn_conv_pre_v"]), "conv_pre.bias": torch.zeros(4),
+		  "ups.0.0.parametrizations.weight.original0": t(g["wn_ups0_g"]), "ups.0.0.parametrizations.weight.original1": t(g["wn_ups0_v"]),
+		  "activation_post.upsample.filter": torch.zeros(1, 1, 12)}
+	out = fold_weight_norm(sd)
+	assert set(out) == {"conv_pre.weight", "conv_pre.bias", "ups.0.0.weight"}
+	assert (out["conv_pre.weight"] - t(g["wn_conv_pre_w"])).abs().max().item() <= 1e-6
+	assert (out["ups.0.0.weight"] - t(g["wn_ups0_w"])).abs().max().item() <= 1e-6
+	assert np.array_equal(aa_filter().numpy(), g["filter_up"])          # the product's own filter restatement, bit for bit
+
+
+def test_clvp_packing_and_shape_selection(golden):
+	from tortoise_tts_amd.clvp import pack_state_dict
+	cfg = W.CLVP_SMALL
+	sd = W.synth_state_dict(W.clvp_shapes(cfg), 3)
+	packed = pack_state_dict(sd | {"text_transformer.transformer.attn_layers.rotary_pos_emb.inv_freq": torch.zeros(16)}, cfg)
+	p = "speech_transformer.transformer.attn_layers.layers.2.1.wrap."
+	assert torch.equal(packed[p + "__qkv.weight"], torch.cat([sd[p + "to_q.weight"], sd[p + "to_k.weight"], sd[p + "to_v.weight"]]))
+	assert not any("inv_freq" in k and not k.startswith("__") for k in packed) and packed["temperature"].shape == (1,)
+	want = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+	assert torch.equal(packed["__rotary_inv_freq"], want) and packed["__rotary_inv_freq"].shape == (16,)
+	# select_hot_path on a CLVP file with a missing tensor names it
+	broken = {k: v for k, v in sd.items() if k != "to_speech_latent.weight"}
+	with pytest.raises(ck.CheckpointError, match="to_speech_latent.weight"):
+		ck.select_hot_path(broken, W.clvp_shapes(cfg), "clvp")
