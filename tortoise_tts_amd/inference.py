@@ -110,7 +110,8 @@ class TTSHotPath:
 		(graph replay), and enqueuing a diffusion is ~10k launches from one C call, so the diffusion is issued from a worker thread on its
 		own HIP stream (ctypes releases the GIL for the call).  Measured at the benchmark's shape: 422.7 ms per line sequentially, 3 % less
 		with both phases issued by one thread, 374.9 ms (-11 %) with the worker; two PROCESSES sharing the GPU reach 1.4x, so launch-path
-		contention inside one process still costs.  Results are identical to calling `inference` per line: every `generate` reseeds the generator to 0
+		contention inside one process still costs.  (Stream priorities make it far worse -- 660 ms with either chain prioritised -- and
+		GPU_MAX_HW_QUEUES=8 removes the gain; the default queue mapping is kept.)  Results are identical to calling `inference` per line: every `generate` reseeds the generator to 0
 		(stream_generator.py:296), and the draws that follow a line's AR phase in the reference (the diffusion start noise,
 		inference.py:404, and DDIM's per-step dummy draws, diffusion.py:685) are made by the main thread in that same order before the next
 		line's AR phase starts; the worker draws nothing.
