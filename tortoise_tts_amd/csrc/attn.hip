@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
 	const T* base = (const T*)p.qkv + (int64_t)b * p.T * p.ld;
 	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
 
+	__shared__ unsigned pf_sink[64 * 4];
+	if (p.pf) {   // the following projection's weights into L2; workgroups are numbered x-fastest over the (query block, head, batch) grid
+		const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+		l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (threadIdx.x >> 6) * 256), lin, gridDim.x * gridDim.y * gridDim.z, threadIdx.x, 256);
+	}
 	if (BIAS) {
 		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid] * LOG2E;   // scores live in the log2 domain (exp2 = one v_exp_f32)
 	}

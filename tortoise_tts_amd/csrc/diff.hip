@@ -20,6 +20,7 @@ struct DLayer { ResBlk res; AttnBlk attn; };
 
 struct ttk_diff {
 	ttk_diff_config cfg;
+	int prefetch = 1;       // GroupNorm-apply launches touch the following GEMM's weights into L2 (TTK_DIFF_PREFETCH=0: off)
 	int dt, wdt;            // kernel arithmetic type / storage type of the block GEMM weights (== dt, or DT_FP8W)
 	size_t es;
 	Arena arena;
@@ -70,24 +71,26 @@ static void gemm_conv3(ttk_diff* h, const void* A, int64_t lda, const Mat& m, in
 }
 
 static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, const float* beta, const float* scale, const float* shift,
-			   int64_t ss_stride, int act, void* out, int out_f32, const int* row_idx, int Tout, hipStream_t s) {
+			   int64_t ss_stride, int act, void* out, int out_f32, const int* row_idx, int Tout, hipStream_t s, const Mat* next = nullptr) {
 	const int C = h->cfg.model_channels;
 	if (h->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);   // else: left by the producing GEMM
 	h->ms_owner = nullptr;
 	GnApplyParams p = {};
 	p.x = x; p.ms = (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
 	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.nchunks = gn_num_chunks(T, C); p.act = act; p.out = out; p.out_f32 = out_f32;
+	if (next && h->prefetch) { p.pf = next->w; p.pf_bytes = (int64_t)next->Npad * next->Kpad * h->es; p.pf_taps = next->ntap; }
 	launch_gn_apply(h->dt, p, s);
 }
 
 // x (f32 stream, in place) = x + proj_out(attention(qkv(GN(x))))         arch_utils.py:183-190
 static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, hipStream_t s) {
 	const int C = h->cfg.model_channels, rows = nb * T;
-	gn(h, x, nb, T, A.gn_g, A.gn_b, nullptr, nullptr, 0, ACT_NONE, h->a.p, 0, nullptr, T, s);
+	gn(h, x, nb, T, A.gn_g, A.gn_b, nullptr, nullptr, 0, ACT_NONE, h->a.p, 0, nullptr, T, s, &A.qkv);
 	gemm1(h, h->a.p, C, A.qkv, rows, h->qkv.p, 3 * C, 0, ACT_NONE, nullptr, s);
 	AttnParams a = {};
 	a.qkv = h->qkv.p; a.ld = 3 * C; a.q_off = 0; a.k_off = 64; a.v_off = 128; a.head_stride = 192;   // head-major [H][3][64], arch_utils.py:79
 	a.out = h->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f;
+	if (h->prefetch) { a.pf = A.proj.w; a.pf_bytes = (int64_t)A.proj.Npad * A.proj.Kpad * h->es; a.pf_taps = 1; }
 	launch_attn_fwd(h->dt, a, s);
 	gemm1(h, h->ao.p, C, A.proj, rows, x, C, 1, ACT_NONE, x, s, T);
 }
@@ -95,10 +98,10 @@ static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, h
 // x = x + conv3(SiLU(GN(conv1(SiLU(GN(x)))) * (1 + scale) + shift))        diffusion.py:1363-1376
 static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, const float* emb_all, int64_t emb_stride, hipStream_t s) {
 	const int C = h->cfg.model_channels, rows = nb * T;
-	gn(h, x, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s);
+	gn(h, x, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s, &R.in);
 	gemm1(h, h->a.p, C, R.in, rows, h->hf.p, C, 1, ACT_NONE, nullptr, s, T);
 	const float* sc = emb_all + (int64_t)R.emb_slot * 2 * C;
-	gn(h, (const float*)h->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->a.p, 0, nullptr, T, s);
+	gn(h, (const float*)h->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->a.p, 0, nullptr, T, s, &R.out3);
 	gemm_conv3(h, h->a.p, C, R.out3, rows, T, x, C, 1, x, 0, s, T);
 }
 
@@ -197,6 +200,7 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	h->es = dtype_size(h->dt);
 	h->in_pad = round_up(cfg->in_channels, 64);
 	h->fuse_stats = getenv("TTK_NO_FUSED_GN") ? 0 : 1;
+	{ const char* e = getenv("TTK_DIFF_PREFETCH"); h->prefetch = e ? atoi(e) : 1; }
 	const int C = cfg->model_channels;
 	WeightMap wm(w, n_w);
 	int rc = TTK_OK;

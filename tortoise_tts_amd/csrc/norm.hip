@@ -4,6 +4,8 @@
 //   GroupNorm32: /root/reference/tortoise_tts/models/arch_utils.py:24-44 (32 groups, float math, eps 1e-5),
 //                used by ResBlock diffusion.py:1338-1372 and AttentionBlock arch_utils.py:163,186
 // Internal layout is channels-last [nb][T][C], so a group is (T rows) x (C/32 contiguous channels).
+#include <stdint.h>
+
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -137,6 +139,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 		const int ti = to < p.Tout ? (p.row_idx ? p.row_idx[to] : to) : 0;
 		xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + ti) * p.C + c);
 	}
+	__shared__ unsigned pf_sink[64 * 4];
+	if (p.pf)     // the next GEMM's weights into L2 (see GnApplyParams)
+		l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (threadIdx.x >> 6) * 256), blockIdx.x, gridDim.x, threadIdx.x, 256);
 	{   // merge: 8 lanes per group, every chunk triple requested up front (one L2 latency, not one per chunk), DPP sums
 		const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
 		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;

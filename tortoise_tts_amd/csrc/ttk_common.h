@@ -77,4 +77,25 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 	return v;
 }
 
+// L2 touch of memory a LATER launch will read (weights of the GEMM that follows): every workgroup touches, one 128-byte line per thread,
+// its share of the slice that the consumer's workgroups on the same XCD (blockIdx % 8) will fetch -- `taps` blocks of `bytes` each, a
+// block's eighth x being XCD x's slice.  The touch is an LDS-DMA load into a sink nobody reads: a load into a VGPR the compiler
+// considers dead could land after that register has been given a new value.  `sink` = LDS byte address of >= 256 bytes per wave.
+__device__ __forceinline__ void l2_touch_for_next(const void* base, int64_t bytes, int taps, unsigned sink, int block, int nblocks, int tid, int nthreads) {
+	const int xcd = block & 7, rank = block >> 3, nx = (nblocks + 7 - xcd) >> 3;      // workgroups on this XCD
+	const int64_t slice = bytes / 8, lines = slice / 128;
+	const int64_t per = (lines + nx - 1) / nx;
+	for (int tap = 0; tap < taps; ++tap)
+		for (int64_t l = tid; l < per; l += nthreads) {
+			const int64_t line = (int64_t)rank * per + l;
+			if (line < lines) {
+				const char* a = (const char*)base + (int64_t)tap * bytes + (int64_t)xcd * slice + line * 128;
+				unsigned keep;
+				asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+							 : "=&s"(keep) : "s"(sink), "v"(a) : "memory");
+			}
+		}
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+
 }  // namespace ttk

@@ -112,6 +112,10 @@ struct GnApplyParams {
 	const float* x; const float* ms; const float* gamma; const float* beta;
 	const float* scale; const float* shift; int64_t ss_stride;   // per-batch stride of scale/shift rows (0 = shared)
 	const int* row_idx; int nb, T, Tout, C; int nchunks; int act; void* out; int out_f32;
+	// optional: weights of the GEMM that consumes this output, touched so that they sit in L2 when it starts.  The matrix is `pf_taps`
+	// blocks of `pf_bytes` each; block bytes are split into 8 equal slices, slice x = the n-range the GEMM's tile order gives XCD x, and
+	// the workgroups on XCD x (blockIdx % 8) touch one 128-byte line per thread of their share of slice x.
+	const void* pf; int64_t pf_bytes; int pf_taps;
 };
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s);
 
@@ -123,6 +127,7 @@ struct AttnParams {
 	int nb, T, H, causal;
 	const float* bias;                    // [H][129] relative-position bias (already scaled) or null
 	float scale;                          // multiplies q.k
+	const void* pf; int64_t pf_bytes; int pf_taps;   // optional L2 touch of the following GEMM's weights (see GnApplyParams)
 };
 void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s);
 
