@@ -14,6 +14,8 @@ Fixtures
   diff_small.npz  DiffusionTTS(128 ch, 2 layers, 2 heads): timestep_independent, forward cond/uncond,
                   DDIM 4 steps, p-sampler 4 steps                            (diffusion.py:1487-1574, :500-810)
   diff_full.npz   full-size DiffusionTTS(): one forward (cond + uncond) at T=26
+  cond_small.npz  UnifiedVoice.get_conditioning / DiffusionTTS.get_conditioning, small widths, 2 clips   (unified_voice.py:535-542,
+  cond_full.npz   diffusion.py:1477-1485); full-size encoders at short clips
   schedule.npz    get_diffuser(steps) tables for steps in 4, 30, 80, 200    (diffusion.py:1576-1590)
 """
 import os
@@ -253,6 +255,32 @@ def clvp_case(cfg, seed):
 	return out
 
 
+def cond_case(d_mod, uv_mod, ar_cfg, diff_cfg, seed, b, n_clips, T_ar, T_diff, full):
+	"""UnifiedVoice.get_conditioning / DiffusionTTS.get_conditioning on seeded synthetic weights (unified_voice.py:535-542,
+	diffusion.py:1477-1485).  Only the sub-modules are built (full-size parents are not needed for their outputs)."""
+	sd_ar = W.synth_state_dict(W.ar_conditioning_shapes(ar_cfg), seed)
+	sd_df = W.synth_state_dict(W.diffusion_conditioning_shapes(diff_cfg), seed + 1)
+	uv = uv_mod.UnifiedVoice(layers=1 if full else ar_cfg.layers, model_dim=ar_cfg.model_dim, heads=ar_cfg.heads, checkpointing=False)
+	missing, unexpected = uv.load_state_dict(sd_ar, strict=False)
+	assert not unexpected and not [k for k in missing if k.startswith("conditioning_encoder.")], unexpected
+	df = d_mod.DiffusionTTS(model_channels=diff_cfg.model_channels, num_layers=1 if full else diff_cfg.num_layers,
+							in_latent_channels=diff_cfg.in_latent_channels, num_heads=diff_cfg.num_heads)
+	missing, unexpected = df.load_state_dict(sd_df, strict=False)
+	assert not unexpected and not [k for k in missing if k.startswith("contextual_embedder.")], unexpected
+	uv.eval(); df.eval()
+	mel_ar = torch.randn(b, n_clips, 80, T_ar, generator=gen(seed + 2)) * 2 - 4
+	mel_df = torch.randn(b, n_clips, diff_cfg.in_channels, T_diff, generator=gen(seed + 3)) * 2 - 4
+	out = dict(seed=np.int64(seed), mel_ar=mel_ar.numpy(), mel_diff=mel_df.numpy())
+	with torch.inference_mode():
+		out["ar_latent"] = uv.get_conditioning(mel_ar).numpy()
+		out["ar_latent_single"] = uv.get_conditioning(mel_ar[:, 0]).numpy()
+		out["diff_latent"] = df.get_conditioning(mel_df).numpy()
+		out["diff_latent_single"] = df.get_conditioning(mel_df[:, 0]).numpy()
+		if not full:
+			out["diff_embed"] = df.contextual_embedder(mel_df[:, 0]).numpy()
+	return out
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -268,6 +296,8 @@ def main():
 		("wrapper", lambda: wrapper_case(uv_mod)),
 		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
 		("clvp_small", lambda: clvp_case(W.CLVP_SMALL, 61)),
+		("cond_small", lambda: cond_case(d_mod, uv_mod, W.AR_SMALL, W.DIFF_SMALL, 71, b=2, n_clips=2, T_ar=37, T_diff=45, full=False)),
+		("cond_full", lambda: cond_case(d_mod, uv_mod, W.AR_FULL, W.DIFF_FULL, 72, b=1, n_clips=2, T_ar=70, T_diff=61, full=True)),
 	]
 	only = set(sys.argv[1:])
 	for name, fn in jobs:

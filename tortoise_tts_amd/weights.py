@@ -195,6 +195,30 @@ def diffusion_shapes(c: DiffusionConfig) -> Dict[str, Tuple[int, ...]]:
 	return s
 
 
+def ar_conditioning_shapes(c: ARConfig, spec_dim: int = 80, attn_blocks: int = 6) -> Dict[str, Tuple[int, ...]]:
+	"""`UnifiedVoice.conditioning_encoder` (ConditioningEncoder, models/unified_voice.py:269-293, built at :397 with
+	`num_attn_heads=heads`): 1x1 conv spec_dim -> model_dim, then AttentionBlocks without relative position bias."""
+	d = c.model_dim
+	s: Dict[str, Tuple[int, ...]] = {"conditioning_encoder.init.weight": (d, spec_dim, 1), "conditioning_encoder.init.bias": (d,)}
+	for i in range(attn_blocks):
+		blk = _attn_shapes(f"conditioning_encoder.attn.{i}.", d, c.heads)
+		s.update({k: v for k, v in blk.items() if "relative_pos" not in k})
+	return s
+
+
+def diffusion_conditioning_shapes(c: DiffusionConfig) -> Dict[str, Tuple[int, ...]]:
+	"""`DiffusionTTS.contextual_embedder` (models/diffusion.py:1441-1447): two stride-2 k=3 convs in_channels -> ch -> 2ch, then
+	five AttentionBlocks of 2ch channels and `num_heads` heads (head width 2ch / heads = 128) with relative position bias."""
+	ch = c.model_channels
+	s: Dict[str, Tuple[int, ...]] = {
+		"contextual_embedder.0.weight": (ch, c.in_channels, 3), "contextual_embedder.0.bias": (ch,),
+		"contextual_embedder.1.weight": (2 * ch, ch, 3), "contextual_embedder.1.bias": (2 * ch,),
+	}
+	for i in range(2, 7):
+		s.update(_attn_shapes(f"contextual_embedder.{i}.", 2 * ch, c.num_heads))
+	return s
+
+
 def vocoder_shapes(c: VocoderConfig) -> Dict[str, Tuple[int, ...]]:
 	"""`BigVGAN.state_dict()` with weight norm folded (plain `weight` instead of `weight_g` / `weight_v`) and without the constant
 	anti-aliasing filter buffers (identical for every Activation1d; recomputed, `vocoder.aa_filter`)."""
