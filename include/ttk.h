@@ -190,6 +190,30 @@ int ttk_clvp_destroy(ttk_clvp* h);
  * candidate, what `text_tokens.repeat(B, 1)` at inference.py:394 amounts to) or Bt == B; codes [B, M] int64 -> scores [B] f32.  */
 int ttk_clvp_score(ttk_clvp* h, const int64_t* text, int Bt, int Tt, const int64_t* codes, int B, int M, float* scores, void* stream);
 
+/* ------------------------------------------------------------------ conditioning-latent encoders
+ * One handle type for both: UnifiedVoice.conditioning_encoder (models/unified_voice.py:269-293: 1x1 conv 80 -> 1024, six AttentionBlocks of
+ * 16 heads, output = position 0) and DiffusionTTS.contextual_embedder (models/diffusion.py:1441-1447: two k=3 stride-2 convs 100 -> 1024 ->
+ * 2048, five AttentionBlocks of 16 heads x 128 with relative position bias; `get_conditioning` :1477-1485 takes the mean over positions).
+ * Weights under module-relative names, as tortoise_tts_amd/conditioning.py packs them from the parents' state_dict():
+ * "stem.{0,1}.weight" reshaped to [out, in * taps] and ".bias"; "blocks.{i}.norm|qkv|proj_out.weight|bias"; with relpos
+ * "blocks.{i}.__relbias" [heads, 129] (the bias of clamp(k - q, -64, 64), already scaled by sqrt(head width), models/xtransformers.py:179-188). */
+typedef struct ttk_cond ttk_cond;
+enum { TTK_COND_STEM_CONV1 = 0, TTK_COND_STEM_DOWN4 = 1 };
+typedef struct {
+	int in_channels;      /* mel bands: 80 (AR) / 100 (diffusion) */
+	int channels;         /* block width: 1024 / 2048; channels / num_heads must be 64 or 128 */
+	int num_heads;
+	int num_blocks;       /* 6 / 5 */
+	int stem;             /* TTK_COND_STEM_CONV1: one 1x1 conv; TTK_COND_STEM_DOWN4: k=3 stride-2 padding-1 convs in -> channels/2 -> channels */
+	int relpos;           /* blocks carry a relative position bias */
+	int pool;             /* 0: position 0 (ConditioningEncoder mean=False); 1: mean over positions */
+	int dtype;            /* TTK_F32 | TTK_BF16 */
+} ttk_cond_config;
+int ttk_cond_create(ttk_cond** out, const ttk_cond_config* cfg, const ttk_weight_view* weights, int n_weights);
+int ttk_cond_destroy(ttk_cond* h);
+/* one clip per batch row: mel f32 [b, in_channels, T] (the reference's channels-first layout) -> out f32 [b, channels] */
+int ttk_cond_encode(ttk_cond* h, const float* mel, int b, int T, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,9 @@ def __getattr__(name):   # lazy: importing the package must not need the built l
 	if name == "CLVP":
 		from .clvp import CLVP
 		return CLVP
+	if name in ("ConditioningEncoder", "ContextualEmbedder"):
+		from . import conditioning
+		return getattr(conditioning, name)
 	if name == "BigVGAN":
 		from .vocoder import BigVGAN
 		return BigVGAN

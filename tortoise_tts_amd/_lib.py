@@ -36,6 +36,10 @@ class DiffConfigC(C.Structure):
 		"model_channels", "num_layers", "in_channels", "in_latent_channels", "out_channels", "num_heads", "dtype")]
 
 
+class CondConfigC(C.Structure):
+	_fields_ = [(n, C.c_int) for n in ("in_channels", "channels", "num_heads", "num_blocks", "stem", "relpos", "pool", "dtype")]
+
+
 class StepC(C.Structure):
 	_fields_ = [("t", C.c_int64)] + [(n, C.c_float) for n in (
 		"sqrt_recip_ac", "sqrt_recipm1_ac", "sqrt_ac_prev", "sqrt_1m_ac_prev", "coef1", "coef2", "min_log", "max_log", "cfk")] + [
@@ -64,6 +68,9 @@ SYMBOLS = {
 	"ttk_clvp_create": (_I, [C.POINTER(_P), _P, C.POINTER(WeightView), _I]),
 	"ttk_clvp_destroy": (_I, [_P]),
 	"ttk_clvp_score": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P]),
+	"ttk_cond_create": (_I, [C.POINTER(_P), C.POINTER(CondConfigC), C.POINTER(WeightView), _I]),
+	"ttk_cond_destroy": (_I, [_P]),
+	"ttk_cond_encode": (_I, [_P, _P, _I, _I, _P, _P]),
 	"ttk_fp8_round_weights": (_I, [_P, _L, C.POINTER(C.c_float), _P]),
 	"ttk_sample_step": (_I, [_P, _L, _I, _I, _P, _L, _P, C.c_float, _L, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P]),
 	"ttk_diff_create": (_I, [C.POINTER(_P), C.POINTER(DiffConfigC), C.POINTER(WeightView), _I]),
