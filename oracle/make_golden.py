@@ -16,6 +16,7 @@ Fixtures
   diff_full.npz   full-size DiffusionTTS(): one forward (cond + uncond) at T=26
   cond_small.npz  UnifiedVoice.get_conditioning / DiffusionTTS.get_conditioning, small widths, 2 clips   (unified_voice.py:535-542,
   cond_full.npz   diffusion.py:1477-1485); full-size encoders at short clips
+  tokenizer.npz   VoiceBpeTokenizer.encode / decode / preprocess_text on the reference vocabulary, digit-free ASCII texts (tokenizer.py:154-177)
   schedule.npz    get_diffuser(steps) tables for steps in 4, 30, 80, 200    (diffusion.py:1576-1590)
 """
 import os
@@ -281,6 +282,58 @@ def cond_case(d_mod, uv_mod, ar_cfg, diff_cfg, seed, b, n_clips, T_ar, T_diff, f
 	return out
 
 
+TOKENIZER_TEXTS = [
+	"The quick brown fox jumps over the lazy dog.",
+	"Hello, world!  This is   a test -- of the emergency broadcast system; please stand by...",
+	"Mr. Smith and Mrs. Jones met Dr. Brown at St. Mary's, near Ft. Knox (Col. Mustard, Esq. was absent).",
+	"\"Quoted\" text: isn't it?  Yes/no; a_b and x-y/z!",
+	"supercalifragilisticexpialidocious antidisestablishmentarianism zzzz qqq xj",
+	"UPPER lower MiXeD\ttabs\nnewlines  ",
+	"",
+	" ",
+	"a",
+	"???!!!...,,,",
+	"[STOP] [UNK] [SPACE] [NOPE] ]x[ @#%^&*+=<>~`|{}",
+]
+
+
+def tokenizer_case():
+	"""The reference's VoiceBpeTokenizer (tokenizer.py:154-177) on its own vocabulary (data/tokenizer.json), for ASCII texts without
+	digits: `inflect` and `unidecode` are absent from this image, so they are stubbed at import (unidecode(ascii) is the identity by its
+	specification; number_to_words is never reached for digit-free text -- the stub raises if it is).  Stores the vocabulary as arrays."""
+	import importlib.util
+	import json
+	import types
+	inflect = types.ModuleType("inflect")
+	class _Engine:
+		def number_to_words(self, *a, **k):
+			raise AssertionError("digit-free fixtures only")
+	inflect.engine = _Engine
+	uni = types.ModuleType("unidecode")
+	def unidecode(text):
+		assert text.isascii(), "ASCII fixtures only"
+		return text
+	uni.unidecode = unidecode
+	sys.modules.setdefault("inflect", inflect)
+	sys.modules.setdefault("unidecode", uni)
+	spec = importlib.util.spec_from_file_location("_ref_tokenizer", "/root/reference/tortoise_tts/tokenizer.py")
+	mod = importlib.util.module_from_spec(spec)
+	spec.loader.exec_module(mod)
+	path = "/root/reference/data/tokenizer.json"
+	tok = mod.VoiceBpeTokenizer(path)
+	j = json.load(open(path))
+	rng = np.random.default_rng(81)
+	alphabet = list("abcdefghijklmnopqrstuvwxyz") + list("  ,.'-!?;:()/") + ["th", "the", "ing", "er", "ou", "and "]
+	texts = list(TOKENIZER_TEXTS) + ["".join(rng.choice(alphabet, size=int(n))) for n in rng.integers(1, 200, size=40)]
+	ids = [tok.encode(t) for t in texts]
+	vocab = sorted(j["model"]["vocab"].items(), key=lambda kv: kv[1])
+	assert [v for _, v in vocab] == list(range(len(vocab)))
+	return dict(texts=np.array(texts), ids=np.array([i for row in ids for i in row], dtype=np.int64), offsets=np.cumsum([0] + [len(r) for r in ids]),
+				cleaned=np.array([tok.preprocess_text(t) for t in texts]), decoded=np.array([tok.decode(np.array(r, dtype=np.int64)) for r in ids]),
+				vocab=np.array([k for k, _ in vocab]), merges=np.array([m if isinstance(m, str) else " ".join(m) for m in j["model"]["merges"]]),
+				special=np.array([a["content"] for a in j["added_tokens"]]))
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -296,6 +349,7 @@ def main():
 		("wrapper", lambda: wrapper_case(uv_mod)),
 		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
 		("clvp_small", lambda: clvp_case(W.CLVP_SMALL, 61)),
+		("tokenizer", tokenizer_case),
 		("cond_small", lambda: cond_case(d_mod, uv_mod, W.AR_SMALL, W.DIFF_SMALL, 71, b=2, n_clips=2, T_ar=37, T_diff=45, full=False)),
 		("cond_full", lambda: cond_case(d_mod, uv_mod, W.AR_FULL, W.DIFF_FULL, 72, b=1, n_clips=2, T_ar=70, T_diff=61, full=True)),
 	]
