@@ -214,6 +214,24 @@ int ttk_cond_destroy(ttk_cond* h);
 /* one clip per batch row: mel f32 [b, in_channels, T] (the reference's channels-first layout) -> out f32 [b, channels] */
 int ttk_cond_encode(ttk_cond* h, const float* mel, int b, int T, float* out, void* stream);
 
+/* ------------------------------------------------------------------ mel front-ends of the conditioning path
+ * TorchMelSpectrogram (models/arch_utils.py:361-395) and TacotronSTFT (:662-700 over STFT :560-623) as one handle type: reflect-padded
+ * frames x "basis" [2 * (n_fft/2 + 1), n_fft] (windowed DFT, Re rows then Im rows) -> |.|^power -> x "mel_basis" [n_mels, n_fft/2 + 1] ->
+ * log(max(., 1e-5)) [/ "mel_norms" [n_mels]].  tortoise_tts_amd/mel.py builds the matrices; arithmetic is f32 throughout. */
+typedef struct ttk_mel ttk_mel;
+typedef struct {
+	int n_fft;            /* 1024; multiple of 64; window length == n_fft */
+	int hop;              /* 256 */
+	int n_mels;           /* 80 (AR side, 22.05 kHz) / 100 (diffusion side, 24 kHz) */
+	int power;            /* 2: power spectrogram (TorchMelSpectrogram); 1: magnitude (TacotronSTFT) */
+	int clip;             /* clamp samples to [-1, 1] first (TacotronSTFT.mel_spectrogram :694) */
+	int has_norms;        /* divide band m of the log-mel by mel_norms[m] (:392-394) */
+} ttk_mel_config;
+int ttk_mel_create(ttk_mel** out, const ttk_mel_config* cfg, const ttk_weight_view* weights, int n_weights);
+int ttk_mel_destroy(ttk_mel* h);
+/* wav f32 [b, n] (n > n_fft / 2) -> mel f32 [b, n_mels, n / hop + 1] */
+int ttk_mel_forward(ttk_mel* h, const float* wav, int b, int n, float* mel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

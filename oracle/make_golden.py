@@ -16,9 +16,11 @@ Fixtures
   diff_full.npz   full-size DiffusionTTS(): one forward (cond + uncond) at T=26
   cond_small.npz  UnifiedVoice.get_conditioning / DiffusionTTS.get_conditioning, small widths, 2 clips   (unified_voice.py:535-542,
   cond_full.npz   diffusion.py:1477-1485); full-size encoders at short clips
+  stft_ref.npz    STFT(1024, 256, 1024).transform magnitudes on seeded audio (arch_utils.py:560-623)
   tokenizer.npz   VoiceBpeTokenizer.encode / decode / preprocess_text on the reference vocabulary, digit-free ASCII texts (tokenizer.py:154-177)
   schedule.npz    get_diffuser(steps) tables for steps in 4, 30, 80, 200    (diffusion.py:1576-1590)
 """
+import math
 import os
 import sys
 import time
@@ -334,6 +336,26 @@ def tokenizer_case():
 				special=np.array([a["content"] for a in j["added_tokens"]]))
 
 
+def stft_case(seed):
+	"""The reference's STFT.transform (arch_utils.py:560-623) -- the DFT-by-convolution TacotronSTFT sits on -- on seeded audio.
+	`librosa.util.pad_center` is absent; with win_length == filter_length (the only use, arch_utils.py:676) it returns its input, so it
+	is bound to that identity here.  Mel bases are not covered: librosa / torchaudio are absent (see oracle/mel_oracle.py)."""
+	import importlib
+	au = importlib.import_module("tortoise_tts.models.arch_utils")
+	def pad_center(x, size):
+		assert len(x) == size
+		return x
+	au.pad_center = pad_center
+	stft = au.STFT(1024, 256, 1024)
+	g = gen(seed)
+	n = 6000
+	t = torch.arange(n) / 24000.0
+	y = 0.4 * torch.sin(2 * math.pi * 440 * t)[None] + 0.1 * torch.sin(2 * math.pi * 5300 * t)[None] + 0.05 * torch.randn(2, n, generator=g)
+	with torch.inference_mode():
+		mag, _ = stft.transform(y)
+	return dict(seed=np.int64(seed), y=y.numpy(), magnitude=mag.numpy())
+
+
 def main():
 	os.makedirs(OUT, exist_ok=True)
 	torch.set_num_threads(8)
@@ -350,6 +372,7 @@ def main():
 		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
 		("clvp_small", lambda: clvp_case(W.CLVP_SMALL, 61)),
 		("tokenizer", tokenizer_case),
+		("stft_ref", lambda: stft_case(91)),
 		("cond_small", lambda: cond_case(d_mod, uv_mod, W.AR_SMALL, W.DIFF_SMALL, 71, b=2, n_clips=2, T_ar=37, T_diff=45, full=False)),
 		("cond_full", lambda: cond_case(d_mod, uv_mod, W.AR_FULL, W.DIFF_FULL, 72, b=1, n_clips=2, T_ar=70, T_diff=61, full=True)),
 	]

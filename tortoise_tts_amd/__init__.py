@@ -20,6 +20,9 @@ def __getattr__(name):   # lazy: importing the package must not need the built l
 	if name in ("ConditioningEncoder", "ContextualEmbedder"):
 		from . import conditioning
 		return getattr(conditioning, name)
+	if name in ("TorchMelSpectrogram", "TacotronSTFT"):
+		from . import mel
+		return getattr(mel, name)
 	if name == "VoiceBpeTokenizer":
 		from .tokenizer import VoiceBpeTokenizer
 		return VoiceBpeTokenizer
