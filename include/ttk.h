@@ -231,6 +231,10 @@ int ttk_mel_create(ttk_mel** out, const ttk_mel_config* cfg, const ttk_weight_vi
 int ttk_mel_destroy(ttk_mel* h);
 /* wav f32 [b, n] (n > n_fft / 2) -> mel f32 [b, n_mels, n / hop + 1] */
 int ttk_mel_forward(ttk_mel* h, const float* wav, int b, int n, float* mel, void* stream);
+/* torchaudio.functional.resample's polyphase FIR (emb/mel.py:67,86 resample clips to 22.05 kHz and 22.05 -> 24 kHz): rates reduced by their
+ * gcd to gorig -> gnew; kernels f32 [gnew, 2 * width + gorig] on the device (tortoise_tts_amd/mel.py builds the windowed-sinc table);
+ * wav f32 [b, n] -> out f32 [b, n_out], n_out = ceil(gnew * n / gorig).  Stateless. */
+int ttk_resample_fir(const float* wav, int b, int n, const float* kernels, int gorig, int gnew, int width, float* out, int n_out, void* stream);
 
 #ifdef __cplusplus
 }

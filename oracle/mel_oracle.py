@@ -91,3 +91,30 @@ def torch_mel_spectrogram(wav: Tensor, mel_norms: Tensor = None, n_fft=1024, hop
 	if mel_norms is not None:
 		mel = mel / mel_norms[None, :, None]
 	return mel
+
+
+def resample(waveform: Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> Tensor:
+	"""torchaudio.functional.resample (sinc_interp_hann), restated from its published source layout: gcd-reduced rates, windowed-sinc
+	kernel bank [new, 1, 2 * width + orig], zero padding (width, width + orig), conv1d with stride orig, interleave, crop to
+	ceil(new * n / orig).  torchaudio is absent here: **parity unpinned**; tests check it against exact band-limited interpolation."""
+	g = math.gcd(int(orig_freq), int(new_freq))
+	orig, new = int(orig_freq) // g, int(new_freq) // g
+	base_freq = min(orig, new) * rolloff
+	width = math.ceil(lowpass_filter_width * orig / base_freq)
+	rows = []
+	for p in range(new):
+		row = []
+		for j in range(-width, width + orig):
+			t = (-p / new + j / orig) * base_freq
+			t = max(-lowpass_filter_width, min(lowpass_filter_width, t))
+			win = math.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+			x = t * math.pi
+			row.append((1.0 if x == 0 else math.sin(x) / x) * win * base_freq / orig)
+		rows.append(row)
+	kernel = torch.tensor(rows, dtype=torch.float64)[:, None, :]
+	shape = waveform.shape
+	w = waveform.reshape(-1, shape[-1]).double()
+	n = w.shape[-1]
+	w = F.pad(w, (width, width + orig))
+	out = F.conv1d(w[:, None], kernel, stride=orig).transpose(1, 2).reshape(w.shape[0], -1)
+	return out[..., : int(math.ceil(new * n / orig))].float().reshape(*shape[:-1], -1)

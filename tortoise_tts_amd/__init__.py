@@ -23,6 +23,9 @@ def __getattr__(name):   # lazy: importing the package must not need the built l
 	if name in ("TorchMelSpectrogram", "TacotronSTFT"):
 		from . import mel
 		return getattr(mel, name)
+	if name == "TTS":
+		from .tts import TTS
+		return TTS
 	if name == "VoiceBpeTokenizer":
 		from .tokenizer import VoiceBpeTokenizer
 		return VoiceBpeTokenizer

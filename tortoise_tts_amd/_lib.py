@@ -74,6 +74,7 @@ SYMBOLS = {
 	"ttk_mel_create": (_I, [C.POINTER(_P), _P, C.POINTER(WeightView), _I]),
 	"ttk_mel_destroy": (_I, [_P]),
 	"ttk_mel_forward": (_I, [_P, _P, _I, _I, _P, _P]),
+	"ttk_resample_fir": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
 	"ttk_fp8_round_weights": (_I, [_P, _L, C.POINTER(C.c_float), _P]),
 	"ttk_sample_step": (_I, [_P, _L, _I, _I, _P, _L, _P, C.c_float, _L, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P]),
 	"ttk_diff_create": (_I, [C.POINTER(_P), C.POINTER(DiffConfigC), C.POINTER(WeightView), _I]),

@@ -59,6 +59,26 @@ __global__ __launch_bounds__(256) void k_mel_log(const float* __restrict__ m, in
 	out[i] = v;
 }
 
+// polyphase FIR resampling as torchaudio lays it out: output sample o = frame * gnew + phase reads K = 2 * width + gorig input samples
+// starting at frame * gorig - width (zeros outside the clip) against row `phase` of the kernel table
+__global__ __launch_bounds__(256) void k_resample_fir(const float* __restrict__ x, int n, const float* __restrict__ kernels, int gorig, int gnew,
+													  int width, int K, int n_out, int64_t total, float* __restrict__ out) {
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= total) return;
+	const int o = (int)(i % n_out);
+	const int64_t b = i / n_out;
+	const int phase = o % gnew, frame = o / gnew;
+	const int base = frame * gorig - width;
+	const float* kr = kernels + (int64_t)phase * K;
+	const float* xr = x + b * n;
+	float acc = 0.f;
+	for (int k = 0; k < K; ++k) {
+		const int j = base + k;
+		if (j >= 0 && j < n) acc += kr[k] * xr[j];
+	}
+	out[i] = acc;
+}
+
 }  // namespace
 
 struct ttk_mel {
@@ -139,6 +159,19 @@ int ttk_mel_forward(ttk_mel* h, const float* wav, int b, int n, float* mel, void
 		const int64_t total = (int64_t)b * c.n_mels * F;
 		hipLaunchKernelGGL(k_mel_log, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mraw, F, c.n_mels, h->norms, total, mel);
 	}
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+int ttk_resample_fir(const float* wav, int b, int n, const float* kernels, int gorig, int gnew, int width, float* out, int n_out, void* stream) {
+	TTK_REQUIRE(wav && kernels && out, TTK_E_ARG, "ttk_resample_fir: null argument");
+	TTK_REQUIRE(b >= 1 && n >= 1 && gorig >= 1 && gnew >= 1 && width >= 0 && n_out >= 1, TTK_E_ARG, "ttk_resample_fir: bad sizes (b=%d n=%d %d->%d width %d n_out=%d)",
+				b, n, gorig, gnew, width, n_out);
+	TTK_REQUIRE((int64_t)n_out <= ((int64_t)n / gorig + 1) * gnew, TTK_E_ARG, "ttk_resample_fir: n_out %d exceeds the %lld samples the clip yields", n_out,
+				(long long)(((int64_t)n / gorig + 1) * gnew));
+	const int64_t total = (int64_t)b * n_out;
+	hipLaunchKernelGGL(k_resample_fir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wav, n, kernels, gorig, gnew, width,
+					   2 * width + gorig, n_out, total, out);
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }

@@ -8,8 +8,9 @@ reference clip before the conditioning encoders --
 
 Both are "reflect-padded frames x windowed DFT matrix -> |.|^p -> mel matrix -> log" and run as two f32 GEMMs behind `ttk_mel_*`; this
 module builds the two matrices on the host in float64.  torchaudio and librosa are absent from this image: their filterbank definitions
-(torchaudio.functional.melscale_fbanks, librosa.filters.mel) are restated from their published formulas.  Resampling
-(`torchaudio.functional.resample`, emb/mel.py:67,86) is not provided: callers hand in 22.05 kHz / 24 kHz audio.
+(torchaudio.functional.melscale_fbanks, librosa.filters.mel) are restated from their published formulas, and so is the polyphase
+windowed-sinc resampler of `torchaudio.functional.resample` (emb/mel.py:67,86), which runs as one FIR kernel (`ttk_resample_fir`).
+`format_autoregressive_conditioning` / `format_diffusion_conditioning` / `encode` mirror emb/mel.py:50-109 on tensors (file IO stays outside).
 """
 from __future__ import annotations
 
@@ -73,6 +74,56 @@ def mel_basis_slaney(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float)
 	ramps = mel_f[:, None] - fftfreqs[None, :]
 	w = np.maximum(0.0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
 	return w * (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+	"""torchaudio.functional.resample's `_get_sinc_resample_kernel` (sinc_interp_hann) in f32, as `functional.resample` computes it for f32
+	audio: (kernels [gnew, 2 * width + gorig], width, gorig, gnew) for the gcd-reduced rates."""
+	g = math.gcd(int(orig_freq), int(new_freq))
+	orig, new = int(orig_freq) // g, int(new_freq) // g
+	base_freq = min(orig, new) * rolloff
+	width = math.ceil(lowpass_filter_width * orig / base_freq)
+	idx = torch.arange(-width, width + orig, dtype=torch.float32)[None, None] / orig
+	t = torch.arange(0, -new, -1, dtype=torch.float32)[:, None, None] / new + idx
+	t = t * base_freq
+	t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+	window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+	t = t * math.pi
+	scale = base_freq / orig
+	kernels = torch.where(t == 0, torch.tensor(1.0), t.sin() / t) * window * scale
+	return kernels.reshape(new, 2 * width + orig).contiguous(), width, orig, new
+
+
+@torch.inference_mode()
+def resample(wav: torch.Tensor, orig_freq: int, new_freq: int, device: str = "cuda:0") -> torch.Tensor:
+	"""`torchaudio.functional.resample(wav, orig_freq, new_freq)` (defaults: sinc_interp_hann, width 6, rolloff 0.99) on the GPU:
+	[..., n] -> [..., ceil(new * n / orig)] f32."""
+	if int(orig_freq) == int(new_freq):
+		return wav
+	dev = torch.device(device)
+	if dev.type != "cuda":
+		raise _lib.TTKError("tortoise_tts_amd runs on an MI355X only (device must be cuda:N)")
+	kernels, width, orig, new = sinc_resample_kernel(orig_freq, new_freq)
+	shape = wav.shape
+	x = wav.reshape(-1, shape[-1]).to(dev, torch.float32).contiguous()
+	b, n = x.shape
+	if b == 0 or n == 0:
+		raise _lib.TTKError("empty clip")
+	n_out = int(math.ceil(new * n / orig))
+	out = torch.empty(b, n_out, device=dev, dtype=torch.float32)
+	k = kernels.to(dev)
+	with torch.cuda.device(dev):
+		_lib.check(_lib.load().ttk_resample_fir(x.data_ptr(), b, n, k.data_ptr(), orig, new, width, out.data_ptr(), n_out, _lib.stream_ptr()), "ttk_resample_fir")
+	return out.reshape(*shape[:-1], n_out)
+
+
+def pad_or_truncate(t: torch.Tensor, length: int) -> torch.Tensor:
+	"""emb/mel.py:20-29."""
+	if t.shape[-1] == length:
+		return t
+	if t.shape[-1] < length:
+		return torch.nn.functional.pad(t, (0, length - t.shape[-1]))
+	return t[..., :length]
 
 
 class _MelFrontEnd:
@@ -155,3 +206,39 @@ class TacotronSTFT(_MelFrontEnd):
 		if y.numel() and (float(y.min()) < -10 or float(y.max()) > 10):
 			raise _lib.TTKError("audio outside [-10, 10] (arch_utils.py:692-693 asserts the same)")
 		return self._run(y)
+
+
+def format_autoregressive_conditioning(wav: torch.Tensor, tms: TorchMelSpectrogram, cond_length: int = 132300, rng=None) -> torch.Tensor:
+	"""emb/mel.py:50-65: wav [1, n] at 22.05 kHz, padded or randomly cropped to `cond_length` samples (0: whole clip) -> mel [1, 80, F].
+	`rng`: a `random.Random` for the crop offset (the reference draws from the global `random`)."""
+	import random
+	if cond_length > 0:
+		gap = wav.shape[-1] - cond_length
+		if gap < 0:
+			wav = torch.nn.functional.pad(wav, pad=(0, abs(gap)))
+		elif gap > 0:
+			start = (rng or random).randint(0, gap)
+			wav = wav[:, start:start + cond_length]
+	return tms(wav.unsqueeze(0)).squeeze(0).unsqueeze(0)
+
+
+def format_diffusion_conditioning(sample: torch.Tensor, stft: TacotronSTFT) -> torch.Tensor:
+	"""emb/mel.py:67-82: wav [1, n] at 22.05 kHz -> 24 kHz, padded / truncated to 102400 samples -> mel [1, 100, 401]."""
+	sample = resample(sample, 22050, 24000, device=str(stft.device))
+	sample = pad_or_truncate(sample, 102400)
+	return stft.mel_spectrogram(sample)
+
+
+@torch.inference_mode()
+def encode(wav: torch.Tensor, sr: int, *, tms: TorchMelSpectrogram, stft: TacotronSTFT, conditioning_encoder, contextual_embedder, rng=None) -> dict:
+	"""emb/mel.py:84-109 without the dvae codes (training data, not needed to speak): one mono clip [1, n] at `sr` ->
+	{"conds": (ar mel [1, 1, 80, F], diffusion mel [1, 1, 100, F']), "latent": ([1, 1024], [1, 2048]), "metadata": {...}}."""
+	n = wav.shape[-1]
+	wav = resample(wav, sr, 22050, device=str(tms.device))
+	ar_conds = torch.stack([format_autoregressive_conditioning(wav, tms, rng=rng)], dim=1)
+	diff_conds = torch.stack([format_diffusion_conditioning(wav, stft)], dim=1)
+	return {
+		"conds": (ar_conds, diff_conds),
+		"latent": (conditioning_encoder.get_conditioning(ar_conds), contextual_embedder.get_conditioning(diff_conds)),
+		"metadata": {"original_length": n, "sample_rate": sr, "duration": n / sr},
+	}
