@@ -166,3 +166,23 @@ def test_clvp_packing_and_shape_selection(golden):
 	broken = {k: v for k, v in sd.items() if k != "to_speech_latent.weight"}
 	with pytest.raises(ck.CheckpointError, match="to_speech_latent.weight"):
 		ck.select_hot_path(broken, W.clvp_shapes(cfg), "clvp")
+
+
+@pytest.mark.gpu
+def test_gpu_conditioning_encoders_from_checkpoint_files(golden, tmp_path):
+	"""whole-model files (hot-path + conditioning tensors side by side, wrapped under 'module') -> load_conditioning_encoder /
+	load_contextual_embedder -> the REFERENCE's get_conditioning outputs (tests/golden/cond_small.npz)"""
+	g = golden("cond_small")
+	seed = int(g["seed"])
+	ar_sd = W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 5) | W.synth_state_dict(W.ar_conditioning_shapes(W.AR_SMALL), seed)
+	df_sd = W.synth_state_dict(W.diffusion_shapes(W.DIFF_SMALL), 6) | W.synth_state_dict(W.diffusion_conditioning_shapes(W.DIFF_SMALL), seed + 1)
+	torch.save({"module": ar_sd, "config": {}}, tmp_path / "autoregressive.pth")
+	ck.save_state_dict(df_sd, tmp_path / "diffusion.safetensors")
+	enc = ck.load_conditioning_encoder(tmp_path / "autoregressive.pth", dtype="f32", device="cuda:0")
+	ctx = ck.load_contextual_embedder(tmp_path / "diffusion.safetensors", dtype="f32", device="cuda:0")
+	a = enc.get_conditioning(t(g["mel_ar"]).to("cuda:0"))
+	d = ctx.get_conditioning(t(g["mel_diff"]).to("cuda:0"))
+	assert (a.cpu() - t(g["ar_latent"])).abs().max().item() < 5e-4 and (d.cpu() - t(g["diff_latent"])).abs().max().item() < 5e-4
+	with pytest.raises(ck.CheckpointError, match="conditioning_encoder"):
+		ck.save_state_dict(W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 5), tmp_path / "bare.safetensors")
+		ck.load_conditioning_encoder(tmp_path / "bare.safetensors", dtype="f32", device="cuda:0")

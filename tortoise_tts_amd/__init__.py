@@ -4,7 +4,8 @@ exposed under the reference's own method names.  See DESIGN.md and INTEGRATION.m
 from .weights import ARConfig, CLVPConfig, DiffusionConfig, VocoderConfig  # noqa: F401
 
 __all__ = ["ARConfig", "DiffusionConfig", "UnifiedVoice", "DiffusionTTS", "get_diffuser", "denormalize_tacotron_mel",
-		   "load_autoregressive", "load_diffusion", "load_bigvgan", "load_clvp", "BigVGAN", "CLVP", "VocoderConfig", "CLVPConfig"]
+		   "load_autoregressive", "load_diffusion", "load_bigvgan", "load_clvp", "load_conditioning_encoder", "load_contextual_embedder", "BigVGAN", "CLVP",
+		   "VocoderConfig", "CLVPConfig", "ConditioningEncoder", "ContextualEmbedder", "TorchMelSpectrogram", "TacotronSTFT", "VoiceBpeTokenizer", "TTS"]
 
 
 def __getattr__(name):   # lazy: importing the package must not need the built library (CPU-side tools, oracle, weights)
@@ -32,7 +33,10 @@ def __getattr__(name):   # lazy: importing the package must not need the built l
 	if name == "BigVGAN":
 		from .vocoder import BigVGAN
 		return BigVGAN
-	if name in ("load_autoregressive", "load_diffusion", "load_bigvgan", "load_clvp"):
+	if name == "mel":
+		import importlib
+		return importlib.import_module(".mel", __name__)
+	if name in ("load_autoregressive", "load_diffusion", "load_bigvgan", "load_clvp", "load_conditioning_encoder", "load_contextual_embedder"):
 		from . import checkpoint
 		return getattr(checkpoint, name)
 	raise AttributeError(name)

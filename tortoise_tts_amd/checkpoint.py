@@ -251,6 +251,30 @@ def load_diffusion(path, *, dtype="bf16", device="cuda", **kw):
 	return DiffusionTTS(sd, cfg, dtype=dtype, device=device)
 
 
+def load_conditioning_encoder(path, lora_path=None, *, dtype="bf16", device="cuda", cfg: Optional[ARConfig] = None, state_dict_key: Optional[str] = None):
+	"""The `conditioning_encoder.*` tensors of `autoregressive.pth` -> `ConditioningEncoder` (`UnifiedVoice.get_conditioning`,
+	unified_voice.py:535-542).  The reference's LoRA only adapts modules under `gpt`; a LoRA file is accepted for symmetry and folded."""
+	from .conditioning import ConditioningEncoder
+	from .weights import ar_conditioning_shapes
+	sd = unwrap_state_dict(read_checkpoint(path), state_dict_key)
+	lora, scaling = read_lora(lora_path) if lora_path is not None else (None, None)
+	sd = materialize_lora(sd, lora, scaling=scaling)
+	cfg = cfg or infer_ar_config(sd)
+	n_blocks = _count_layers(sd, r"^conditioning_encoder\.attn\.(\d+)\.")
+	spec_dim = sd["conditioning_encoder.init.weight"].shape[1] if "conditioning_encoder.init.weight" in sd else 80
+	picked = select_hot_path(sd, ar_conditioning_shapes(cfg, spec_dim, n_blocks), "autoregressive (conditioning_encoder)")
+	return ConditioningEncoder(picked, cfg, dtype=dtype, device=device, spec_dim=spec_dim, attn_blocks=n_blocks)
+
+
+def load_contextual_embedder(path, *, dtype="bf16", device="cuda", cfg: Optional[DiffusionConfig] = None, state_dict_key: Optional[str] = None):
+	"""The `contextual_embedder.*` tensors of `diffusion.pth` -> `ContextualEmbedder` (`DiffusionTTS.get_conditioning`, diffusion.py:1477-1485)."""
+	from .conditioning import ContextualEmbedder
+	from .weights import diffusion_conditioning_shapes
+	sd = materialize_lora(unwrap_state_dict(read_checkpoint(path), state_dict_key))
+	cfg = cfg or infer_diffusion_config(sd)
+	return ContextualEmbedder(select_hot_path(sd, diffusion_conditioning_shapes(cfg), "diffusion (contextual_embedder)"), cfg, dtype=dtype, device=device)
+
+
 def load_bigvgan(path, *, cfg=None, dtype="bf16", device="cuda", state_dict_key: Optional[str] = "generator"):
 	"""`load_model("bigvgan")` (models/__init__.py:128-140): the generator's tensors sit under 'generator' in the upstream file; weight norm
 	is folded and the config defaults to the published bigvgan_24khz_100band values (weights.VocoderConfig: an assumption, the JSON is a
