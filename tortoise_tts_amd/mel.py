@@ -15,6 +15,7 @@ windowed-sinc resampler of `torchaudio.functional.resample` (emb/mel.py:67,86), 
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from typing import Optional
 
@@ -76,6 +77,7 @@ def mel_basis_slaney(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float)
 	return w * (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
 
 
+@functools.lru_cache(maxsize=16)
 def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
 	"""torchaudio.functional.resample's `_get_sinc_resample_kernel` (sinc_interp_hann) in f32, as `functional.resample` computes it for f32
 	audio: (kernels [gnew, 2 * width + gorig], width, gorig, gnew) for the gcd-reduced rates."""
@@ -92,6 +94,11 @@ def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: in
 	scale = base_freq / orig
 	kernels = torch.where(t == 0, torch.tensor(1.0), t.sin() / t) * window * scale
 	return kernels.reshape(new, 2 * width + orig).contiguous(), width, orig, new
+
+
+@functools.lru_cache(maxsize=16)
+def _device_kernels(orig_freq: int, new_freq: int, device: str) -> torch.Tensor:
+	return sinc_resample_kernel(orig_freq, new_freq)[0].to(device)
 
 
 @torch.inference_mode()
@@ -111,7 +118,7 @@ def resample(wav: torch.Tensor, orig_freq: int, new_freq: int, device: str = "cu
 		raise _lib.TTKError("empty clip")
 	n_out = int(math.ceil(new * n / orig))
 	out = torch.empty(b, n_out, device=dev, dtype=torch.float32)
-	k = kernels.to(dev)
+	k = _device_kernels(int(orig_freq), int(new_freq), str(dev))
 	with torch.cuda.device(dev):
 		_lib.check(_lib.load().ttk_resample_fir(x.data_ptr(), b, n, k.data_ptr(), orig, new, width, out.data_ptr(), n_out, _lib.stream_ptr()), "ttk_resample_fir")
 	return out.reshape(*shape[:-1], n_out)
