@@ -136,9 +136,9 @@ def main():
 	gdev = "cpu" if rehearsal else dev
 	gathered = [torch.empty((CANDIDATES, MEL_TOKENS), dtype=torch.long, device=gdev) for _ in range(world)] if world > 1 else None
 
-	def step():
+	def step(exchange=True):
 		mels, seconds, aux = tts.inference(text, ar_lat, df_lat, **kw)
-		if world > 1:   # hand the candidate ids to the scoring rank (RCCL all-gather over xGMI, 32 KB per rank)
+		if world > 1 and exchange:   # hand the candidate ids to the scoring rank (RCCL all-gather over xGMI, 32 KB per rank)
 			dist.all_gather(gathered, aux["codes"].contiguous().to(gdev))
 		return seconds
 
@@ -167,7 +167,7 @@ def main():
 	roof = None
 	if rank == 0 and not a.no_roofline:
 		from tortoise_tts_amd import profiling
-		roof = profiling.dominant_kernel_roofline(lambda: step(), ar, df)
+		roof = profiling.dominant_kernel_roofline(lambda: step(exchange=False), ar, df)   # rank 0 alone: no collective in here
 	# informational, never `value`: a stream of utterances with line i's diffusion overlapped with line i+1's sampling
 	# (TTSHotPath.inference_lines; identical results).  `value` above stays the one-utterance-at-a-time figure of configs[1].
 	piped = None
