@@ -9,6 +9,8 @@
           -> per (kernel, grid) average FETCH_SIZE / WRITE_SIZE per launch, read side corrected as MI355X_MICROARCH.md prescribes for
              gfx950 (FETCH_SIZE counts KB and under-reports 16-byte-per-lane coalesced streams by 2x), plus the launch-weighted
              k_skinny average bench.py reports as roofline.traffic.
+  MFMA / LDS passes (bash tests/diag/pmc_ddim.sh):
+      python profiles/summarize.py mfma BUSY_DIR LDS_DIR profiles/rNN_pmc_mfma.json
 """
 import csv
 import glob
@@ -87,8 +89,33 @@ def pmc(fetch_dir, write_dir, out):
 	print("k_skinny avg HBM bytes / launch:", res["k_skinny_avg_hbm_bytes_per_launch"], "over", sk_calls, "launches")
 
 
+def mfma(busy_dir, lds_dir, out):
+	"""MFMA utilisation and LDS bank-conflict share per kernel of the DDIM loop: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x
+	256 CUs x 4 SIMDs) and SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (separate --pmc runs)."""
+	busy, calls = _counter(busy_dir, "SQ_VALU_MFMA_BUSY_CYCLES")
+	active, _ = _counter(busy_dir, "GRBM_GUI_ACTIVE")
+	conf, _ = _counter(lds_dir, "SQ_LDS_BANK_CONFLICT")
+	idx, _ = _counter(lds_dir, "SQ_LDS_IDX_ACTIVE")
+	per = []
+	for k in sorted(busy, key=lambda k: -active.get(k, 0) * calls[k]):
+		if "ttk" not in k[0] or not active.get(k):
+			continue
+		per.append({"kernel": short(k[0]), "grid": k[1], "wg": k[2], "launches": calls[k],
+					"mfma_busy_cycles": int(busy[k]), "gui_active_cycles_per_xcd": int(active[k] / 8),
+					"mfma_util": round(busy[k] / (active[k] / 8 * 256 * 4), 4),
+					"lds_bank_conflict_share": round(conf.get(k, 0.0) / idx[k], 4) if idx.get(k) else None})
+	res = {"how": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE and, in a separate run, --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE over "
+				  "tests/diag/run_ddim.py 3 (bf16, T=1088, cond-free batch of 2); mfma_util = busy / (GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)",
+		   "per_kernel": per[:16]}
+	json.dump(res, open(out, "w"), indent=1)
+	for r in per[:8]:
+		print(r["kernel"][:60], r["grid"], "launches", r["launches"], "mfma_util", r["mfma_util"], "lds_conflict", r["lds_bank_conflict_share"])
+
+
 if __name__ == "__main__":
-	if len(sys.argv) == 4 and sys.argv[1] == "trace":
+	if len(sys.argv) == 5 and sys.argv[1] == "mfma":
+		mfma(sys.argv[2], sys.argv[3], sys.argv[4])
+	elif len(sys.argv) == 4 and sys.argv[1] == "trace":
 		trace(sys.argv[2], sys.argv[3])
 	elif len(sys.argv) == 5 and sys.argv[1] == "pmc":
 		pmc(sys.argv[2], sys.argv[3], sys.argv[4])
