@@ -1,7 +1,7 @@
 """Diagnostic (not a test): decode time per layer when all weights fit the 256 MiB Infinity Cache (8 layers) vs not (30)."""
 import sys, os, time, dataclasses
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tortoise_tts_amd import weights as W
 from tortoise_tts_amd.autoregressive import UnifiedVoice

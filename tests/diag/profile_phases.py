@@ -1,7 +1,7 @@
 """Diagnostic (not a test): wall time of each phase of the benchmark step."""
 import sys, os, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tortoise_tts_amd import weights as W
 from tortoise_tts_amd.autoregressive import UnifiedVoice

@@ -1,7 +1,7 @@
 """Diagnostic: K utterances through inference (sequential) vs inference_lines (AR of line i+1 overlapping DDIM of line i)."""
 import sys, os, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tortoise_tts_amd import weights as W
 from tortoise_tts_amd.autoregressive import UnifiedVoice
