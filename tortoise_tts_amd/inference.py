@@ -1,7 +1,8 @@
 """The hot-path section of `TTS.inference` (/root/reference/tortoise_tts/inference.py:331-413) over the libttk-backed
 modules: AR sampling -> stop-token fix-up -> latent pass -> calm-token trim -> [candidate pick] -> timestep-independent
-conditioning -> DDIM loop -> mel denormalisation.  Everything before (tokenizer, conditioning latents) and after (CLVP,
-vocoder) stays on the reference path and is represented here by its inputs/outputs.
+conditioning -> DDIM loop -> mel denormalisation.  What comes before (tokenizer, conditioning latents: tokenizer.py, mel.py,
+conditioning.py) and after (CLVP, vocoder: clvp.py, vocoder.py) is assembled around this class by `tortoise_tts_amd.tts.TTS`;
+here those stages appear as inputs (token ids, latents) and optional attachments (`clvp=`, `vocoder=`).
 """
 from __future__ import annotations
 

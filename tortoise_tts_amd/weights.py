@@ -168,7 +168,7 @@ def _resblock_shapes(p: str, ch: int):
 
 def diffusion_shapes(c: DiffusionConfig) -> Dict[str, Tuple[int, ...]]:
 	"""Hot-path subset of `DiffusionTTS.state_dict()` (contextual_embedder / code_converter /
-	code_embedding / mel_head are off-path: conditioning latents come from the reference path and
+	code_embedding / mel_head are off-path: conditioning latents are inputs here (`diffusion_conditioning_shapes` lists the encoder's tensors) and
 	aligned conditioning is always a latent at inference, inference.py:402)."""
 	ch = c.model_channels
 	s: Dict[str, Tuple[int, ...]] = {
