@@ -35,6 +35,7 @@ def parse():
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w"], help="fp8w = BASELINE config 5: bf16 arithmetic, block GEMM weights in fp8-e4m3")
+	ap.add_argument("--with-vocoder", action="store_true", help="BASELINE config 5's tail: the BigVGAN vocoder (bf16) inside the step; off for the headline metric")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-roofline", action="store_true")
 	ap.add_argument("--small", action="store_true", help="tiny models (plumbing check only; the number is NOT the metric)")
@@ -126,7 +127,12 @@ def main():
 	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(ar_cfg), 0), ar_cfg, dtype=a.dtype, device=dev, max_batch=CANDIDATES,
 					  max_ctx=TEXT_TOKENS + 4 + MEL_TOKENS + 8)
 	df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(df_cfg), 0), df_cfg, dtype=a.dtype, device=dev)
-	tts = TTSHotPath(ar, df)
+	voc = None
+	if a.with_vocoder:
+		from tortoise_tts_amd.vocoder import BigVGAN
+		vcfg = W.VOC_SMALL if a.small else W.VOC_FULL
+		voc = BigVGAN(W.synth_state_dict(W.vocoder_shapes(vcfg), 0), vcfg, dtype="f32" if a.dtype == "f32" else "bf16", device=dev)
+	tts = TTSHotPath(ar, df, vocoder=voc)
 	g = torch.Generator().manual_seed(1234 + rank)
 	text = torch.randint(1, 255, (1, TEXT_TOKENS), generator=g).to(dev)
 	ar_lat = torch.randn(1, ar_cfg.model_dim, generator=g).to(dev)
@@ -138,6 +144,8 @@ def main():
 
 	def step(exchange=True):
 		mels, seconds, aux = tts.inference(text, ar_lat, df_lat, **kw)
+		if voc is not None:
+			voc.inference(mels)
 		if world > 1 and exchange:   # hand the candidate ids to the scoring rank (RCCL all-gather over xGMI, 32 KB per rank)
 			dist.all_gather(gathered, aux["codes"].contiguous().to(gdev))
 		return seconds
@@ -197,7 +205,7 @@ def main():
 								   "latent pass on 16 candidates, 80 DDIM steps with cond-free guidance at T=1088 (11.6 s audio)",
 					   "text_tokens": TEXT_TOKENS, "candidates": CANDIDATES, "mel_tokens": MEL_TOKENS, "ddim_steps": DDIM_STEPS,
 					   "mel_frames": MEL_TOKENS * 4 * 24000 // 22050, "parallelism": f"utterances x{world}" if world > 1 else "single GPU",
-					   "small_models": bool(a.small)},
+					   "small_models": bool(a.small), "vocoder_in_step": bool(a.with_vocoder)},
 			"roofline": roof, "cpu_baseline": cpu, "pipelined_lines": piped,
 		}
 		print(json.dumps(line), flush=True)
