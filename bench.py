@@ -34,7 +34,8 @@ def parse():
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
-	ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w"], help="fp8w = BASELINE config 5: bf16 arithmetic, block GEMM weights in fp8-e4m3")
+	ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w", "fp8"],
+					help="BASELINE config 5 -- fp8w: bf16 arithmetic, block GEMM weights in fp8-e4m3; fp8: also fp8 activations into the diffusion block GEMMs (fp8 MFMA)")
 	ap.add_argument("--with-vocoder", action="store_true", help="BASELINE config 5's tail: the BigVGAN vocoder (bf16) inside the step; off for the headline metric")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-roofline", action="store_true")

@@ -29,8 +29,11 @@ extern "C" {
 enum { TTK_OK = 0, TTK_E_ARG = -1, TTK_E_HIP = -2, TTK_E_WEIGHT = -3, TTK_E_STATE = -4 };
 /* arithmetic mode: storage/MFMA operand type (accumulation is always f32).  TTK_FP8W (BASELINE config 5) = TTK_BF16 arithmetic with
  * the GEMM weights of the GPT-2 blocks / ResBlocks / AttentionBlocks rounded to fp8-e4m3 (OCP, round to nearest even) times a
- * power-of-two per-tensor scale; the KV-cached decode streams them as fp8 bytes, the dense GEMMs hold the same values in bf16. */
-enum { TTK_F32 = 0, TTK_BF16 = 1, TTK_FP8W = 2 };
+ * power-of-two per-tensor scale; the KV-cached decode streams them as fp8 bytes, the dense GEMMs hold the same values in bf16.
+ * TTK_FP8 (diffusion handle only) = TTK_FP8W with the ACTIVATION operand of the ResBlock / AttentionBlock GEMMs rounded to fp8-e4m3 as well
+ * (scale 1: they are GroupNorm outputs and attention outputs), those GEMMs running on the fp8 MFMA with f32 accumulation: the result is
+ * the TTK_BF16 arithmetic applied to operands rounded that way, up to f32 summation order. */
+enum { TTK_F32 = 0, TTK_BF16 = 1, TTK_FP8W = 2, TTK_FP8 = 3 };
 
 typedef struct {
 	const char* name;     /* reference state_dict key, e.g. "gpt.h.0.attn.c_attn.weight" */
@@ -113,7 +116,7 @@ typedef struct ttk_diff ttk_diff;
 
 typedef struct {
 	int model_channels, num_layers, in_channels, in_latent_channels, out_channels, num_heads;   /* diffusion.py:1392-1400 */
-	int dtype;
+	int dtype;                                /* TTK_F32 | TTK_BF16 | TTK_FP8W | TTK_FP8 */
 } ttk_diff_config;
 
 /* Besides the hot-path subset of DiffusionTTS.state_dict() (weights.py: diffusion_shapes) the caller passes two derived
@@ -213,6 +216,12 @@ int ttk_cond_create(ttk_cond** out, const ttk_cond_config* cfg, const ttk_weight
 int ttk_cond_destroy(ttk_cond* h);
 /* one clip per batch row: mel f32 [b, in_channels, T] (the reference's channels-first layout) -> out f32 [b, channels] */
 int ttk_cond_encode(ttk_cond* h, const float* mel, int b, int T, float* out, void* stream);
+
+/* ------------------------------------------------------------------ the dense GEMM kernel on caller-provided operands
+ * C f32 [M, N] = out_scale * A [M, K] . W [N, K]^T + bias, operands in `dtype`: f32, bf16, or TTK_FP8 = fp8-e4m3 bytes on the fp8 MFMA (out_scale
+ * then carries the tensor scale; 0 = none).  N % 128 == 0, K % 32 / 64 / 128 == 0.  No reference counterpart: exposed so the kernel behind every
+ * conv / linear of both networks can be tested against a plain matmul of the same operands. */
+int ttk_gemm_nt(int dtype, const void* A, const void* W, int M, int N, int K, float out_scale, const float* bias, float* C, void* stream);
 
 /* ------------------------------------------------------------------ mel front-ends of the conditioning path
  * TorchMelSpectrogram (models/arch_utils.py:361-395) and TacotronSTFT (:662-700 over STFT :560-623) as one handle type: reflect-padded

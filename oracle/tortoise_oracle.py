@@ -338,11 +338,25 @@ def rel_pos_bias(table: Tensor, i: int, j: int, scale: float) -> Tensor:
 	return table[bucket].permute(2, 0, 1) * scale
 
 
+# Operand rounding of the build's fp8 mode (include/ttk.h TTK_FP8), for tests that pin "fp8 mode == the same arithmetic on operands rounded to
+# fp8-e4m3": when set, the activation entering each ResBlock / AttentionBlock convolution passes through it.  None = the reference's arithmetic.
+BLOCK_OPERAND_ROUNDING = None
+
+
+def fp8_e4m3_round(x: Tensor) -> Tensor:
+	"""OCP e4m3 (torch.float8_e4m3fn), round to nearest even, saturating at +-448 like v_cvt_pk_fp8_f32."""
+	return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(x.dtype)
+
+
+def _q(x: Tensor) -> Tensor:
+	return x if BLOCK_OPERAND_ROUNDING is None else BLOCK_OPERAND_ROUNDING(x)
+
+
 def attention_block(w: W, p: str, x: Tensor, heads: int) -> Tensor:
 	"""arch_utils.py:136-190 AttentionBlock._forward + :59-94 QKVAttentionLegacy (head-major [H,3,ch]
 	channel split, q*s and k*s with s = ch^-1/4, softmax in float)."""
 	b, c, T = x.shape
-	qkv = F.conv1d(group_norm32(x, w[p + "norm.weight"], w[p + "norm.bias"]), w[p + "qkv.weight"], w[p + "qkv.bias"])
+	qkv = F.conv1d(_q(group_norm32(x, w[p + "norm.weight"], w[p + "norm.bias"])), w[p + "qkv.weight"], w[p + "qkv.bias"])
 	ch = c // heads
 	q, k, v = qkv.reshape(b * heads, ch * 3, T).split(ch, dim=1)
 	s = 1 / math.sqrt(math.sqrt(ch))
@@ -351,17 +365,17 @@ def attention_block(w: W, p: str, x: Tensor, heads: int) -> Tensor:
 	weight = (weight.reshape(b, heads, T, T) + bias).reshape(b * heads, T, T)
 	weight = torch.softmax(weight.float(), dim=-1)
 	a = torch.einsum("bts,bcs->bct", weight, v).reshape(b, -1, T)
-	return x + F.conv1d(a, w[p + "proj_out.weight"], w[p + "proj_out.bias"])
+	return x + F.conv1d(_q(a), w[p + "proj_out.weight"], w[p + "proj_out.bias"])
 
 
 def res_block(w: W, p: str, x: Tensor, emb: Tensor) -> Tensor:
 	"""diffusion.py:1316-1376 ResBlock(use_scale_shift_norm=True, efficient_config=True, kernel 3)."""
-	h = F.conv1d(F.silu(group_norm32(x, w[p + "in_layers.0.weight"], w[p + "in_layers.0.bias"])),
+	h = F.conv1d(_q(F.silu(group_norm32(x, w[p + "in_layers.0.weight"], w[p + "in_layers.0.bias"]))),
 				w[p + "in_layers.2.weight"], w[p + "in_layers.2.bias"])
 	e = F.linear(F.silu(emb), w[p + "emb_layers.1.weight"], w[p + "emb_layers.1.bias"])[..., None]
 	scale, shift = torch.chunk(e, 2, dim=1)
 	h = group_norm32(h, w[p + "out_layers.0.weight"], w[p + "out_layers.0.bias"]) * (1 + scale) + shift
-	h = F.conv1d(F.silu(h), w[p + "out_layers.3.weight"], w[p + "out_layers.3.bias"], padding=1)
+	h = F.conv1d(_q(F.silu(h)), w[p + "out_layers.3.weight"], w[p + "out_layers.3.bias"], padding=1)
 	return x + h
 
 

@@ -8,7 +8,7 @@ from tortoise_tts_amd import weights as W
 from tortoise_tts_amd.diffusion import DiffusionTTS, get_diffuser
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL, dtype="bf16", device=dev)
+df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL, dtype=os.environ.get("TTK_DDIM_DTYPE", "bf16"), device=dev)
 g = torch.Generator().manual_seed(1)
 T = 1088
 E = torch.randn(1, 1024, T, generator=g).to(dev)

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("TTK_LIB") or os.path.join(HERE, "libttk.so")   # TTK_
 
 TTK_F32, TTK_BF16 = 0, 1
 TTK_FP8W = 2
-DTYPES = {"f32": TTK_F32, "fp32": TTK_F32, "float32": TTK_F32, "bf16": TTK_BF16, "bfloat16": TTK_BF16, "fp8w": TTK_FP8W, "fp8": TTK_FP8W}
+TTK_FP8 = 3      # diffusion handle only: fp8 activations into the block GEMMs as well (fp8 MFMA); elsewhere it means fp8w
+DTYPES = {"f32": TTK_F32, "fp32": TTK_F32, "float32": TTK_F32, "bf16": TTK_BF16, "bfloat16": TTK_BF16, "fp8w": TTK_FP8W, "fp8": TTK_FP8}
 
 
 class TTKError(RuntimeError):
@@ -75,6 +76,7 @@ SYMBOLS = {
 	"ttk_mel_destroy": (_I, [_P]),
 	"ttk_mel_forward": (_I, [_P, _P, _I, _I, _P, _P]),
 	"ttk_resample_fir": (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _I, _P]),
+	"ttk_gemm_nt": (_I, [_I, _P, _P, _I, _I, _I, C.c_float, _P, _P, _P]),
 	"ttk_fp8_round_weights": (_I, [_P, _L, C.POINTER(C.c_float), _P]),
 	"ttk_sample_step": (_I, [_P, _L, _I, _I, _P, _L, _P, C.c_float, _L, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P]),
 	"ttk_diff_create": (_I, [C.POINTER(_P), C.POINTER(DiffConfigC), C.POINTER(WeightView), _I]),

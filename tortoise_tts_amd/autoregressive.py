@@ -31,6 +31,8 @@ class UnifiedVoice:
 			raise _lib.TTKError("tortoise_tts_amd runs on an MI355X only (device must be cuda:N)")
 		self.lib = _lib.load()
 		self.dtype = _lib.DTYPES[dtype]
+		if self.dtype == _lib.TTK_FP8:      # the decode GEMVs have 16 rows: fp8 activations buy nothing there; 'fp8' means fp8 weights
+			self.dtype = _lib.TTK_FP8W
 		self.max_batch = max_batch
 		self.max_ctx = max_ctx or (cfg.max_text_seq_len + 2 + cfg.max_mel_seq_len)
 		self.use_graph = use_graph

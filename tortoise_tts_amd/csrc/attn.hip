@@ -263,11 +263,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
 		const float inv = 1.0f / l;
 		const int qi = q0 + 16 * qt + li;
 		if (qi < p.T) {
-			T* dst = (T*)p.out + ((int64_t)b * p.T + qi) * p.ldo + h * HD;
+			if (p.out_f8) {      // operand of an fp8 projection GEMM: four consecutive head dims = one 32-bit store
+				unsigned char* dst = (unsigned char*)p.out + ((int64_t)b * p.T + qi) * p.ldo + h * HD;
 #pragma unroll
-			for (int dt = 0; dt < 4; ++dt)
+				for (int dt = 0; dt < 4; ++dt)
+					*(unsigned*)(dst + 16 * dt + 4 * g) = pack4_fp8(o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+			} else {
+				T* dst = (T*)p.out + ((int64_t)b * p.T + qi) * p.ldo + h * HD;
 #pragma unroll
-				for (int r = 0; r < 4; ++r) dst[16 * dt + 4 * g + r] = cvt<T>(o[qt][dt][r] * inv);
+				for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) dst[16 * dt + 4 * g + r] = cvt<T>(o[qt][dt][r] * inv);
+			}
 		}
 	}
 }

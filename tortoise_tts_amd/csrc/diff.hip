@@ -21,7 +21,8 @@ struct DLayer { ResBlk res; AttnBlk attn; };
 struct ttk_diff {
 	ttk_diff_config cfg;
 	int prefetch = 1;       // GroupNorm-apply launches touch the following GEMM's weights into L2 (TTK_DIFF_PREFETCH=0: off)
-	int dt, wdt;            // kernel arithmetic type / storage type of the block GEMM weights (== dt, or DT_FP8W)
+	int dt, wdt;            // kernel arithmetic type / storage type of the block GEMM weights (== dt, DT_FP8W or DT_FP8)
+	int a8 = 0;             // DT_FP8: the block GEMMs take fp8 activations too (written by GroupNorm-apply / attention) and run on the fp8 MFMA
 	size_t es;
 	Arena arena;
 	AttnBlk lat_attn[4];
@@ -54,8 +55,9 @@ static void gemm1(ttk_diff* h, const void* A, int64_t lda, const Mat& m, int M, 
 	g.nseg = 1; g.seg[0] = {A, lda, 0, 0};
 	g.W = m.w; g.ldw = m.Kpad; g.M = M; g.N = m.N; g.K = m.Kpad; g.bias = m.bias;
 	g.residual = residual; g.ldr = ldc; g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.act = act;
+	if (m.wes == 1) g.out_scale = m.wscale;      // fp8 operands (A is fp8 too: written by gn() / the attention for exactly these matrices)
 	want_stats(h, g, gn_T);
-	launch_gemm(h->dt, g, s);
+	launch_gemm(m.wes == 1 ? DT_FP8 : h->dt, g, s);
 }
 
 // k=3 'same' conv over rows inside each batch element: tap j multiplies row t + j - 1
@@ -66,8 +68,9 @@ static void gemm_conv3(ttk_diff* h, const void* A, int64_t lda, const Mat& m, in
 	for (int j = 0; j < 3; ++j) g.seg[j] = {A, lda, j - 1, (int64_t)j * m.Npad * m.Kpad};
 	g.W = m.w; g.ldw = m.Kpad; g.M = M; g.N = m.N; g.K = m.Kpad; g.rows_per_batch = Tper; g.bias = m.bias;
 	g.residual = residual; g.ldr = ldc; g.C = C; g.ldc = ldc; g.out_f32 = out_f32; g.transpose_out = transpose_out;
+	if (m.wes == 1) g.out_scale = m.wscale;
 	want_stats(h, g, gn_T);
-	launch_gemm(h->dt, g, s);
+	launch_gemm(m.wes == 1 ? DT_FP8 : h->dt, g, s);
 }
 
 static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, const float* beta, const float* scale, const float* shift,
@@ -78,7 +81,8 @@ static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, c
 	GnApplyParams p = {};
 	p.x = x; p.ms = (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
 	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.nchunks = gn_num_chunks(T, C); p.act = act; p.out = out; p.out_f32 = out_f32;
-	if (next && h->prefetch) { p.pf = next->w; p.pf_bytes = (int64_t)next->Npad * next->Kpad * h->es; p.pf_taps = next->ntap; }
+	if (next && h->prefetch) { p.pf = next->w; p.pf_bytes = (int64_t)next->Npad * next->Kpad * next->wes; p.pf_taps = next->ntap; }
+	if (next && next->wes == 1) p.out_f8 = 1;    // the consumer is an fp8 GEMM
 	launch_gn_apply(h->dt, p, s);
 }
 
@@ -90,7 +94,8 @@ static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, h
 	AttnParams a = {};
 	a.qkv = h->qkv.p; a.ld = 3 * C; a.q_off = 0; a.k_off = 64; a.v_off = 128; a.head_stride = 192;   // head-major [H][3][64], arch_utils.py:79
 	a.out = h->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f;
-	if (h->prefetch) { a.pf = A.proj.w; a.pf_bytes = (int64_t)A.proj.Npad * A.proj.Kpad * h->es; a.pf_taps = 1; }
+	if (h->prefetch) { a.pf = A.proj.w; a.pf_bytes = (int64_t)A.proj.Npad * A.proj.Kpad * A.proj.wes; a.pf_taps = 1; }
+	a.out_f8 = A.proj.wes == 1;
 	launch_attn_fwd(h->dt, a, s);
 	gemm1(h, h->ao.p, C, A.proj, rows, x, C, 1, ACT_NONE, x, s, T);
 }
@@ -192,11 +197,13 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	TTK_REQUIRE(cfg->in_latent_channels % 64 == 0, TTK_E_ARG, "ttk_diff_create: in_latent_channels %% 64 != 0");
 	TTK_REQUIRE(cfg->model_channels % 128 == 0 && cfg->model_channels <= 1024 && 1024 % cfg->model_channels == 0, TTK_E_ARG,
 				"ttk_diff_create: model_channels %d unsupported (128, 256, 512 or 1024)", cfg->model_channels);
-	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_FP8W, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
+	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_FP8W || cfg->dtype == TTK_FP8, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
+	TTK_REQUIRE(cfg->dtype != TTK_FP8 || cfg->model_channels % 128 == 0, TTK_E_ARG, "ttk_diff_create: fp8 GEMMs need channels %% 128 == 0");
 	ttk_diff* h = new ttk_diff();
 	h->cfg = *cfg;
 	h->wdt = cfg->dtype;              // ResBlock / AttentionBlock GEMM weights: rounded to fp8-e4m3 in DT_FP8W (held exactly in bf16)
 	h->dt = kernel_dtype(cfg->dtype);
+	h->a8 = cfg->dtype == TTK_FP8;
 	h->es = dtype_size(h->dt);
 	h->in_pad = round_up(cfg->in_channels, 64);
 	h->fuse_stats = getenv("TTK_NO_FUSED_GN") ? 0 : 1;

@@ -17,6 +17,8 @@
 // Roofline: MFMA-bound for the diffusion shapes (M = b*T ~ 2k rows, N,K in 1k..3k); bytes/flop is tiny.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include <hip/hip_ext.h>
 
 #include "ttk_common.h"
@@ -46,6 +48,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 template <typename T, int MODE, bool GUARD, int MI, int NI>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int row0, int col0, int lane) {
 	const int lr = 4 * (lane >> 4), lc = lane & 15;
+	typedef typename OutOf<T>::type OT;
+	if (p.out_scale != 0.f) {
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int j = 0; j < NI; ++j) acc[i][j] *= p.out_scale;
+	}
 	float bj[NI];
 #pragma unroll
 	for (int j = 0; j < NI; ++j) {
@@ -109,7 +118,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 				acc[i][j][r] = v;
 				if (MODE == 2) ((float*)p.C)[((int64_t)bb * p.N + gn) * p.rows_per_batch + t] = v;
 				else if (MODE == 1) ((float*)p.C)[(int64_t)gm * p.ldc + gn] = v;
-				else ((T*)p.C)[(int64_t)gm * p.ldc + gn] = cvt<T>(v);
+				else ((OT*)p.C)[(int64_t)gm * p.ldc + gn] = cvt<OT>(v);
 			}
 		}
 	}
@@ -148,9 +157,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	constexpr int ES = sizeof(T);
+	constexpr bool F8 = ES == 1;       // fp8 operands: a lane's 16-byte read feeds two 16x16x32 MFMAs (k order is free as long as A and W agree)
 	constexpr int BKE = 128 / ES;      // K elements per tile row
-	constexpr int KSTEPS = BKE / 32;   // MFMA k-steps per tile
-	constexpr int FCH = 8 * ES / 16;   // 16-byte chunks per fragment
+	constexpr int KSTEPS = F8 ? 2 : BKE / 32;   // fragment reads per row and tile (one MFMA k-step each; fp8: two)
+	constexpr int FCH = F8 ? 1 : 8 * ES / 16;   // 16-byte chunks per fragment
 	constexpr int EPC = 16 / ES;       // elements per chunk
 	constexpr int NW = NWM * NWN;
 	constexpr int WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 		const char* Bs = As + BM * 128;
 #pragma unroll
 		for (int ks = 0; ks < KSTEPS; ++ks) {
-			const int c0 = (ks * 32 + 8 * (lane >> 4)) / EPC;
+			const int c0 = F8 ? 4 * ks + (lane >> 4) : (ks * 32 + 8 * (lane >> 4)) / EPC;
 #pragma unroll
 			for (int i = 0; i < MI; ++i) {
 				const int row = wm * WM + 16 * i + (lane & 15);
@@ -274,10 +284,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 			for (int i = 0; i < MI; ++i)
 #pragma unroll
 				for (int j = 0; j < NI; ++j) {
-					union { FragT v; uint4 q[FCH]; } ua, ub;
+					if constexpr (F8) {
+						union { uint4 q; long l[2]; } ua, ub;
+						ua.q = fr.a[ks][i][0]; ub.q = fr.b[ks][j][0];
+						acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.l[0], ub.l[0], acc[i][j], 0, 0, 0);
+						acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.l[1], ub.l[1], acc[i][j], 0, 0, 0);
+					} else {
+						union { FragT v; uint4 q[FCH]; } ua, ub;
 #pragma unroll
-					for (int f = 0; f < FCH; ++f) { ua.q[f] = fr.a[ks][i][f]; ub.q[f] = fr.b[ks][j][f]; }
-					acc[i][j] = mma16<T>(ua.v, ub.v, acc[i][j]);
+						for (int f = 0; f < FCH; ++f) { ua.q[f] = fr.a[ks][i][f]; ub.q[f] = fr.b[ks][j][f]; }
+						acc[i][j] = mma16<typename std::conditional<F8, bf16, T>::type>(ua.v, ub.v, acc[i][j]);
+					}
 				}
 	};
 	// One pipeline step for tile kt (not the last) whose fragments are already in `cur`:
@@ -380,7 +397,8 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
 	hipEvent_t ea = nullptr, eb = nullptr;      // kernel start / stop timestamps when profiling (prof_pair)
 	if (g_prof_on) prof_pair(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, &ea, &eb);
-	if (dt == DT_BF16) launch_gemm_t<bf16>(p, s, ea, eb);
+	if (dt == DT_FP8) launch_gemm_t<f8>(p, s, ea, eb);          // A and W are fp8-e4m3 bytes, K % 128 == 0
+	else if (dt == DT_BF16) launch_gemm_t<bf16>(p, s, ea, eb);
 	else launch_gemm_t<float>(p, s, ea, eb);
 }
 

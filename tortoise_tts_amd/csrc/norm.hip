@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 		float o0 = xv[i].x * a0 + d0, o1 = xv[i].y * a1 + d1, o2 = xv[i].z * a2 + d2, o3 = xv[i].w * a3 + d3;
 		if (p.act == ACT_SILU) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
 		OT* dst = (OT*)p.out + ((int64_t)b * p.Tout + to) * p.C + c;
-		if (sizeof(OT) == 2) {
+		if (sizeof(OT) == 1) {
+			*(unsigned*)dst = pack4_fp8(o0, o1, o2, o3);
+		} else if (sizeof(OT) == 2) {
 			union { bf16x4 v; uint2 u; } pk;
 			pk.v = bf16x4{(bf16)o0, (bf16)o1, (bf16)o2, (bf16)o3};
 			*(uint2*)dst = pk.u;
@@ -193,10 +195,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 }
 
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
-	ProfScope prof(PROF_GN_APPLY, (double)p.nb * p.Tout * p.C * (4.0 + (p.out_f32 ? 4.0 : dtype_size(dt))), s);
+	ProfScope prof(PROF_GN_APPLY, (double)p.nb * p.Tout * p.C * (4.0 + (p.out_f8 ? 1.0 : p.out_f32 ? 4.0 : dtype_size(dt))), s);
 	const int strip = (256 / (p.C / 4)) * GN_PASSES;
 	const int grid = p.nb * ((p.Tout + strip - 1) / strip);
-	if (p.out_f32 || dt == DT_F32) hipLaunchKernelGGL((k_gn_apply<float>), dim3(grid), dim3(256), 0, s, p);
+	if (p.out_f8) hipLaunchKernelGGL((k_gn_apply<f8>), dim3(grid), dim3(256), 0, s, p);
+	else if (p.out_f32 || dt == DT_F32) hipLaunchKernelGGL((k_gn_apply<float>), dim3(grid), dim3(256), 0, s, p);
 	else hipLaunchKernelGGL((k_gn_apply<bf16>), dim3(grid), dim3(256), 0, s, p);
 }
 

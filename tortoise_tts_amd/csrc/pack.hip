@@ -99,6 +99,29 @@ __global__ void k_fp8_roundtrip(float* x, int64_t n, float scale, float inv) {
 void launch_fp8_roundtrip(float* x, int64_t n, float scale, hipStream_t s) {
 	hipLaunchKernelGGL(k_fp8_roundtrip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, scale, 1.0f / scale);
 }
+// the dense fp8 GEMM's weight operand: same index mapping as k_pack_nk, one fp8-e4m3 byte per element (value / scale, exact: the source was
+// rounded to scale * fp8 grid by k_fp8_roundtrip)
+__global__ void k_pack_nk_f8(const float* src, int layout, int N, int K, int Npad, int Kpad, int ntap, float inv, unsigned char* dst) {
+	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int64_t per = (int64_t)Npad * Kpad;
+	if (idx >= ntap * per) return;
+	const int tap = (int)(idx / per);
+	const int64_t r = idx - tap * per;
+	const int n = (int)(r / Kpad), k = (int)(r - (int64_t)n * Kpad);
+	float v = 0.f;
+	if (n < N && k < K) {
+		if (layout == PK_NK) v = src[(int64_t)n * K + k];
+		else if (layout == PK_KN) v = src[(int64_t)k * N + n];
+		else if (layout == PK_CONVT) v = src[((int64_t)k * N + n) * ntap + tap];
+		else v = src[((int64_t)n * K + k) * ntap + tap];
+	}
+	dst[idx] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v * inv, 0.f, 0, false) & 0xff);
+}
+void launch_pack_nk_f8(const float* src, int layout, int N, int K, int Npad, int Kpad, float scale, void* dst, hipStream_t s, int ntap) {
+	if (ntap <= 0) ntap = layout == PK_CONV3 ? 3 : 1;
+	const int64_t total = (int64_t)ntap * Npad * Kpad;
+	hipLaunchKernelGGL(k_pack_nk_f8, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, ntap, 1.0f / scale, (unsigned char*)dst);
+}
 // [Npad][K] bf16 (values = fp8 grid * scale) -> Wp8[n_tile][k_step][lane][8 bytes], same element order as k_pack_frag
 __global__ void k_pack_frag_fp8(const bf16* src, int Npad, int K, float inv, unsigned char* dst) {
 	const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;      // two elements (one 16-bit half) per thread

@@ -20,6 +20,19 @@ namespace ttk {
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x8 type; };
 template <> struct Frag<bf16> { typedef bf16x8 type; };
+// fp8-e4m3 (OCP) storage tag for the dense GEMM's operands in the fp8 mode of the diffusion network: one byte per element; a lane's
+// 16-byte LDS read then holds its k elements for TWO v_mfma_f32_16x16x32_fp8_fp8 steps (low / high 8 bytes).
+struct f8 { unsigned char v; };
+template <> struct Frag<f8> { typedef uint4 type; };
+// what a "T-typed" output means: the arithmetic type itself, bf16 for fp8 operands
+template <typename T> struct OutOf { typedef T type; };
+template <> struct OutOf<f8> { typedef bf16 type; };
+// four f32 -> four fp8-e4m3 bytes (v_cvt_pk_fp8_f32: round to nearest even, saturating at +-448), element 0 in the low byte
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+	int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+	w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+	return (unsigned)w;
+}
 
 template <typename T>
 __device__ __forceinline__ f32x4 mma16(typename Frag<T>::type a, typename Frag<T>::type b, f32x4 c);

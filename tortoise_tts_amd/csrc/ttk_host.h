@@ -86,6 +86,7 @@ struct Mat {
 	void* wfrag = nullptr;  // [Npad/16][Kpad/32][64][8], decode path only (one byte per element when w8)
 	bool w8 = false;        // DT_FP8W: weights rounded to fp8-e4m3 * wscale; `w` holds them exactly in bf16, `wfrag` as fp8 bytes
 	float wscale = 1.f;
+	int wes = 2;            // bytes per element of `w` (1: DT_FP8, the dense GEMM reads fp8 bytes and applies wscale in its epilogue)
 	float* bias = nullptr;
 	int N = 0, K = 0, Npad = 0, Kpad = 0, ntap = 1;
 };

@@ -32,10 +32,11 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 				(long long)numel(v), (long long)N * K * ntap);
 	out->N = N; out->K = K; out->ntap = ntap;
 	out->Npad = round_up(N, 128);
-	out->Kpad = round_up(K, 64);
-	const bool w8 = dt == DT_FP8W;
+	out->Kpad = round_up(K, dt == DT_FP8 ? 128 : 64);
+	const bool w8 = dt == DT_FP8W || dt == DT_FP8;
 	const int kdt = kernel_dtype(dt);
-	const size_t es = dtype_size(kdt);
+	const size_t es = dt == DT_FP8 ? 1 : dtype_size(kdt);
+	out->wes = (int)es;
 	float* tmp = nullptr;
 	TTK_HIP(hipMalloc((void**)&tmp, (size_t)numel(v) * sizeof(float)));
 	hipError_t e = hipMemcpy(tmp, v->data, (size_t)numel(v) * sizeof(float), hipMemcpyDefault);
@@ -50,8 +51,9 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 	const size_t wbytes = (size_t)ntap * out->Npad * out->Kpad * es;
 	int rc = ar.alloc(&out->w, wbytes);
 	if (rc == TTK_OK) {
-		launch_pack_nk(kdt, tmp, layout, N, K, out->Npad, out->Kpad, out->w, 0, ntap);
-		if (frag && ntap == 1) {
+		if (dt == DT_FP8) launch_pack_nk_f8(tmp, layout, N, K, out->Npad, out->Kpad, out->wscale, out->w, 0, ntap);
+		else launch_pack_nk(kdt, tmp, layout, N, K, out->Npad, out->Kpad, out->w, 0, ntap);
+		if (frag && ntap == 1 && dt != DT_FP8) {
 			rc = ar.alloc(&out->wfrag, w8 ? wbytes / 2 : wbytes);
 			if (rc == TTK_OK) {
 				if (w8) launch_pack_frag_fp8(out->w, out->Npad, out->Kpad, out->wscale, out->wfrag, 0);
@@ -126,5 +128,21 @@ extern "C" int ttk_fp8_round_weights(float* x, int64_t n, float* scale_out, void
 	launch_fp8_roundtrip(x, n, s, (hipStream_t)stream);
 	TTK_HIP(hipGetLastError());
 	if (scale_out) *scale_out = s;
+	return TTK_OK;
+}
+
+// The dense NT GEMM on caller-provided operands: kernel-level numerics tests (a plain f32 matmul of the same operands is the reference) and tuning.
+extern "C" int ttk_gemm_nt(int dtype, const void* A, const void* W, int M, int N, int K, float out_scale, const float* bias, float* C, void* stream) {
+	using namespace ttk;
+	TTK_REQUIRE(A && W && C, TTK_E_ARG, "ttk_gemm_nt: null argument");
+	TTK_REQUIRE(dtype == TTK_F32 || dtype == TTK_BF16 || dtype == TTK_FP8, TTK_E_ARG, "ttk_gemm_nt: dtype must be TTK_F32, TTK_BF16 or TTK_FP8 (fp8-e4m3 bytes), got %d", dtype);
+	const int kmul = dtype == TTK_FP8 ? 128 : (dtype == TTK_BF16 ? 64 : 32);
+	TTK_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && K >= kmul && K % kmul == 0, TTK_E_ARG,
+				"ttk_gemm_nt: need M >= 1, N %% 128 == 0, K %% %d == 0 (got M=%d N=%d K=%d)", kmul, M, N, K);
+	GemmParams g = {};
+	g.nseg = 1; g.seg[0] = {A, K, 0, 0};
+	g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias; g.C = C; g.ldc = N; g.out_f32 = 1; g.out_scale = out_scale;
+	launch_gemm(dtype, g, (hipStream_t)stream);
+	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }

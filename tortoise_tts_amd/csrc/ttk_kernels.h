@@ -9,9 +9,11 @@ namespace ttk {
 
 // DT_FP8W (handles only): bf16 activations and arithmetic, GEMM weights rounded to fp8-e4m3 with a power-of-two per-tensor scale; the
 // decode GEMVs stream the weights as fp8 bytes.  Kernels are launched with DT_BF16 plus a per-matrix flag.
-enum DType { DT_F32 = 0, DT_BF16 = 1, DT_FP8W = 2 };
+// DT_FP8 (diffusion handle only): as DT_FP8W, and the ResBlock / AttentionBlock GEMMs take their ACTIVATION operand in fp8-e4m3 as well
+// (written by the GroupNorm-apply and attention kernels) and run on v_mfma_f32_16x16x32_fp8_fp8; launch_gemm accepts DT_FP8 for those.
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_FP8W = 2, DT_FP8 = 3 };
 inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
-inline int kernel_dtype(int dt) { return dt == DT_FP8W ? DT_BF16 : dt; }
+inline int kernel_dtype(int dt) { return (dt == DT_FP8W || dt == DT_FP8) ? DT_BF16 : dt; }
 
 // ---------------------------------------------------------------- per-kernel timing (ttk_host.hip)
 // When enabled (ttk_prof_begin) every launcher brackets its launch with two HIP events on the launch stream and adds its
@@ -55,7 +57,8 @@ struct GemmParams {
 	void* C;
 	int64_t ldc;
 	int act;            // ttk::Act
-	int out_f32;        // C is f32 (else T)
+	float out_scale;    // 0 = none; else the accumulators are multiplied by it before the bias (the fp8 weights' power-of-two tensor scale)
+	int out_f32;        // C is f32 (else T; bf16 when the operands are fp8)
 	int transpose_out;  // C is f32 [M / rows_per_batch][N][rows_per_batch]
 	// optional fused GroupNorm32 statistics of the f32 output (see gemm_fuses_gn_stats): part[b][32][gn_T / 64][3]
 	float* gn_part; int gn_T;
@@ -112,6 +115,7 @@ struct GnApplyParams {
 	const float* x; const float* ms; const float* gamma; const float* beta;
 	const float* scale; const float* shift; int64_t ss_stride;   // per-batch stride of scale/shift rows (0 = shared)
 	const int* row_idx; int nb, T, Tout, C; int nchunks; int act; void* out; int out_f32;
+	int out_f8;        // out is fp8-e4m3 bytes (operand of an fp8 GEMM); overrides out_f32
 	// optional: weights of the GEMM that consumes this output, touched so that they sit in L2 when it starts.  The matrix is `pf_taps`
 	// blocks of `pf_bytes` each; block bytes are split into 8 equal slices, slice x = the n-range the GEMM's tile order gives XCD x, and
 	// the workgroups on XCD x (blockIdx % 8) touch one 128-byte line per thread of their share of slice x.
@@ -124,6 +128,7 @@ struct AttnParams {
 	const void* qkv; int64_t ld;          // T [nb*T][ld]
 	int q_off, k_off, v_off, head_stride; // column of (h, d) = off + h*head_stride + d ; head_dim is 64
 	void* out; int64_t ldo;               // T [nb*T][ldo], column h*64 + d
+	int out_f8;                           // out is fp8-e4m3 bytes instead of T (operand of an fp8 GEMM; bf16 kernel only)
 	int nb, T, H, causal;
 	const float* bias;                    // [H][129] relative-position bias (already scaled) or null
 	float scale;                          // multiplies q.k
@@ -180,6 +185,7 @@ enum PackLayout { PK_NK = 0, PK_KN = 1, PK_CONV3 = 2, PK_CONVK = 3, PK_CONVT = 4
 int device_absmax(const float* x, int64_t n, float* out_host);
 void launch_fp8_roundtrip(float* x, int64_t n, float scale, hipStream_t s);
 void launch_pack_frag_fp8(const void* src_bf16, int Npad, int K, float scale, void* dst, hipStream_t s);
+void launch_pack_nk_f8(const float* src, int layout, int N, int K, int Npad, int Kpad, float scale, void* dst, hipStream_t s, int ntap = 0);
 float fp8_scale_for(float absmax);
 // src f32 -> dst T [ntap][Npad][Kpad] (zero padded)
 void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s, int ntap = 0);
