@@ -147,3 +147,27 @@ def test_fp8_diffusion_is_the_arithmetic_on_fp8_rounded_operands(golden):
 	mel = get_diffuser(steps=4, cond_free=True).sample_loop(m8, (1, 100, int(g["T"])), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E[:1].to(DEV)})
 	mel_w = get_diffuser(steps=4, cond_free=True).sample_loop(mw, (1, 100, int(g["T"])), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E[:1].to(DEV)})
 	assert torch.isfinite(mel).all() and relerr(mel, mel_w) < 0.15
+
+
+def test_fp8_full_size_network_evaluation():
+	"""the 292 M-parameter network at the benchmark's frame count, one cond + cond-free evaluation: the fp8 mode stays within 0.1 relative L2 of
+	the weight-only mode and of bf16, finite and repeatable (every block GEMM here is K = 1024 or 3 x 1024 on the fp8 MFMA)"""
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	cfg = W.DIFF_FULL
+	sd = W.synth_state_dict(W.diffusion_shapes(cfg), 41)
+	g = torch.Generator().manual_seed(4)
+	T = 1088
+	x = torch.randn(1, 100, T, generator=g).to(DEV)
+	E = torch.randn(1, 1024, T, generator=g).to(DEV)
+	t = torch.tensor([2345]).to(DEV)
+	ys = {}
+	for dt in ("fp8", "fp8w", "bf16"):
+		m = DiffusionTTS(sd, cfg, dtype=dt, device=DEV)
+		ys[dt] = (m(x, t, precomputed_aligned_embeddings=E), m(x, t, precomputed_aligned_embeddings=E, conditioning_free=True))
+		if dt == "fp8":
+			assert torch.equal(ys[dt][0], m(x, t, precomputed_aligned_embeddings=E))
+		del m
+	for i in range(2):
+		assert torch.isfinite(ys["fp8"][i]).all()
+		assert relerr(ys["fp8"][i], ys["fp8w"][i]) < 0.1 and relerr(ys["fp8"][i], ys["bf16"][i]) < 0.1
+		assert relerr(ys["fp8"][i], ys["fp8w"][i]) > 1e-3
