@@ -34,7 +34,7 @@ struct ttk_diff {
 	int n_emb;               // number of ResBlocks = rows of emb_cat / 2C
 	int in_pad;              // in_channels rounded up to 64
 	// workspaces
-	WsBuf cs, xs, hf, a, qkv, ao, h0, csT, xcl, outb, ecl, ms, temb, e1, e2, se, emb_all, lat_T;
+	WsBuf cs, xs, hf, a, qkv, ao, h0, csT, xcl, outb, ecl, ms, ms_ecl, temb, e1, e2, se, emb_all, lat_T;
 	int cur_b = 0, cur_T = 0, staged = 0;
 	const void* ms_owner = nullptr;   // tensor whose GroupNorm statistics currently sit in `ms` (written by a GEMM epilogue)
 	int fuse_stats = 1;
@@ -74,12 +74,15 @@ static void gemm_conv3(ttk_diff* h, const void* A, int64_t lda, const Mat& m, in
 }
 
 static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, const float* beta, const float* scale, const float* shift,
-			   int64_t ss_stride, int act, void* out, int out_f32, const int* row_idx, int Tout, hipStream_t s, const Mat* next = nullptr) {
+			   int64_t ss_stride, int act, void* out, int out_f32, const int* row_idx, int Tout, hipStream_t s, const Mat* next = nullptr,
+			   const float* ms_pre = nullptr) {
 	const int C = h->cfg.model_channels;
-	if (h->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);   // else: left by the producing GEMM
-	h->ms_owner = nullptr;
+	if (!ms_pre) {
+		if (h->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);   // else: left by the producing GEMM
+		h->ms_owner = nullptr;
+	}
 	GnApplyParams p = {};
-	p.x = x; p.ms = (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
+	p.x = x; p.ms = ms_pre ? ms_pre : (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
 	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.nchunks = gn_num_chunks(T, C); p.act = act; p.out = out; p.out_f32 = out_f32;
 	if (next && h->prefetch) { p.pf = next->w; p.pf_bytes = (int64_t)next->Npad * next->Kpad * next->wes; p.pf_taps = next->ntap; }
 	if (next && next->wes == 1) p.out_f8 = 1;    // the consumer is an fp8 GEMM
@@ -101,13 +104,17 @@ static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, h
 }
 
 // x = x + conv3(SiLU(GN(conv1(SiLU(GN(x)))) * (1 + scale) + shift))        diffusion.py:1363-1376
-static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, const float* emb_all, int64_t emb_stride, hipStream_t s) {
+// x_in (with its precomputed GroupNorm statistics ms_in): the block reads its input there and writes x -- the first integrator block of a
+// sampler step reads the staged code embedding directly instead of a per-step copy of it
+static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, const float* emb_all, int64_t emb_stride, hipStream_t s,
+					  const float* x_in = nullptr, const float* ms_in = nullptr) {
 	const int C = h->cfg.model_channels, rows = nb * T;
-	gn(h, x, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s, &R.in);
+	const float* src = x_in ? x_in : x;
+	gn(h, src, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s, &R.in, ms_in);
 	gemm1(h, h->a.p, C, R.in, rows, h->hf.p, C, 1, ACT_NONE, nullptr, s, T);
 	const float* sc = emb_all + (int64_t)R.emb_slot * 2 * C;
 	gn(h, (const float*)h->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->a.p, 0, nullptr, T, s, &R.out3);
-	gemm_conv3(h, h->a.p, C, R.out3, rows, T, x, C, 1, x, 0, s, T);
+	gemm_conv3(h, h->a.p, C, R.out3, rows, T, x, C, 1, src, 0, s, T);
 }
 
 static int reserve_ws(ttk_diff* h, int nb, int T) {
@@ -138,12 +145,13 @@ static int time_path(ttk_diff* h, const int64_t* t_dev, const int64_t* t_host, i
 
 // The network body on nb sequences of T frames.  Inputs: h->xcl (T-typed [nb*T][in_pad]) and h->cs (f32 code embedding stream
 // [nb*T][C], consumed); emb rows at emb_all + b * emb_stride.  Output: out f32 [nb][out_channels][T].     diffusion.py:1549-1564
-static void network(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, float* out, hipStream_t s) {
+static void network(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, float* out, hipStream_t s,
+					const float* cs_in = nullptr, const float* ms_in = nullptr) {
 	const int C = h->cfg.model_channels, rows = nb * T;
 	float* cs = (float*)h->cs.p;
 	float* x = (float*)h->xs.p;
 	for (int i = 0; i < 3; ++i) {
-		res_block(h, h->integrator[i].res, cs, nb, T, emb_all, emb_stride, s);
+		res_block(h, h->integrator[i].res, cs, nb, T, emb_all, emb_stride, s, i == 0 ? cs_in : nullptr, i == 0 ? ms_in : nullptr);
 		attn_block(h, h->integrator[i].attn, cs, nb, T, s);
 	}
 	gemm_conv3(h, h->xcl.p, h->in_pad, h->inp_block, rows, T, h->h0.p, C, 0, nullptr, 0, s);
@@ -253,7 +261,7 @@ int ttk_diff_destroy(ttk_diff* h) {
 	if (!h) return TTK_OK;
 	(void)hipDeviceSynchronize();
 	WsBuf* all[] = {&h->cs, &h->xs, &h->hf, &h->a, &h->qkv, &h->ao, &h->h0, &h->csT, &h->xcl, &h->outb, &h->ecl, &h->ms,
-					&h->temb, &h->e1, &h->e2, &h->se, &h->emb_all, &h->lat_T};
+					&h->temb, &h->e1, &h->e2, &h->se, &h->emb_all, &h->lat_T, &h->ms_ecl};
 	for (WsBuf* b : all) b->release();
 	h->arena.release();
 	delete h;
@@ -305,6 +313,9 @@ int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream) {
 	float* ecl = (float*)h->ecl.p;
 	launch_cf_to_cl(DT_F32, E, b, C, T, ecl, C, 1, s);
 	launch_bcast_rows(DT_F32, h->uncond, b * T, C, ecl + (size_t)b * T * C, s);
+	// the staged embedding is the same in every step: its GroupNorm statistics once, here
+	TTK_TRY(h->ms_ecl.reserve((size_t)2 * b * 32 * gn_num_chunks(T, C) * 3 * 4));
+	launch_gn_stats(ecl, 2 * b, T, C, (float*)h->ms_ecl.p, s);
 	h->cur_b = b; h->cur_T = T; h->staged = 1;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
@@ -314,10 +325,9 @@ static int step_impl(ttk_diff* h, float* x, const ttk_step* st, const float* noi
 	const int C = h->cfg.model_channels, b = h->cur_b, T = h->cur_T;
 	const bool cf = st->cfk >= 0.f;
 	const int nb = cf ? 2 * b : b;
-	TTK_HIP(hipMemcpyAsync(h->cs.p, h->ecl.p, (size_t)nb * T * C * sizeof(float), hipMemcpyDeviceToDevice, s));
 	launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, cf ? 2 : 1, s);
 	float* out = (float*)h->outb.p;
-	network(h, nb, T, emb_row, 0, out, s);
+	network(h, nb, T, emb_row, 0, out, s, (const float*)h->ecl.p, (const float*)h->ms_ecl.p);
 	StepCoefs k = {};
 	k.sqrt_recip_ac = st->sqrt_recip_ac; k.sqrt_recipm1_ac = st->sqrt_recipm1_ac; k.sqrt_ac_prev = st->sqrt_ac_prev;
 	k.sqrt_1m_ac_prev = st->sqrt_1m_ac_prev; k.cfk = st->cfk; k.coef1 = st->coef1; k.coef2 = st->coef2;
