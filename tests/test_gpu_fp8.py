@@ -147,6 +147,10 @@ def test_fp8_diffusion_is_the_arithmetic_on_fp8_rounded_operands(golden):
 	mel = get_diffuser(steps=4, cond_free=True).sample_loop(m8, (1, 100, int(g["T"])), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E[:1].to(DEV)})
 	mel_w = get_diffuser(steps=4, cond_free=True).sample_loop(mw, (1, 100, int(g["T"])), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E[:1].to(DEV)})
 	assert torch.isfinite(mel).all() and relerr(mel, mel_w) < 0.15
+	# the conditioning pre-pass (4 AttentionBlocks over the M latent rows: the small-M tile of the fp8 GEMM) in this mode
+	lat, dcond = torch.from_numpy(g["latents"]).to(DEV), torch.from_numpy(g["cond"]).to(DEV)
+	E8, Ew = m8.timestep_independent(lat, dcond, int(g["T"]), False), mw.timestep_independent(lat, dcond, int(g["T"]), False)
+	assert E8.shape == Ew.shape and torch.isfinite(E8).all() and 1e-4 < relerr(E8, Ew) < 0.1 and relerr(E8, g["E"]) < 0.15
 
 
 def test_fp8_full_size_network_evaluation():
