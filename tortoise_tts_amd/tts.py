@@ -34,10 +34,12 @@ class TTS:
 		self.device = autoregressive.device
 
 	def encode_text(self, text: Union[str, torch.Tensor], language: str = "en") -> torch.Tensor:
-		"""inference.py:104-111."""
+		"""inference.py:104-111 over `tokenize` (data.py:279-282: a list of pieces is joined first)."""
 		if isinstance(text, torch.Tensor):
 			return text
-		return torch.tensor(self.tokenizer.encode(text))
+		if isinstance(text, list):
+			text = "".join(text)
+		return torch.tensor(self.tokenizer.encode(text), dtype=torch.int64)
 
 	def encode_audio(self, wav: Union[dict, torch.Tensor, Sequence[torch.Tensor]], sr: int = 22050) -> dict:
 		"""inference.py:113-124 over emb/mel.py:84-137 (`encode` / `encode_from_files`): a mono clip [1, n] (or a list of them, concatenated
