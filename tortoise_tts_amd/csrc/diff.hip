@@ -16,6 +16,12 @@ namespace {
 struct AttnBlk { float *gn_g, *gn_b; Mat qkv, proj; float* relbias; };
 struct ResBlk { float *gn1_g, *gn1_b, *gn2_g, *gn2_b; Mat in, out3; int emb_slot; };
 struct DLayer { ResBlk res; AttnBlk attn; };
+// the scratch a chain of ResBlocks / AttentionBlocks works in; two of them so that the conditioning integrator of the NEXT sampler step
+// can run on a side stream beside the main body of the current one
+struct Lane {
+	WsBuf a, hf, qkv, ao, ms;
+	const void* ms_owner = nullptr;   // tensor whose GroupNorm statistics currently sit in `ms` (written by a GEMM epilogue)
+};
 }  // namespace
 
 struct ttk_diff {
@@ -34,18 +40,22 @@ struct ttk_diff {
 	int n_emb;               // number of ResBlocks = rows of emb_cat / 2C
 	int in_pad;              // in_channels rounded up to 64
 	// workspaces
-	WsBuf cs, xs, hf, a, qkv, ao, h0, csT, xcl, outb, ecl, ms, ms_ecl, temb, e1, e2, se, emb_all, lat_T;
+	Lane lane[2];
+	Lane* L = &lane[0];      // the lane the block helpers below enqueue into (host code is sequential: flipped around the side-stream work)
+	WsBuf cs, cs2, xs, h0, csT, xcl, outb, ecl, ms_ecl, temb, e1, e2, se, emb_all, lat_T;
+	hipStream_t side = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_int[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+	int pipe = 1;           // ttk_diff_sample_ddim overlaps step i+1's integrator with step i's body (TTK_DIFF_PIPE=0: sequential)
 	int cur_b = 0, cur_T = 0, staged = 0;
-	const void* ms_owner = nullptr;   // tensor whose GroupNorm statistics currently sit in `ms` (written by a GEMM epilogue)
 	int fuse_stats = 1;
 };
 
 // gn_T > 0: the output is a GroupNorm input of gn_T rows per batch element; its statistics are produced in the epilogue when the
 // shape allows (gemm_fuses_gn_stats), which saves the separate k_gn_stats launch.
 static void want_stats(ttk_diff* h, GemmParams& g, int gn_T) {
-	h->ms_owner = nullptr;
+	h->L->ms_owner = nullptr;
 	if (h->fuse_stats && gn_T > 0 && g.out_f32 && !g.transpose_out && gemm_fuses_gn_stats(g.M, g.N, h->cfg.model_channels, gn_T)) {
-		g.gn_part = (float*)h->ms.p; g.gn_T = gn_T; h->ms_owner = g.C;
+		g.gn_part = (float*)h->L->ms.p; g.gn_T = gn_T; h->L->ms_owner = g.C;
 	}
 }
 
@@ -78,11 +88,11 @@ static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, c
 			   const float* ms_pre = nullptr) {
 	const int C = h->cfg.model_channels;
 	if (!ms_pre) {
-		if (h->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->ms.p, s);   // else: left by the producing GEMM
-		h->ms_owner = nullptr;
+		if (h->L->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->L->ms.p, s);   // else: left by the producing GEMM
+		h->L->ms_owner = nullptr;
 	}
 	GnApplyParams p = {};
-	p.x = x; p.ms = ms_pre ? ms_pre : (const float*)h->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
+	p.x = x; p.ms = ms_pre ? ms_pre : (const float*)h->L->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
 	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.nchunks = gn_num_chunks(T, C); p.act = act; p.out = out; p.out_f32 = out_f32;
 	if (next && h->prefetch) { p.pf = next->w; p.pf_bytes = (int64_t)next->Npad * next->Kpad * next->wes; p.pf_taps = next->ntap; }
 	if (next && next->wes == 1) p.out_f8 = 1;    // the consumer is an fp8 GEMM
@@ -92,15 +102,15 @@ static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, c
 // x (f32 stream, in place) = x + proj_out(attention(qkv(GN(x))))         arch_utils.py:183-190
 static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, hipStream_t s) {
 	const int C = h->cfg.model_channels, rows = nb * T;
-	gn(h, x, nb, T, A.gn_g, A.gn_b, nullptr, nullptr, 0, ACT_NONE, h->a.p, 0, nullptr, T, s, &A.qkv);
-	gemm1(h, h->a.p, C, A.qkv, rows, h->qkv.p, 3 * C, 0, ACT_NONE, nullptr, s);
+	gn(h, x, nb, T, A.gn_g, A.gn_b, nullptr, nullptr, 0, ACT_NONE, h->L->a.p, 0, nullptr, T, s, &A.qkv);
+	gemm1(h, h->L->a.p, C, A.qkv, rows, h->L->qkv.p, 3 * C, 0, ACT_NONE, nullptr, s);
 	AttnParams a = {};
-	a.qkv = h->qkv.p; a.ld = 3 * C; a.q_off = 0; a.k_off = 64; a.v_off = 128; a.head_stride = 192;   // head-major [H][3][64], arch_utils.py:79
-	a.out = h->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f;
+	a.qkv = h->L->qkv.p; a.ld = 3 * C; a.q_off = 0; a.k_off = 64; a.v_off = 128; a.head_stride = 192;   // head-major [H][3][64], arch_utils.py:79
+	a.out = h->L->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f;
 	if (h->prefetch) { a.pf = A.proj.w; a.pf_bytes = (int64_t)A.proj.Npad * A.proj.Kpad * A.proj.wes; a.pf_taps = 1; }
 	a.out_f8 = A.proj.wes == 1;
 	launch_attn_fwd(h->dt, a, s);
-	gemm1(h, h->ao.p, C, A.proj, rows, x, C, 1, ACT_NONE, x, s, T);
+	gemm1(h, h->L->ao.p, C, A.proj, rows, x, C, 1, ACT_NONE, x, s, T);
 }
 
 // x = x + conv3(SiLU(GN(conv1(SiLU(GN(x)))) * (1 + scale) + shift))        diffusion.py:1363-1376
@@ -110,21 +120,27 @@ static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, con
 					  const float* x_in = nullptr, const float* ms_in = nullptr) {
 	const int C = h->cfg.model_channels, rows = nb * T;
 	const float* src = x_in ? x_in : x;
-	gn(h, src, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s, &R.in, ms_in);
-	gemm1(h, h->a.p, C, R.in, rows, h->hf.p, C, 1, ACT_NONE, nullptr, s, T);
+	gn(h, src, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->L->a.p, 0, nullptr, T, s, &R.in, ms_in);
+	gemm1(h, h->L->a.p, C, R.in, rows, h->L->hf.p, C, 1, ACT_NONE, nullptr, s, T);
 	const float* sc = emb_all + (int64_t)R.emb_slot * 2 * C;
-	gn(h, (const float*)h->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->a.p, 0, nullptr, T, s, &R.out3);
-	gemm_conv3(h, h->a.p, C, R.out3, rows, T, x, C, 1, src, 0, s, T);
+	gn(h, (const float*)h->L->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->L->a.p, 0, nullptr, T, s, &R.out3);
+	gemm_conv3(h, h->L->a.p, C, R.out3, rows, T, x, C, 1, src, 0, s, T);
 }
 
+static int reserve_lane(ttk_diff* h, Lane& L, int nb, int T) {
+	const size_t rows = (size_t)nb * T, C = h->cfg.model_channels, es = h->es;
+	TTK_TRY(L.hf.reserve(rows * C * 4)); TTK_TRY(L.a.reserve(rows * C * es)); TTK_TRY(L.qkv.reserve(rows * 3 * C * es)); TTK_TRY(L.ao.reserve(rows * C * es));
+	TTK_TRY(L.ms.reserve((size_t)nb * 32 * gn_num_chunks(T, (int)C) * 3 * 4));
+	return TTK_OK;
+}
 static int reserve_ws(ttk_diff* h, int nb, int T) {
 	TTK_REQUIRE(gn_num_chunks(T, h->cfg.model_channels) <= 64, TTK_E_ARG, "%d frames exceed the GroupNorm chunk table (64 chunks)", T);
 	const size_t rows = (size_t)nb * T, C = h->cfg.model_channels, es = h->es;
-	TTK_TRY(h->cs.reserve(rows * C * 4)); TTK_TRY(h->xs.reserve(rows * C * 4)); TTK_TRY(h->hf.reserve(rows * C * 4));
-	TTK_TRY(h->a.reserve(rows * C * es)); TTK_TRY(h->qkv.reserve(rows * 3 * C * es)); TTK_TRY(h->ao.reserve(rows * C * es));
+	h->L = &h->lane[0];
+	TTK_TRY(reserve_lane(h, h->lane[0], nb, T));
+	TTK_TRY(h->cs.reserve(rows * C * 4)); TTK_TRY(h->xs.reserve(rows * C * 4));
 	TTK_TRY(h->h0.reserve(rows * C * es)); TTK_TRY(h->csT.reserve(rows * C * es)); TTK_TRY(h->xcl.reserve(rows * h->in_pad * es));
 	TTK_TRY(h->outb.reserve(rows * h->cfg.out_channels * 4)); TTK_TRY(h->ecl.reserve(rows * C * 4));
-	TTK_TRY(h->ms.reserve((size_t)nb * 32 * gn_num_chunks(T, (int)C) * 3 * 4));
 	return TTK_OK;
 }
 
@@ -143,19 +159,23 @@ static int time_path(ttk_diff* h, const int64_t* t_dev, const int64_t* t_host, i
 	return TTK_OK;
 }
 
-// The network body on nb sequences of T frames.  Inputs: h->xcl (T-typed [nb*T][in_pad]) and h->cs (f32 code embedding stream
-// [nb*T][C], consumed); emb rows at emb_all + b * emb_stride.  Output: out f32 [nb][out_channels][T].     diffusion.py:1549-1564
-static void network(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, float* out, hipStream_t s,
-					const float* cs_in = nullptr, const float* ms_in = nullptr) {
-	const int C = h->cfg.model_channels, rows = nb * T;
-	float* cs = (float*)h->cs.p;
-	float* x = (float*)h->xs.p;
+// One evaluation = integrator (the three conditioning_timestep_integrator layers on the code-embedding stream `cs`; depends on the timestep
+// only, not on x) + body (everything that sees x).  Inputs of the body: h->xcl (T-typed [nb*T][in_pad]) and cs (f32 [nb*T][C]); emb rows at
+// emb_all + b * emb_stride.  Output: out f32 [nb][out_channels][T].     diffusion.py:1549-1564
+static void integrator(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, float* cs, hipStream_t s,
+					   const float* cs_in = nullptr, const float* ms_in = nullptr) {
 	for (int i = 0; i < 3; ++i) {
 		res_block(h, h->integrator[i].res, cs, nb, T, emb_all, emb_stride, s, i == 0 ? cs_in : nullptr, i == 0 ? ms_in : nullptr);
 		attn_block(h, h->integrator[i].attn, cs, nb, T, s);
 	}
+}
+static void body(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, const float* cs, float* out, hipStream_t s,
+				 hipEvent_t cs_consumed = nullptr) {
+	const int C = h->cfg.model_channels, rows = nb * T;
+	float* x = (float*)h->xs.p;
 	gemm_conv3(h, h->xcl.p, h->in_pad, h->inp_block, rows, T, h->h0.p, C, 0, nullptr, 0, s);
 	launch_cast(h->dt, cs, h->csT.p, (int64_t)rows * C, s);
+	if (cs_consumed) (void)hipEventRecord(cs_consumed, s);     // the last reader of `cs`: the side stream may overwrite it from here on
 	{   // integrating_conv over cat([h0, code_emb], channels): two K segments of one [C][2C] matrix
 		GemmParams g = {};
 		g.nseg = 2;
@@ -171,8 +191,13 @@ static void network(ttk_diff* h, int nb, int T, const float* emb_all, int64_t em
 		attn_block(h, h->layers[i].attn, x, nb, T, s);
 	}
 	for (int i = 0; i < 3; ++i) res_block(h, h->tail[i], x, nb, T, emb_all, emb_stride, s);
-	gn(h, x, nb, T, h->out_g, h->out_b, nullptr, nullptr, 0, ACT_SILU, h->a.p, 0, nullptr, T, s);
-	gemm_conv3(h, h->a.p, C, h->out_conv, rows, T, out, 0, 1, nullptr, 1, s);
+	gn(h, x, nb, T, h->out_g, h->out_b, nullptr, nullptr, 0, ACT_SILU, h->L->a.p, 0, nullptr, T, s);
+	gemm_conv3(h, h->L->a.p, C, h->out_conv, rows, T, out, 0, 1, nullptr, 1, s);
+}
+static void network(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, float* out, hipStream_t s,
+					const float* cs_in = nullptr, const float* ms_in = nullptr) {
+	integrator(h, nb, T, emb_all, emb_stride, (float*)h->cs.p, s, cs_in, ms_in);
+	body(h, nb, T, emb_all, emb_stride, (const float*)h->cs.p, out, s);
 }
 
 static int load_attn(ttk_diff* h, const WeightMap& wm, const std::string& p, AttnBlk* A) {
@@ -216,6 +241,7 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	h->in_pad = round_up(cfg->in_channels, 64);
 	h->fuse_stats = getenv("TTK_NO_FUSED_GN") ? 0 : 1;
 	{ const char* e = getenv("TTK_DIFF_PREFETCH"); h->prefetch = e ? atoi(e) : 1; }
+	{ const char* e = getenv("TTK_DIFF_PIPE"); h->pipe = e ? atoi(e) : 1; }
 	const int C = cfg->model_channels;
 	WeightMap wm(w, n_w);
 	int rc = TTK_OK;
@@ -260,9 +286,11 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 int ttk_diff_destroy(ttk_diff* h) {
 	if (!h) return TTK_OK;
 	(void)hipDeviceSynchronize();
-	WsBuf* all[] = {&h->cs, &h->xs, &h->hf, &h->a, &h->qkv, &h->ao, &h->h0, &h->csT, &h->xcl, &h->outb, &h->ecl, &h->ms,
-					&h->temb, &h->e1, &h->e2, &h->se, &h->emb_all, &h->lat_T, &h->ms_ecl};
+	WsBuf* all[] = {&h->cs, &h->cs2, &h->xs, &h->h0, &h->csT, &h->xcl, &h->outb, &h->ecl, &h->temb, &h->e1, &h->e2, &h->se, &h->emb_all, &h->lat_T, &h->ms_ecl};
 	for (WsBuf* b : all) b->release();
+	for (Lane& L : h->lane) { L.a.release(); L.hf.release(); L.qkv.release(); L.ao.release(); L.ms.release(); }
+	if (h->side) (void)hipStreamDestroy(h->side);
+	for (hipEvent_t e : {h->ev_fork, h->ev_int[0], h->ev_int[1], h->ev_free[0], h->ev_free[1]}) if (e) (void)hipEventDestroy(e);
 	h->arena.release();
 	delete h;
 	return TTK_OK;
@@ -321,13 +349,14 @@ int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream) {
 	return TTK_OK;
 }
 
-static int step_impl(ttk_diff* h, float* x, const ttk_step* st, const float* noise, const float* emb_row, hipStream_t s) {
-	const int C = h->cfg.model_channels, b = h->cur_b, T = h->cur_T;
+// the part of a sampler step that sees x: layout change, network body on the integrated code stream `cs`, the DDIM / ancestral update
+static int step_body(ttk_diff* h, float* x, const ttk_step* st, const float* noise, const float* emb_row, const float* cs, hipEvent_t cs_consumed, hipStream_t s) {
+	const int b = h->cur_b, T = h->cur_T;
 	const bool cf = st->cfk >= 0.f;
 	const int nb = cf ? 2 * b : b;
 	launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, cf ? 2 : 1, s);
 	float* out = (float*)h->outb.p;
-	network(h, nb, T, emb_row, 0, out, s, (const float*)h->ecl.p, (const float*)h->ms_ecl.p);
+	body(h, nb, T, emb_row, 0, cs, out, s, cs_consumed);
 	StepCoefs k = {};
 	k.sqrt_recip_ac = st->sqrt_recip_ac; k.sqrt_recipm1_ac = st->sqrt_recipm1_ac; k.sqrt_ac_prev = st->sqrt_ac_prev;
 	k.sqrt_1m_ac_prev = st->sqrt_1m_ac_prev; k.cfk = st->cfk; k.coef1 = st->coef1; k.coef2 = st->coef2;
@@ -335,6 +364,11 @@ static int step_impl(ttk_diff* h, float* x, const ttk_step* st, const float* noi
 	const int Cin = h->cfg.in_channels;
 	launch_diffusion_step(out, out + (size_t)b * h->cfg.out_channels * T, x, noise, b, Cin, T, k, s);
 	return TTK_OK;
+}
+static int step_impl(ttk_diff* h, float* x, const ttk_step* st, const float* noise, const float* emb_row, hipStream_t s) {
+	const int nb = st->cfk >= 0.f ? 2 * h->cur_b : h->cur_b;
+	integrator(h, nb, h->cur_T, emb_row, 0, (float*)h->cs.p, s, (const float*)h->ecl.p, (const float*)h->ms_ecl.p);
+	return step_body(h, x, st, noise, emb_row, (const float*)h->cs.p, nullptr, s);
 }
 
 int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise, void* stream) {
@@ -359,8 +393,47 @@ int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, co
 	for (int i = 0; i < n_steps; ++i) { ts[i] = steps[i].t; TTK_REQUIRE(steps[i].sampler == 0, TTK_E_ARG, "ttk_diff_sample_ddim: step %d is not a ddim step", i); }
 	TTK_TRY(time_path(h, nullptr, ts.data(), n_steps, s));
 	const int64_t stride = (int64_t)h->n_emb * 2 * h->cfg.model_channels;
-	for (int i = n_steps - 1; i >= 0; --i)
-		TTK_TRY(step_impl(h, x, &steps[i], nullptr, (const float*)h->emb_all.p + i * stride, s));
+	const float* emb_all = (const float*)h->emb_all.p;
+	if (!h->pipe || n_steps < 2) {
+		for (int i = n_steps - 1; i >= 0; --i) TTK_TRY(step_impl(h, x, &steps[i], nullptr, emb_all + i * stride, s));
+		TTK_HIP(hipGetLastError());
+		return TTK_OK;
+	}
+	// Pipelined over two streams.  The integrator of a step depends on its timestep and the staged embedding only, never on x: the one of
+	// step j+1 runs on the side stream (own scratch lane, the other `cs` buffer) while the body of step j runs here.  Both are chains of
+	// small dependent launches that leave most of the chip idle, so they overlap; one fork and one join edge per step.
+	const int nb_max = 2 * b;
+	if (!h->side) {
+		TTK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+		TTK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+		for (int i = 0; i < 2; ++i) {
+			TTK_HIP(hipEventCreateWithFlags(&h->ev_int[i], hipEventDisableTiming));
+			TTK_HIP(hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
+		}
+	}
+	TTK_TRY(reserve_lane(h, h->lane[1], nb_max, T));
+	TTK_TRY(h->cs2.reserve((size_t)nb_max * T * h->cfg.model_channels * 4));
+	float* csb[2] = {(float*)h->cs.p, (float*)h->cs2.p};
+	TTK_HIP(hipEventRecord(h->ev_fork, s));
+	TTK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+	auto enqueue_integrator = [&](int j) {      // j-th step of the loop = schedule index n_steps - 1 - j
+		const int i = n_steps - 1 - j;
+		const int nb = steps[i].cfk >= 0.f ? 2 * b : b;
+		h->L = &h->lane[1];
+		integrator(h, nb, T, emb_all + i * stride, 0, csb[j & 1], h->side, (const float*)h->ecl.p, (const float*)h->ms_ecl.p);
+		h->L = &h->lane[0];
+		(void)hipEventRecord(h->ev_int[j & 1], h->side);
+	};
+	enqueue_integrator(0);
+	for (int j = 0; j < n_steps; ++j) {
+		if (j + 1 < n_steps) {
+			if (j >= 1) TTK_HIP(hipStreamWaitEvent(h->side, h->ev_free[(j - 1) & 1], 0));   // body j-1 has read the buffer integrator j+1 writes
+			enqueue_integrator(j + 1);
+		}
+		TTK_HIP(hipStreamWaitEvent(s, h->ev_int[j & 1], 0));
+		const int i = n_steps - 1 - j;
+		TTK_TRY(step_body(h, x, &steps[i], nullptr, emb_all + i * stride, csb[j & 1], h->ev_free[j & 1], s));
+	}
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }
