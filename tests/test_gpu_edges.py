@@ -214,3 +214,22 @@ def test_new_handles_reject_bad_arguments_with_messages():
 	assert lib.ttk_fp8_round_weights(None, 0, None, None) != 0 and b"ttk_fp8_round_weights" in lib.ttk_last_error()
 	# destroying null handles is a no-op
 	assert lib.ttk_voc_destroy(None) == 0 and lib.ttk_clvp_destroy(None) == 0
+
+
+def test_two_stream_ddim_loop_equals_the_sequential_one(monkeypatch):
+	"""`ttk_diff_sample_ddim` runs step j+1's conditioning integrator on a side stream beside step j's body (it depends on the timestep and the
+	staged embedding only, diffusion.py:1549-1556); same kernels on the same data, so the mel must equal the one-stream loop bit for bit --
+	with and without conditioning-free guidance, odd and even step counts, two utterances back to back on one handle."""
+	from tortoise_tts_amd.diffusion import DiffusionTTS, get_diffuser
+	cfg = W.DIFF_SMALL
+	sd = W.synth_state_dict(W.diffusion_shapes(cfg), 77)
+	monkeypatch.setenv("TTK_DIFF_PIPE", "0")
+	seq = DiffusionTTS(sd, cfg, dtype="bf16", device=DEV)
+	monkeypatch.setenv("TTK_DIFF_PIPE", "1")
+	pip = DiffusionTTS(sd, cfg, dtype="bf16", device=DEV)
+	g = torch.Generator().manual_seed(5)
+	for T, steps, cf in ((70, 5, True), (129, 2, True), (33, 4, False), (70, 3, True)):
+		E = torch.randn(1, cfg.model_channels, T, generator=g).to(DEV)
+		noise = torch.randn(1, 100, T, generator=g).to(DEV)
+		outs = [get_diffuser(steps, cf).sample_loop(m, (1, 100, T), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E}) for m in (seq, pip, pip)]
+		assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), (T, steps, cf)
