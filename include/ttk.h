@@ -150,7 +150,9 @@ int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream);
  * epilogue; x [b, in, T] f32 updated in place; noise [b, in, T] f32 for the p sampler (NULL for ddim).
  * (GaussianDiffusion.p_mean_variance / ddim_sample / p_sample, diffusion.py:325-431, 646-694, 510-554)               */
 int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise, void* stream);
-/* Whole DDIM loop: steps[n-1], ..., steps[0] applied in that order (ddim_sample_loop_progressive :794-810). */
+/* Whole DDIM loop: steps[n-1], ..., steps[0] applied in that order (ddim_sample_loop_progressive :794-810).  The conditioning integrator of a
+ * step does not depend on x, so the one of the next step runs on an internal side stream beside the current step's body; the side stream is
+ * forked from and joined back to `stream` inside the call (results are ordered on `stream`; identical to the one-stream loop bit for bit). */
 int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream);
 
 /* ------------------------------------------------------------------ BigVGAN vocoder
