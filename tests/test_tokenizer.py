@@ -75,7 +75,16 @@ def test_number_expansion_known_answers():
 	assert number_to_words(21) == "twenty-one" and number_to_words(100) == "one hundred"
 	assert number_to_words(123) == "one hundred and twenty-three" and number_to_words(123, andword="") == "one hundred twenty-three"
 	assert number_to_words(1234) == "one thousand, two hundred and thirty-four"
-	assert number_to_words(1000000, andword="") == "one million" and number_to_words(45017, andword="") == "forty-five thousand, seventeen"
+	assert number_to_words(1000000, andword="") == "one million" and number_to_words(45017, andword="") == "forty-five thousand seventeen"
+	assert number_to_words(1001) == "one thousand and one" and number_to_words(45300, andword="") == "forty-five thousand, three hundred"
+	# the Tacotron cleaners' own known answers for this pipeline (the reference's tokenizer.py is that code)
+	for text, want in (("1", "one"), ("15", "fifteen"), ("24", "twenty-four"), ("100", "one hundred"), ("101", "one hundred one"), ("456", "four hundred fifty-six"),
+					   ("1000", "one thousand"), ("1800", "eighteen hundred"), ("2,000", "two thousand"), ("3000", "three thousand"), ("18000", "eighteen thousand"),
+					   ("24,000", "twenty-four thousand"), ("124,001", "one hundred twenty-four thousand one"), ("6.4 sec", "six point four sec"),
+					   ("1906", "nineteen oh six"), ("2007", "two thousand seven"), ("1900", "nineteen hundred"), ("2010", "twenty ten"),
+					   ("$3.50 for gas.", "three dollars, fifty cents for gas."), ("$1", "one dollar"), ("$20", "twenty dollars"), ("1st", "first"),
+					   ("2nd", "second"), ("23rd", "twenty-third"), ("100th", "one hundredth")):
+		assert normalize_numbers(text) == want, text
 	assert number_to_words(1984, andword="", zero="oh", group=2) == "nineteen, eighty-four"
 	assert number_to_words(1905, andword="", zero="oh", group=2) == "nineteen, oh five"
 	assert ordinal_words(1) == "first" and ordinal_words(2) == "second" and ordinal_words(3) == "third" and ordinal_words(12) == "twelfth"

@@ -43,7 +43,8 @@ def _tens(t: int, u: int) -> str:
 
 def number_to_words(num: int, andword: str = "and", zero: str = "zero", group: int = 0) -> str:
 	"""inflect.engine().number_to_words for a non-negative integer.  group=0: thousands groups joined by ", ", `andword` between a
-	group's hundreds and its remainder ("one thousand, two hundred and thirty-four").  group=2: the digits read in pairs, joined by
+	group's hundreds and its remainder ("one thousand, two hundred and thirty-four") and in place of the last comma when the final group is
+	one word.  group=2: the digits read in pairs, joined by
 	", ", a leading zero of a pair spoken as `zero` ("nineteen, oh five")."""
 	digits = str(int(num))
 	if group == 2:
@@ -76,7 +77,13 @@ def number_to_words(num: int, andword: str = "and", zero: str = "zero", group: i
 			words.append(f"{_UNIT[h]} hundred{joint}{_tens(t, u)}{_MILL[mindex]}")
 		elif rem:
 			words.append(f"{_tens(t, u)}{_MILL[mindex]}")
-	return ", ".join(words)
+	out = ", ".join(words)
+	# inflect: a final group that is a single word ("one", "twenty-one") is joined with `andword` instead of the comma
+	# ("one thousand and one"; with andword='' "one hundred twenty-four thousand one", the Tacotron cleaners' known answer for 124,001)
+	head, sep, last = out.rpartition(", ")
+	if sep and " " not in last:
+		out = head + (f" {andword} " if andword else " ") + last
+	return out
 
 
 def ordinal_words(num: int) -> str:
