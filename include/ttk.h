@@ -99,6 +99,37 @@ int ttk_sample_step(const float* scores, int64_t ld, int B, int V, const float* 
 					int64_t* col, int64_t* history, int64_t hist_ld, int64_t hist_off, int* live_rows, int* all_done,
 					void* stream);
 
+/* ttk_sample_step with the reference's other processors and warpers inside the same kernel, in HF's order (stream_generator.py:56-101 builds
+ * Temperature -> TopK -> TopP; HF `_get_logits_processor` puts RepetitionPenaltyLogitsProcessor and SuppressTokensLogitsProcessor in front):
+ *   repetition_penalty (HF:generation/logits_process.py RepetitionPenaltyLogitsProcessor): every id that occurs in history[b, 0 : hist_off + col[b]]
+ *     (= input_ids: the caller writes the prefix ids into the first hist_off columns, the kernel appends the sampled ones) has its score
+ *     multiplied (< 0) or divided (>= 0) by the penalty; 1 or 0 = off;
+ *   suppress, temperature: as ttk_sample_step;
+ *   top_k (TopKLogitsWarper): scores below the k-th largest become -inf; 0 = off;
+ *   top_p (TopPLogitsWarper): ascending cumulative softmax <= 1 - top_p becomes -inf, the largest score always stays; >= 1 or 0 = off.
+ * The CLI's defaults (__main__.py:17-21: top-k 16) therefore stay on this one launch: no torch.topk / torch.sort per token, no host
+ * round trip, capturable.  top-k / top-p / the penalty need V <= 9216 (the row is held in registers); TypicalLogitsWarper
+ * (unified_voice.py:47-75) is not included -- a caller that wants it applies it in front and passes the finished scores.      */
+typedef struct {
+	const float* scores; int64_t ld; int B, V;
+	const float* q; int64_t ldq;              /* Exp(1) noise of torch.multinomial, drawn by the caller */
+	const unsigned char* suppress;            /* [V] byte mask or NULL */
+	float temperature;                        /* > 0 */
+	int top_k; float top_p; float repetition_penalty;
+	int64_t stop_token;
+	int64_t *unfinished, *tok, *ids; int64_t ids_ld, ids_cols; int64_t* col;
+	int64_t* history; int64_t hist_ld, hist_off;   /* optional unless repetition_penalty is on */
+	int *live_rows, *all_done;                /* optional, see ttk_sample_step */
+} ttk_sample_args;
+int ttk_sample_step_warped(const ttk_sample_args* a, void* stream);
+
+/* The same launch, additionally writing the input row of the decode step that follows (the first lines of GPT2InferenceModel.forward's
+ * cached branch, unified_voice.py:212-214): x[b] = mel_embedding[tok[b]] + mel_pos_embedding[col[b] + 1] with col[b] already counting
+ * the new token (the reference's k + 1 indexing).  ttk_ar_decode_next then runs the step from that row: the pair replaces
+ * ttk_ar_decode's embedding-gather launch.  Both may be mixed freely with ttk_ar_decode on one handle.                        */
+int ttk_ar_sample_next(ttk_ar* h, const ttk_sample_args* a, void* stream);
+int ttk_ar_decode_next(ttk_ar* h, float* logits_out, float* hidden_out, void* stream);
+
 /* The weight rounding of TTK_FP8W applied in place to a device f32 array: x <- fp8_e4m3(x / s) * s with s = the smallest power of
  * two >= max|x| / 448, returned in *scale_out (host).  This is exactly what ttk_*_create does to a TTK_FP8W matrix, exposed so that a
  * caller (and the parity tests) can build the equivalent TTK_BF16 model.                                                     */
@@ -154,6 +185,12 @@ int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise,
  * step does not depend on x, so the one of the next step runs on an internal side stream beside the current step's body; the side stream is
  * forked from and joined back to `stream` inside the call (results are ordered on `stream`; identical to the one-stream loop bit for bit). */
 int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream);
+
+/* Whole ancestral-sampler loop (p_sample_loop_progressive, diffusion.py:556-644 -- what the second caller of the path, train.py:178, runs with
+ * 30 steps): the same two-stream loop with p_sample's update (:510-554).  noise [n_steps, b, in, T] f32: the `th.randn_like(x)` draws of the
+ * steps in the order the loop makes them (block j belongs to the j-th executed step, steps[n-1-j]); the caller draws them so the generator
+ * stream stays the reference's.  Equal to n_steps ttk_diff_step calls bit for bit.                                                       */
+int ttk_diff_sample_p(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, const float* noise, void* stream);
 
 /* ------------------------------------------------------------------ BigVGAN vocoder
  * The generator of models/bigvgan.py (BigVGAN.__init__ :419-486) on the hot path's kernels.  Weights: the generator's state_dict

@@ -148,6 +148,22 @@ class AROracle:
 		hidden, past = gpt2_stack(self.w, self.cfg.layers, self.cfg.heads, emb.unsqueeze(1), past)
 		return self.lm_head(hidden)[:, -1], past, hidden[:, -1]
 
+	def teacher_forced_logits(self, cond_latent: Tensor, text: Tensor, toks: Tensor, steps: Sequence[int]) -> Tensor:
+		"""Logits after `j` fed-back tokens for every j in `steps`, of a teacher-forced decode that feeds toks[:, 0], toks[:, 1], ...:
+		ONE dense causal pass over [prefix | start_mel at mel position 0 | token k at mel position k + 1] -- the sequence the
+		KV-cached loop of `prefill` + `decode` builds (unified_voice.py:203-214, position quirk included), so equal to its steps
+		up to f32 summation order (tests/test_oracle_golden.py pins that).  Long contexts at full size cost one pass instead of
+		hundreds of cached steps.  Returns [b, len(steps), V]."""
+		w, c = self.w, self.cfg
+		b, n = toks.shape
+		prefix = self.prefix_embeddings(cond_latent, text).expand(b, -1, -1)
+		P = prefix.shape[1]
+		start = (w["mel_embedding.weight"][c.start_mel_token] + w["mel_pos_embedding.emb.weight"][0]).view(1, 1, -1).expand(b, 1, -1)
+		last = max(steps)
+		fed = w["mel_embedding.weight"][toks[:, :last]] + w["mel_pos_embedding.emb.weight"][2:last + 2]
+		hidden, _ = gpt2_stack(w, c.layers, c.heads, torch.cat([prefix, start, fed], dim=1))
+		return self.lm_head(hidden[:, [P + j for j in steps]])
+
 	def forward_latents(self, cond_latent: Tensor, text: Tensor, codes: Tensor) -> Tensor:
 		"""unified_voice.py:544-599 with return_latent=True, clip_inputs=False, text_first=True, and
 		get_logits :508-522.  set_mel_padding (:494-506) is a no-op when wav_lengths =

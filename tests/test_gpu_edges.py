@@ -126,6 +126,33 @@ def test_ddim_linearity_of_the_epilogue_and_clamp(small_diff):
 	assert torch.isfinite(mel).all()
 
 
+def test_whole_loop_ancestral_sampler_equals_the_per_step_calls(small_diff):
+	"""ttk_diff_sample_p (two-stream whole loop, noise pre-drawn in loop order) == n x ttk_diff_step, bit for bit; 30 steps as train.py:178 runs."""
+	from tortoise_tts_amd import _lib
+	from tortoise_tts_amd.diffusion import get_diffuser
+	model, _ = small_diff
+	T, n = 70, 30
+	E = torch.randn(1, 128, T, generator=gen(3)).to(DEV)
+	x0 = torch.randn(1, 100, T, generator=gen(4)).to(DEV)
+	d = get_diffuser(steps=n, cond_free=True)
+	torch.manual_seed(5)
+	whole = d.sample_loop(model, (1, 100, T), sampler="p", noise=x0, model_kwargs={"precomputed_aligned_embeddings": E})
+	after = torch.rand(3, device=DEV)
+	torch.manual_seed(5)
+	x = x0.clone()
+	_lib.check(model.lib.ttk_diff_begin(model._h, E.data_ptr(), 1, T, _lib.stream_ptr()), "ttk_diff_begin")
+	for i in reversed(range(n)):
+		nz = torch.randn_like(x)
+		st = d.step_coefs(i, "p")
+		_lib.check(model.lib.ttk_diff_step(model._h, x.data_ptr(), _lib.C.byref(st), nz.data_ptr(), _lib.stream_ptr()), "ttk_diff_step")
+	assert torch.equal(whole, x) and torch.equal(after, torch.rand(3, device=DEV)) and torch.isfinite(x).all()
+	# a ddim step list handed to the p entry (and the reverse) is refused
+	steps = (_lib.StepC * 2)(*[d.step_coefs(i, "ddim") for i in range(2)])
+	assert model.lib.ttk_diff_sample_p(model._h, x.data_ptr(), E.data_ptr(), 1, T, steps, 2, x.data_ptr(), None) != 0
+	assert b"sampler" in model.lib.ttk_last_error()
+	assert model.lib.ttk_diff_sample_p(model._h, x.data_ptr(), E.data_ptr(), 1, T, steps, 2, None, None) != 0
+
+
 def test_full_size_bf16_properties():
 	"""BASELINE-size models (configs[1] shapes, bf16): determinism of the sampled ids across two runs and across graph/eager,
 	all ids in range, fixed length with the stop token suppressed; DDIM mel finite and in the clamp-implied range."""

@@ -275,6 +275,74 @@ def test_fused_sample_step_is_the_reference_sampling_chain():
 	assert b"ttk_sample_step" in lib.ttk_last_error()
 
 
+@pytest.mark.parametrize("temp,top_k,top_p,pen", [(0.8, 16, 1.0, 1.0), (0.8, 0, 0.9, 1.0), (1.0, 0, 1.0, 2.0), (0.7, 16, 0.9, 2.0),
+												   (1.3, 50, 0.5, 1.2), (0.2, 1, 1.0, 1.0), (0.8, 8000, 0.999, 1.0), (1.0, 8194, 0.05, 5.0)])
+def test_warpers_inside_the_sampling_kernel_equal_the_torch_op_chain(temp, top_k, top_p, pen):
+	"""ttk_sample_step_warped == the reference's processor / warper chain run as torch ops on the device (repetition penalty over
+	input_ids, suppress_tokens, temperature, top-k, top-p -- the oracle's `process_logits`, HF's classes restated), then softmax +
+	torch.multinomial, token by token with a growing history that contains repeats, including the generator stream it consumes."""
+	from tortoise_tts_amd import _lib
+	lib = _lib.load()
+	B, V, stop, steps, off = 16, 8194, 8193, 8, 2
+	g = torch.Generator().manual_seed(int(temp * 100) + top_k)
+	logits = [(torch.randn((B, V), generator=g) * 4).to(DEV) for _ in range(steps)]
+	for lg in logits:
+		lg[:, :40] += 5.0                    # a few dominant ids: sampled tokens repeat, so the penalty meets duplicates in input_ids
+	sup = [7, 8193]
+	mask = torch.zeros(V, dtype=torch.bool, device=DEV)
+	mask[sup] = True
+	# reference chain (torch ops on the device)
+	torch.manual_seed(3); torch.cuda.manual_seed_all(3)
+	input_ids = torch.ones((B, off), dtype=torch.long, device=DEV)
+	input_ids[:, -1] = 8192
+	ref = []
+	for lg in logits:
+		sc = O.process_logits(input_ids, lg, temperature=temp, top_k=top_k, top_p=top_p, repetition_penalty=pen, suppress_tokens=sup)
+		nxt = torch.multinomial(torch.softmax(sc, dim=-1), num_samples=1).squeeze(1)
+		input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
+		ref.append(nxt)
+	ref = torch.stack(ref, 1)
+	after_ref = torch.rand(4, device=DEV)
+	# fused kernel
+	torch.manual_seed(3); torch.cuda.manual_seed_all(3)
+	unf = torch.ones(B, dtype=torch.long, device=DEV)
+	tok = torch.empty(B, dtype=torch.long, device=DEV)
+	ids = torch.full((B, steps), -1, dtype=torch.long, device=DEV)
+	col = torch.zeros(B, dtype=torch.long, device=DEV)
+	hist = torch.ones((B, off + steps), dtype=torch.long, device=DEV)
+	hist[:, off - 1] = 8192
+	q = torch.empty((B, V), device=DEV)
+	a = _lib.SampleArgs()
+	a.ld, a.B, a.V, a.q, a.ldq = V, B, V, q.data_ptr(), V
+	a.suppress, a.temperature, a.top_k, a.top_p, a.repetition_penalty = mask.data_ptr(), temp, top_k, top_p, pen
+	a.stop_token, a.unfinished, a.tok, a.ids, a.ids_ld, a.ids_cols, a.col = stop, unf.data_ptr(), tok.data_ptr(), ids.data_ptr(), steps, steps, col.data_ptr()
+	a.history, a.hist_ld, a.hist_off = hist.data_ptr(), hist.stride(0), off
+	for lg in logits:
+		q.exponential_(1)
+		a.scores = lg.data_ptr()
+		_lib.check(lib.ttk_sample_step_warped(_lib.C.byref(a), _lib.stream_ptr()), "ttk_sample_step_warped")
+	torch.cuda.synchronize()
+	after = torch.rand(4, device=DEV)
+	assert torch.equal(ids, ref), (ids != ref).sum().item()
+	assert torch.equal(hist[:, off:], ref) and torch.equal(after, after_ref)
+	if top_k == 1:
+		assert torch.equal(ids, torch.stack([torch.where(mask, -float("inf"), lg).argmax(-1) for lg in logits], 1))   # greedy = argmax of what is left
+
+
+def test_sampling_kernel_rejects_what_it_cannot_do():
+	from tortoise_tts_amd import _lib
+	lib = _lib.load()
+	a = _lib.SampleArgs()
+	assert lib.ttk_sample_step_warped(_lib.C.byref(a), None) != 0 and b"ttk_sample_step_warped" in lib.ttk_last_error()
+	x = torch.zeros(1, 20000, device=DEV)
+	i64 = torch.zeros(4, dtype=torch.long, device=DEV)
+	a.scores, a.ld, a.B, a.V, a.q, a.ldq, a.temperature, a.top_k = x.data_ptr(), 20000, 1, 20000, x.data_ptr(), 20000, 1.0, 5
+	a.unfinished = a.tok = a.ids = a.col = i64.data_ptr()
+	assert lib.ttk_sample_step_warped(_lib.C.byref(a), None) != 0 and b"9216" in lib.ttk_last_error()   # wide rows: no in-kernel top-k
+	a.top_k, a.V, a.ld, a.ldq, a.repetition_penalty = 0, 100, 100, 100, 1.5
+	assert lib.ttk_sample_step_warped(_lib.C.byref(a), None) != 0 and b"history" in lib.ttk_last_error()
+
+
 @pytest.mark.parametrize("bias", [2.0, 4.5, 9.0])
 def test_early_stop_without_per_token_sync_keeps_ids_and_rng_stream(lib, bias):
 	"""Graph mode looks at the all-finished flag a few tokens late; the tokens generated past the true end must be cut off and the

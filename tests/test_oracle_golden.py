@@ -55,6 +55,28 @@ def test_ar_small_prefill_decode_latents(golden):
 		close(lat, g["latents"], 2e-5)
 
 
+def test_dense_teacher_forced_pass_equals_cached_decode(golden):
+	"""AROracle.teacher_forced_logits (one dense pass, used by the full-size GPU tests at ctx 318 / 750) against the reference's
+	own KV-cached logits of the golden fixture and against the oracle's cached steps on a longer run."""
+	g, ar = _ar(golden, "ar_small", W.AR_SMALL)
+	text, cond, toks = t(g["text"]), t(g["cond"]), t(g["dec_tokens"])
+	n = toks.shape[1]
+	with torch.inference_mode():
+		dense = ar.teacher_forced_logits(cond, text, toks, list(range(n + 1)))
+		close(dense[:, 0], g["prefill_logits"], 2e-5)
+		close(dense[:, 1:], g["decode_logits"], 2e-5)
+		toks = torch.randint(0, 8192, (3, 40), generator=torch.Generator().manual_seed(3))
+		steps = [0, 1, 17, 39, 40]
+		dense = ar.teacher_forced_logits(cond, text, toks, steps)
+		lg, past, _ = ar.prefill(ar.prefix_embeddings(cond, text), 3)
+		cached = {0: lg[:, -1]}
+		for k in range(1, 41):
+			lg, past, _ = ar.decode(toks[:, k - 1], k, past)
+			cached[k] = lg
+		for i, j in enumerate(steps):
+			close(dense[:, i], cached[j], 5e-5)
+
+
 def test_ar_decode_position_quirk_matters(golden):
 	"""k+1 indexing (unified_voice.py:214): using k instead must NOT reproduce the reference."""
 	g, ar = _ar(golden, "ar_small", W.AR_SMALL)

@@ -47,6 +47,15 @@ class StepC(C.Structure):
 		("sampler", C.c_int), ("nonzero", C.c_int)]
 
 
+class SampleArgs(C.Structure):
+	"""ttk_sample_args (include/ttk.h)"""
+	_fields_ = [("scores", C.c_void_p), ("ld", C.c_int64), ("B", C.c_int), ("V", C.c_int), ("q", C.c_void_p), ("ldq", C.c_int64),
+				("suppress", C.c_void_p), ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float),
+				("repetition_penalty", C.c_float), ("stop_token", C.c_int64), ("unfinished", C.c_void_p), ("tok", C.c_void_p),
+				("ids", C.c_void_p), ("ids_ld", C.c_int64), ("ids_cols", C.c_int64), ("col", C.c_void_p), ("history", C.c_void_p),
+				("hist_ld", C.c_int64), ("hist_off", C.c_int64), ("live_rows", C.c_void_p), ("all_done", C.c_void_p)]
+
+
 class ProfResult(C.Structure):
 	_fields_ = [("ms", C.c_double), ("launches", C.c_int64), ("work", C.c_double)]
 
@@ -62,6 +71,9 @@ SYMBOLS = {
 	"ttk_ar_destroy": (_I, [_P]),
 	"ttk_ar_prefill": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
 	"ttk_ar_decode": (_I, [_P, _P, _P, _P, _P]),
+	"ttk_ar_decode_next": (_I, [_P, _P, _P, _P]),
+	"ttk_ar_sample_next": (_I, [_P, C.POINTER(SampleArgs), _P]),
+	"ttk_sample_step_warped": (_I, [C.POINTER(SampleArgs), _P]),
 	"ttk_ar_latents": (_I, [_P, _P, _P, _I, _P, _I, _I, _P, _P]),
 	"ttk_voc_create": (_I, [C.POINTER(_P), _P, C.POINTER(WeightView), _I]),
 	"ttk_voc_destroy": (_I, [_P]),
@@ -86,6 +98,7 @@ SYMBOLS = {
 	"ttk_diff_begin": (_I, [_P, _P, _I, _I, _P]),
 	"ttk_diff_step": (_I, [_P, _P, C.POINTER(StepC), _P, _P]),
 	"ttk_diff_sample_ddim": (_I, [_P, _P, _P, _I, _I, C.POINTER(StepC), _I, _P]),
+	"ttk_diff_sample_p": (_I, [_P, _P, _P, _I, _I, C.POINTER(StepC), _I, _P, _P]),
 }
 
 _lib = None

@@ -5,10 +5,12 @@ every forward goes through the C ABI or raises.
 
 What runs where
   * GPT-2 stack, embeddings, final norms, mel head, KV cache ........ libttk  (csrc/ar.hip and kernels)
-  * logit warpers + torch.multinomial + the stop/pad bookkeeping ..... torch ops on the same stream (sampling.py):
-    the generator stream is part of the reference's observable behaviour (seed 0 on every call).
-  * the per-token loop .............................................. here; one HIP-graph replay per token when the
-    logits pipeline needs no token history (the default), eager launches otherwise.
+  * logits processors / warpers, softmax, multinomial(1) given its noise, stop/pad bookkeeping, the next step's input
+    embedding ......................................................... libttk  (csrc/sample.hip, one launch per token)
+  * the Exp(1) noise of torch.multinomial ............................ torch `exponential_` on the same stream: the
+    generator stream is part of the reference's observable behaviour (seed 0 on every call); typical sampling (rare,
+    off by default) also stays a torch op in front of the kernel (sampling.py).
+  * the per-token loop .............................................. here; one HIP-graph replay per token.
 """
 from __future__ import annotations
 
@@ -55,8 +57,7 @@ class UnifiedVoice:
 		with torch.cuda.device(self.device):
 			_lib.check(self.lib.ttk_ar_create(_lib.C.byref(self._h), _lib.C.byref(c), views, len(names)), "ttk_ar_create")
 		del keep
-		self._graph = None
-		self._graph_key = None
+		self._states: Dict[tuple, "_GenState"] = {}
 		self._prefix = None
 
 	def __del__(self):
@@ -75,18 +76,30 @@ class UnifiedVoice:
 		return self
 
 	# ------------------------------------------------------------------ C-ABI calls
+	def _check_ids(self, ids: torch.Tensor, n: int, what: str):
+		"""token ids index embedding rows on the device: an id outside the table must be the IndexError nn.Embedding raises in the
+		reference, not an out-of-bounds read"""
+		if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= n):
+			raise IndexError(f"{what} ids must lie in [0, {n}); got [{int(ids.min())}, {int(ids.max())}]")
+
 	def _prefill(self, cond: torch.Tensor, text: torch.Tensor, B: int) -> torch.Tensor:
 		cond = cond.to(self.device, torch.float32).contiguous()
 		text = text.to(self.device, torch.int64).contiguous().view(-1)
 		_lib.require_cuda(cond, text)
+		self._check_ids(text, self.cfg.number_text_tokens + 1, "text token")
 		logits = torch.empty((B, self.cfg.number_mel_codes), device=self.device, dtype=torch.float32)
 		_lib.check(self.lib.ttk_ar_prefill(self._h, cond.data_ptr(), cond.shape[0], text.data_ptr(), text.numel(), B,
 										   logits.data_ptr(), _lib.stream_ptr()), "ttk_ar_prefill")
 		return logits
 
 	def _decode(self, tok: torch.Tensor, logits: torch.Tensor, hidden: Optional[torch.Tensor] = None):
+		"""one KV-cached step fed with `tok` (callers pass ids this module sampled, or teacher-forced ones they validated)"""
 		_lib.check(self.lib.ttk_ar_decode(self._h, tok.data_ptr(), logits.data_ptr(), _lib.ptr(hidden), _lib.stream_ptr()),
 				   "ttk_ar_decode")
+
+	def _decode_next(self, logits: torch.Tensor, hidden: Optional[torch.Tensor] = None):
+		"""the same step started from the input row the fused sampling launch (ttk_ar_sample_next) left in the handle"""
+		_lib.check(self.lib.ttk_ar_decode_next(self._h, logits.data_ptr(), _lib.ptr(hidden), _lib.stream_ptr()), "ttk_ar_decode_next")
 
 	# ------------------------------------------------------------------ reference surface
 	def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths, types=None,
@@ -105,6 +118,8 @@ class UnifiedVoice:
 			text = text.expand(B, -1)
 		text = text.contiguous()
 		codes = mel_codes.to(self.device, torch.int64).contiguous()
+		self._check_ids(text, self.cfg.number_text_tokens + 1, "text token")
+		self._check_ids(codes, self.cfg.number_mel_codes, "mel code")
 		# set_mel_padding (:494-506) rewrites codes past wav_lengths // compression + 1 with the stop token
 		mel_lengths = torch.div(torch.as_tensor(wav_lengths).view(-1).to("cpu"), self.mel_length_compression, rounding_mode="trunc")
 		if mel_lengths.numel() not in (1, B):
@@ -177,22 +192,23 @@ class UnifiedVoice:
 			return self._loop_stream(cond, text, B, max_new, pipe)
 		can_stop = c.stop_mel_token not in suppress
 		with torch.cuda.device(self.device):
-			st = self._gen_state(B, max_new, trunc_index, pipe_key)
+			st = self._gen_state(B, max_new, pipe_key)
 			setup_seed(kw.get("seed", 0))
 			st.reset(c)
 			st.logits.copy_(self._prefill(cond, text, B))
 			n = 0
-			if not (self.use_graph and not st.pipe.needs_history):
+			if not (self.use_graph and st.graphable):
 				while True:
 					st.sample(n)
 					n += 1
 					if n >= max_new or (can_stop and int(st.unfinished.max()) == 0):
 						break
-					self._decode(st.tok, st.logits)
+					self._decode_next(st.logits)
 			else:
 				# tokens 1 and 2 eagerly (the second pass also warms every kernel before a capture), then one HIP-graph
-				# replay per token: {ttk_ar_decode; warp; multinomial; bookkeeping}.  Every position-dependent quantity
-				# (cache length, mel position, output column) lives in device memory, so one graph serves all tokens.
+				# replay per token: {ttk_ar_decode_next; [typical warper]; exponential_; ttk_ar_sample_next}.  Every position-dependent
+				# quantity (cache length, mel position, output column, length of the token history the repetition penalty reads) lives in
+				# device memory, so ONE graph serves all tokens and every text length.
 				# HF's stopping test (`unfinished_sequences.max() == 0` after every token, a host round trip that idles the GPU)
 				# becomes a flag the sampling kernel raises in pinned memory; the host looks at it LAG replays late, so the GPU
 				# always has work queued.  The <= LAG tokens generated past the true end are all padding; they are cut off below
@@ -208,15 +224,18 @@ class UnifiedVoice:
 				stopped = can_stop and int(st.unfinished.max()) == 0
 				while n < max_new and not stopped:
 					if st.graph is None:
-						self._decode(st.tok, st.logits)
+						self._decode_next(st.logits)
 						st.sample(n)
 						n += 1
 						stopped = can_stop and int(st.unfinished.max()) == 0
 						if n < max_new and not stopped:
 							torch.cuda.synchronize(self.device)
 							g = torch.cuda.CUDAGraph()
-							with torch.cuda.graph(g):
-								self._decode(st.tok, st.logits)
+							# thread-local capture mode: another host thread may be enqueuing (and allocating for) the previous
+							# line's diffusion meanwhile (TTSHotPath.inference_lines); in the default global mode its hipMalloc /
+							# hipFree would invalidate this capture
+							with torch.cuda.graph(g, capture_error_mode="thread_local"):
+								self._decode_next(st.logits)
 								st.sample(0)
 							st.graph = g
 						continue
@@ -241,12 +260,18 @@ class UnifiedVoice:
 							n = n_true
 			return st.ids[:, :n].clone(), None
 
-	def _gen_state(self, B, max_new, trunc_index, pipe_key):
-		key = (B, max_new, trunc_index, pipe_key)
-		if self._graph_key != key:
-			self._graph = _GenState(self, B, max_new, trunc_index, pipe_key)
-			self._graph_key = key
-		return self._graph
+	def _gen_state(self, B, max_new, pipe_key):
+		"""generation states (device buffers + the captured token step) keyed by what is baked into them; a few are kept so that
+		alternating shapes (e.g. `TTS.inference` lines with different max lengths) do not re-capture every call"""
+		key = (B, max_new, pipe_key)
+		states = self._states
+		if key in states:
+			states[key] = states.pop(key)             # most recently used last
+		else:
+			while len(states) >= 4:
+				states.pop(next(iter(states)))
+			states[key] = _GenState(self, B, max_new, pipe_key)
+		return states[key]
 
 	def _loop_stream(self, cond, text, B, max_new, pipe):
 		c = self.cfg
@@ -272,11 +297,13 @@ class UnifiedVoice:
 
 
 class _GenState:
-	"""Persistent device buffers of one generation shape, so a captured token step can be replayed across calls."""
+	"""Persistent device buffers of one generation shape, so a captured token step can be replayed across calls (and across text
+	lengths: nothing in it depends on the prefix length)."""
 
-	def __init__(self, model: UnifiedVoice, B, max_new, trunc_index, pipe_key):
+	def __init__(self, model: UnifiedVoice, B, max_new, pipe_key):
 		c, dev = model.cfg, model.device
-		self.B, self.max_new, self.trunc_index = B, max_new, trunc_index
+		self.model = model
+		self.B, self.max_new = B, max_new
 		self.pipe = LogitsPipeline(temperature=pipe_key[0], top_k=pipe_key[1], top_p=pipe_key[2], repetition_penalty=pipe_key[3],
 								   suppress_tokens=pipe_key[4], typical_mass=pipe_key[5], vocab=c.number_mel_codes, device=dev)
 		self.stop = c.stop_mel_token
@@ -289,12 +316,34 @@ class _GenState:
 		self.live = torch.zeros(1, dtype=torch.int32, device=dev)        # unfinished rows, decremented on the device
 		self.done = torch.zeros(1, dtype=torch.int32).pin_memory()       # raised by the row that finishes last; polled by the host
 		self.rng_step = None                                             # generator offset consumed by one sample() call
-		self.history = torch.ones((B, trunc_index + max_new), dtype=torch.long, device=dev) if self.pipe.needs_history else None
-		# suppress_tokens and temperature are folded into the fused kernel (the common case); any other warper runs as torch ops
-		# first and the kernel then sees finished scores
+		# input_ids as the repetition penalty sees them: the fake prefix ids are all 1 with start_mel last (unified_voice.py:647-649),
+		# i.e. the SET {1, start_mel} whatever the text length (the penalty acts once per distinct id), then the sampled tokens
+		self.history = None
+		if self.pipe.needs_history:
+			self.history = torch.ones((B, 2 + max_new), dtype=torch.long, device=dev)
+		# everything but typical sampling runs inside the fused kernel (V <= 9216: the row lives in registers); the typical warper, when
+		# asked for, runs as torch ops in front of it in HF's order (after the processors, before temperature), which means the
+		# processors then run as torch ops too and the kernel sees finished scores for that part
 		p = self.pipe
-		self.fused_temperature = p.temperature or 1.0
-		self.fused = p.top_k is None and p.top_p is None and p.repetition_penalty is None and p.typical_mass is None
+		self.in_kernel = p.typical_mass is None and c.number_mel_codes <= 9216
+		self.graphable = self.in_kernel or not p.needs_history      # torch-op penalty: its history slice grows with the host's step count
+		a = _lib.SampleArgs()
+		a.ld, a.B, a.V = self.logits.stride(0), B, c.number_mel_codes
+		a.q, a.ldq = self.q.data_ptr(), self.q.stride(0)
+		a.stop_token = self.stop
+		a.unfinished, a.tok, a.ids = self.unfinished.data_ptr(), self.tok.data_ptr(), self.ids.data_ptr()
+		a.ids_ld, a.ids_cols, a.col = self.ids.stride(0), self.ids.shape[1], self.col.data_ptr()
+		if self.history is not None:
+			a.history, a.hist_ld, a.hist_off = self.history.data_ptr(), self.history.stride(0), 2
+		a.live_rows, a.all_done = self.live.data_ptr(), self.done.data_ptr()
+		if self.in_kernel:
+			a.scores = self.logits.data_ptr()
+			a.suppress = _lib.ptr(p.suppress_mask)
+			a.temperature = p.temperature or 1.0
+			a.top_k, a.top_p, a.repetition_penalty = p.top_k or 0, p.top_p or 1.0, p.repetition_penalty or 1.0
+		else:
+			a.temperature, a.top_k, a.top_p, a.repetition_penalty = 1.0, 0, 1.0, 1.0
+		self.args = a
 		self.graph = None
 
 	def reset(self, c):
@@ -305,23 +354,17 @@ class _GenState:
 		self.done.zero_()
 		if self.history is not None:
 			self.history.fill_(1)
-			self.history[:, self.trunc_index - 1] = c.start_mel_token
+			self.history[:, 1] = c.start_mel_token
 
 	def sample(self, n):
-		"""one token from self.logits: warp, sample, pad finished rows, record      (HF:generation/utils.py:2894-2937)"""
-		if self.fused:
-			scores, temperature, suppress = self.logits, self.fused_temperature, self.pipe.suppress_mask
-		else:
-			hist = None if self.history is None else self.history[:, :self.trunc_index + n]
-			scores, temperature, suppress = self.pipe(hist, self.logits), 1.0, None
-			if not scores.is_contiguous():
-				scores = scores.contiguous()
+		"""one token from self.logits: process / warp, sample, pad finished rows, record, and write the next step's input row
+		(HF:generation/utils.py:2894-2937; unified_voice.py:212-214)"""
+		a = self.args
+		if not self.in_kernel:
+			hist = None if self.history is None else self.history[:, :2 + n]
+			scores = self.pipe(hist, self.logits)
+			self.scores = scores if scores.is_contiguous() else scores.contiguous()      # kept alive until the launch has run
+			a.scores, a.ld = self.scores.data_ptr(), self.scores.stride(0)
 		# multinomial(softmax(scores), 1) == argmax(softmax(scores) / q), q ~ Exp(1) from the torch generator (see sampling.multinomial1)
 		self.q.exponential_(1)
-		V = scores.shape[1]
-		_lib.check(_lib.load().ttk_sample_step(scores.data_ptr(), scores.stride(0), self.B, V, self.q.data_ptr(), self.q.stride(0),
-											   _lib.ptr(suppress), float(temperature), self.stop, self.unfinished.data_ptr(), self.tok.data_ptr(),
-											   self.ids.data_ptr(), self.ids.stride(0), self.ids.shape[1], self.col.data_ptr(),
-											   _lib.ptr(self.history), 0 if self.history is None else self.history.stride(0),
-											   self.trunc_index, self.live.data_ptr(), self.done.data_ptr(), _lib.stream_ptr()),
-				   "ttk_sample_step")
+		_lib.check(self.model.lib.ttk_ar_sample_next(self.model._h, _lib.C.byref(a), _lib.stream_ptr()), "ttk_ar_sample_next")

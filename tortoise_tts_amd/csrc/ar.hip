@@ -89,6 +89,8 @@ struct ttk_ar {
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
 	int wv_proj = 8, wv_proj2 = 16;   // waves per workgroup of the two plain decode GEMVs (TTK_AR_WV_PROJ / TTK_AR_WV_PROJ2)
+	int wv_head = 4;                  // waves per workgroup of the ln_f + final_norm + mel_head launch (TTK_AR_WV_HEAD): 513 n-tiles; with 8-wave
+	                                  // workgroups two fit a CU (512 slots), so tile 513 ran as a second round on an empty chip; 4-wave ones fit four
 	int hfrag = 1;                // MLP activations of the decode step in MFMA-fragment order (TTK_AR_HFRAG=0: row-major)
 	int narrow2 = 4;              // same for mlp.c_proj (TTK_AR_NARROW2)
 	int narrow = 4;               // c_proj / mlp.c_proj decode GEMVs as 4-column workgroups without split-K (TTK_AR_NARROW=0: 16-column + split-K)
@@ -150,12 +152,12 @@ static void head_launch(ttk_ar* h, int B, float* logits, float* hidden_out, hipS
 	p.ln_count = 2; p.x = h->x; p.ldx = h->cfg.model_dim;
 	p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hidden_out;
 	p.mode = SK_STORE_F32; p.out_f32 = logits; p.ldc = h->cfg.number_mel_codes;
-	launch_skinny(h->dt, p, h->cfg.model_dim >= 1024 ? 8 : 4, s);
+	launch_skinny(h->dt, p, h->cfg.model_dim >= 1024 ? h->wv_head : 4, s);
 }
 
 // one row group [r0, r0 + nrows) of a decode step on stream s: 30 x {ln_1+c_attn+KV append, attention, c_proj+res, ln_2+c_fc+gelu,
 // mlp.c_proj+res} + ln_f/final_norm/mel_head
-static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out, float* hidden_out, hipStream_t s) {
+static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out, float* hidden_out, hipStream_t s, bool bump_pos) {
 	const ttk_ar_config& c = h->cfg;
 	const int d = c.model_dim, H = c.heads, dt = h->dt;
 	const size_t es = h->es;
@@ -200,7 +202,10 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	p.ln_count = 2; p.x = x; p.ldx = d;
 	p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hidden_out ? hidden_out + (size_t)r0 * d : nullptr;
 	p.mode = SK_STORE_F32; p.out_f32 = logits_out + (size_t)r0 * c.number_mel_codes; p.ldc = c.number_mel_codes;
-	launch_skinny(dt, p, d >= 1024 ? 8 : 4, s);
+	// the last launch of the step advances the cache length: every reader of *d_pos (c_attn epilogues, attention) is behind it on the
+	// stream, the next reader is the next step -- one 1-thread launch per token less (an otherwise unused field carries the pointer)
+	if (bump_pos) p.d_pos = h->d_pos;
+	launch_skinny(dt, p, d >= 1024 ? h->wv_head : 4, s);
 }
 
 extern "C" {
@@ -272,6 +277,8 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 		if (e1 && atoi(e1) >= 4 && atoi(e1) <= 16) h->wv_proj = atoi(e1);
 		h->wv_proj2 = h->narrow2 ? 16 : 8;
 		if (e2 && atoi(e2) >= 4 && atoi(e2) <= 16) h->wv_proj2 = atoi(e2);
+		const char* e3 = getenv("TTK_AR_WV_HEAD");
+		if (e3 && (atoi(e3) == 4 || atoi(e3) == 8)) h->wv_head = atoi(e3);
 		const char* e = getenv("TTK_AR_SPLIT");
 		h->nsplit = e ? atoi(e) : 1;
 		if (h->nsplit != 1 && h->nsplit != 2 && h->nsplit != 4) h->nsplit = 1;
@@ -322,16 +329,17 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
 	return TTK_OK;
 }
 
-int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidden_out, void* stream) {
-	TTK_REQUIRE(h && tok && logits_out, TTK_E_ARG, "ttk_ar_decode: null argument");
-	TTK_REQUIRE(h->ready, TTK_E_STATE, "ttk_ar_decode: call ttk_ar_prefill first");
+static int decode_impl(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidden_out, void* stream, const char* who) {
+	TTK_REQUIRE(h && logits_out, TTK_E_ARG, "%s: null argument", who);
+	TTK_REQUIRE(h->ready, TTK_E_STATE, "%s: call ttk_ar_prefill first", who);
 	const ttk_ar_config& c = h->cfg;
-	const int B = h->B, d = c.model_dim, H = c.heads, dt = h->dt;
-	TTK_REQUIRE(h->P + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "ttk_ar_decode: KV cache full (max_ctx=%d)", c.max_ctx);
-	TTK_REQUIRE(h->k + 2 < c.max_mel_seq_len, TTK_E_STATE, "ttk_ar_decode: mel position table exhausted (%d rows)", c.max_mel_seq_len);
+	const int B = h->B, d = c.model_dim;
+	TTK_REQUIRE(h->P + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "%s: KV cache full (max_ctx=%d)", who, c.max_ctx);
+	TTK_REQUIRE(h->k + 2 < c.max_mel_seq_len, TTK_E_STATE, "%s: mel position table exhausted (%d rows)", who, c.max_mel_seq_len);
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)
-	launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s);
+	// (tok == null: ttk_ar_sample_next has written the rows already)
+	if (tok) launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s);
 	// Experiment kept behind TTK_AR_SPLIT (default 1 = off): cut the candidates into row groups whose launch chains run on forked
 	// streams.  Rows are independent, so results are unchanged -- but on MI355X it LOSES (B=16, 250 tokens: 283 ms -> 340 ms with
 	// 2 groups, 517 ms with 4): the LayerNorm kernels already hold one 8-wave workgroup per CU, so the second chain cannot
@@ -345,16 +353,33 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
 	for (int gi = 0; gi < nsplit; ++gi) {
 		hipStream_t gs = gi == 0 ? s : h->side[gi - 1];
 		const int r0 = (B * gi) / nsplit, r1 = (B * (gi + 1)) / nsplit;
-		decode_rows(h, r0, r1 - r0, gi, logits_out, hidden_out, gs);
+		decode_rows(h, r0, r1 - r0, gi, logits_out, hidden_out, gs, nsplit == 1);
 	}
 	for (int gi = 1; gi < nsplit; ++gi) {
 		TTK_HIP(hipEventRecord(h->ev_join[gi - 1], h->side[gi - 1]));
 		TTK_HIP(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
 	}
-	launch_add_int(h->d_pos, 1, s);
+	if (nsplit > 1) launch_add_int(h->d_pos, 1, s);
 	h->k += 1;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
+}
+
+int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidden_out, void* stream) {
+	TTK_REQUIRE(tok, TTK_E_ARG, "ttk_ar_decode: null argument");
+	return decode_impl(h, tok, logits_out, hidden_out, stream, "ttk_ar_decode");
+}
+
+int ttk_ar_decode_next(ttk_ar* h, float* logits_out, float* hidden_out, void* stream) {
+	return decode_impl(h, nullptr, logits_out, hidden_out, stream, "ttk_ar_decode_next");
+}
+
+int ttk_ar_sample_next(ttk_ar* h, const ttk_sample_args* a, void* stream) {
+	TTK_REQUIRE(h && a, TTK_E_ARG, "ttk_ar_sample_next: null argument");
+	TTK_REQUIRE(h->ready, TTK_E_STATE, "ttk_ar_sample_next: call ttk_ar_prefill first");
+	TTK_REQUIRE(a->B == h->B && a->V == h->cfg.number_mel_codes, TTK_E_ARG, "ttk_ar_sample_next: shape (B %d, V %d) is not the prefilled one (B %d, V %d)",
+				a->B, a->V, h->B, h->cfg.number_mel_codes);
+	return launch_sample_step(a, h->mel_emb, h->mel_pos, h->x, h->cfg.model_dim, h->cfg.max_mel_seq_len, (hipStream_t)stream, "ttk_ar_sample_next");
 }
 
 int ttk_ar_latents(ttk_ar* h, const float* cond, const int64_t* text, int Tt, const int64_t* codes, int M, int B, float* latents_out, void* stream) {

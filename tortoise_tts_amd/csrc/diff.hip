@@ -383,19 +383,23 @@ int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise,
 	return TTK_OK;
 }
 
-int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream) {
-	TTK_REQUIRE(h && x && E && steps && n_steps >= 1, TTK_E_ARG, "ttk_diff_sample_ddim: bad argument");
-	TTK_REQUIRE(h->cfg.out_channels == 2 * h->cfg.in_channels, TTK_E_ARG, "ttk_diff_sample_ddim: learned-range output needs out = 2 * in channels");
+// The whole sampler loop, both samplers: steps[n-1], ..., steps[0]; `noise` (ancestral sampler) holds one [b, in, T] draw per step in the order
+// the loop consumes them (the j-th executed step reads block j), null for ddim.
+static int sample_loop(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, const float* noise, int sampler, void* stream, const char* who) {
+	TTK_REQUIRE(h && x && E && steps && n_steps >= 1, TTK_E_ARG, "%s: bad argument", who);
+	TTK_REQUIRE(sampler == 0 || noise, TTK_E_ARG, "%s: the p sampler needs one noise block per step", who);
+	TTK_REQUIRE(h->cfg.out_channels == 2 * h->cfg.in_channels, TTK_E_ARG, "%s: learned-range output needs out = 2 * in channels", who);
+	const size_t nz = (size_t)b * h->cfg.in_channels * T;
 	hipStream_t s = (hipStream_t)stream;
 	TTK_TRY(ttk_diff_begin(h, E, b, T, stream));
 	// the timestep-only work of ALL steps in one pass: [n_steps] rows through time_embed + every emb_layers (weights read once)
 	std::vector<int64_t> ts(n_steps);
-	for (int i = 0; i < n_steps; ++i) { ts[i] = steps[i].t; TTK_REQUIRE(steps[i].sampler == 0, TTK_E_ARG, "ttk_diff_sample_ddim: step %d is not a ddim step", i); }
+	for (int i = 0; i < n_steps; ++i) { ts[i] = steps[i].t; TTK_REQUIRE(steps[i].sampler == sampler, TTK_E_ARG, "%s: step %d has sampler %d", who, i, steps[i].sampler); }
 	TTK_TRY(time_path(h, nullptr, ts.data(), n_steps, s));
 	const int64_t stride = (int64_t)h->n_emb * 2 * h->cfg.model_channels;
 	const float* emb_all = (const float*)h->emb_all.p;
 	if (!h->pipe || n_steps < 2) {
-		for (int i = n_steps - 1; i >= 0; --i) TTK_TRY(step_impl(h, x, &steps[i], nullptr, emb_all + i * stride, s));
+		for (int i = n_steps - 1; i >= 0; --i) TTK_TRY(step_impl(h, x, &steps[i], noise ? noise + (size_t)(n_steps - 1 - i) * nz : nullptr, emb_all + i * stride, s));
 		TTK_HIP(hipGetLastError());
 		return TTK_OK;
 	}
@@ -432,10 +436,18 @@ int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, co
 		}
 		TTK_HIP(hipStreamWaitEvent(s, h->ev_int[j & 1], 0));
 		const int i = n_steps - 1 - j;
-		TTK_TRY(step_body(h, x, &steps[i], nullptr, emb_all + i * stride, csb[j & 1], h->ev_free[j & 1], s));
+		TTK_TRY(step_body(h, x, &steps[i], noise ? noise + (size_t)j * nz : nullptr, emb_all + i * stride, csb[j & 1], h->ev_free[j & 1], s));
 	}
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
+}
+
+int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream) {
+	return sample_loop(h, x, E, b, T, steps, n_steps, nullptr, 0, stream, "ttk_diff_sample_ddim");
+}
+
+int ttk_diff_sample_p(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, const float* noise, void* stream) {
+	return sample_loop(h, x, E, b, T, steps, n_steps, noise, 1, stream, "ttk_diff_sample_p");
 }
 
 }  // extern "C"

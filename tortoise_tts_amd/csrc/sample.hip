@@ -1,11 +1,22 @@
-// One sampled token per candidate row, fused: temperature -> softmax -> multinomial(1) -> finished-row padding -> bookkeeping.
+// One sampled token per candidate row, fused: the logits processors and warpers of the reference's sample branch, softmax,
+// multinomial(1), finished-row padding, bookkeeping and (AR-aware entry) the next decode step's input embedding.
 //
-// Reference: HF `_sample` as driven by stream_generator.py (warpers :56-101, then HF:generation/utils.py:2894-2937):
-//     probs = softmax(scores / T);  next = multinomial(probs, 1);  next = next * unfinished + pad * (1 - unfinished);
+// Reference: HF `_sample` as driven by stream_generator.py (processors / warpers :56-101, then HF:generation/utils.py:2894-2937):
+//     scores = top_p(top_k(temperature(suppress(repetition_penalty(input_ids, logits)))))
+//     probs = softmax(scores);  next = multinomial(probs, 1);  next = next * unfinished + pad * (1 - unfinished);
 //     input_ids = cat(input_ids, next);  unfinished &= next != eos
+// and the first lines of the following forward (unified_voice.py:212-214): emb = mel_embedding(next) + mel_pos_embedding[k + 1].
 // ATen's multinomial for one sample is `argmax(probs / q)` with q ~ Exp(1) drawn by `exponential_` on the caller's generator
 // (aten/src/ATen/native/Distributions.cpp).  The noise q stays a torch op in the caller so the Philox stream is the reference's; this
-// kernel is everything around it, i.e. ~15 tiny elementwise/reduction launches per token collapsed into one.
+// kernel is everything around it, i.e. the ~15-40 tiny elementwise / sort / reduction launches per token collapsed into one, with no
+// host round trip, so the whole token step stays inside one captured HIP graph for every warper combination of the CLI
+// (__main__.py:17-21: temperature 0.8, top-k 16, top-p 1, repetition penalty 1).
+//
+// Selection without sorting.  top-k needs the k-th largest score, top-p the smallest score whose ascending cumulative probability
+// exceeds 1 - top_p: both are a 4-pass radix descent over the order-preserving 32-bit key of the float (256-bin histogram in LDS per
+// pass) -- counts for top-k, fixed-point probability mass (p * 2^40 as 64-bit integers, so the sums are exact and independent of the
+// order in which the atomics land: bitwise reproducible) for top-p.  Everything at or above the threshold VALUE is kept, which is what
+// `scores < kth` / the sorted cumulative sum do except inside a group of exactly equal scores that straddles the top-p boundary.
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 #include "ttk_host.h"
@@ -14,6 +25,22 @@ namespace ttk {
 
 constexpr int SAMPLE_THREADS = 1024;
 constexpr int SAMPLE_NPT = 9;          // elements per thread held in registers on the fast path
+constexpr int SAMPLE_MAXV = SAMPLE_NPT * SAMPLE_THREADS;
+
+static_assert(sizeof(ttk_sample_args) == 160, "ttk_sample_args layout (tortoise_tts_amd/_lib.py: SampleArgs mirrors it)");
+
+struct SampleParams {
+	const float* scores; int64_t ld; int V;
+	const float* q; int64_t ldq;
+	const unsigned char* suppress; float inv_t;
+	int top_k; float top_p; float penalty, inv_penalty;          // 0 / >= 1 / 1 = off
+	int64_t stop_token;
+	int64_t *unfinished, *tok, *ids; int64_t ids_ld, ids_cols; int64_t* col;
+	int64_t* history; int64_t hist_ld, hist_off;
+	int *live_rows, *all_done;
+	// next decode step's input row (AR-aware entry only): x[b] = emb[next] + pos[col + 2]
+	const float *emb, *pos; float* x_out; int d, pos_rows;
+};
 
 __device__ __forceinline__ float block_max(float v, float* red, int tid) {
 	v = wave_max(v);
@@ -37,41 +64,180 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 	return s;
 }
 
-// grid = B rows, 1024 threads.  max, sum of exp, argmax of p / q over the row; rows up to 9216 wide stay in registers between the
-// three reductions, wider ones are re-read (32 KB, L2-resident after the first pass).
-__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* scores, int64_t ld, int V, const float* q, int64_t ldq, const unsigned char* suppress, float inv_t,
-		int64_t stop_token, int64_t* unfinished, int64_t* tok, int64_t* ids, int64_t ids_ld, int64_t ids_cols, int64_t* col, int64_t* history,
-		int64_t hist_ld, int64_t hist_off, int* live_rows, int* all_done) {
+// order-preserving key: a < b  <=>  key(a) < key(b)   (-inf lowest; NaNs sort to the ends and are not expected here)
+__device__ __forceinline__ unsigned fkey(float f) {
+	const unsigned u = __float_as_uint(f);
+	return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+
+// One level of the radix descent, run by wave 0 over the 256 bins `h` (counts or masses): walking the bins in DESCENDING (top-k) or
+// ASCENDING (top-p) order, find the first bin at which the running total reaches past `target` -- descending: total >= target (the
+// k-th largest lies in it), ascending: total > target (the first kept element lies in it).  Returns the bin and the total BEFORE it.
+template <typename C, bool DESC>
+__device__ __forceinline__ void pick_bin(const C* h, C target, int lane, int& bin_out, C& before_out) {
+	C g[4], s = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { const int b = DESC ? 255 - (4 * lane + i) : 4 * lane + i; g[i] = h[b]; s += g[i]; }
+	C incl = s;
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const C o = __shfl_up(incl, off);
+		if (lane >= off) incl += o;
+	}
+	const C excl = incl - s;
+	const bool hit = DESC ? (incl >= target) : (incl > target);
+	const unsigned long long m = __ballot(hit);
+	const int first = m ? __ffsll((long long)m) - 1 : 63;        // no lane reaches it (rounding of the total): take the last bin
+	int bin = DESC ? 255 - (4 * first + 3) : 4 * first + 3;
+	C before = excl + g[0] + g[1] + g[2];
+	if (lane == first) {
+		C run = excl;
+		bool found = false;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const bool here = DESC ? (run + g[i] >= target) : (run + g[i] > target);
+			if (!found && (here || i == 3)) { bin = DESC ? 255 - (4 * lane + i) : 4 * lane + i; before = run; found = true; }
+			run += g[i];
+		}
+	}
+	bin_out = __shfl(bin, first);
+	before_out = __shfl(before, first);
+}
+
+// grid = B rows, 1024 threads.  Rows up to 9216 wide (8194 mel codes = 9 per thread) stay in registers from the one trip to memory
+// to the argmax; wider rows take the plain three-pass path, which supports suppress + temperature only.
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(SampleParams p) {
 	__shared__ float red[SAMPLE_THREADS / 64];
 	__shared__ int redi[SAMPLE_THREADS / 64];
-	const int b = blockIdx.x, tid = threadIdx.x;
-	const float* s = scores + (int64_t)b * ld;
-	const float* qq = q + (int64_t)b * ldq;
+	__shared__ unsigned seen[SAMPLE_MAXV / 32];                  // repetition penalty: bit i = token i occurs in input_ids
+	__shared__ unsigned hist32[256];
+	__shared__ unsigned long long hist64[256];
+	__shared__ int s_bin;
+	__shared__ unsigned long long s_before;
+	__shared__ long long s_next;
+	const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+	const int V = p.V;
+	const float* s = p.scores + (int64_t)b * p.ld;
+	const float* qq = p.q + (int64_t)b * p.ldq;
 	// ATen divides a tensor by a host scalar as `x * (1 / t)` with the reciprocal rounded to f32 (BinaryDivTrueKernel.cu), and that
-	// is what TemperatureLogitsWarper's `scores / temperature` runs on the GPU; inv_t is that reciprocal.
-	const bool scale = inv_t != 1.0f;
+	// is what TemperatureLogitsWarper's `scores / temperature` and the penalty's `score / penalty` run on the GPU.
+	const bool scale = p.inv_t != 1.0f;
+	const int64_t c0 = p.col[b];
 	float best = -INFINITY;
 	int besti = 0x7fffffff;
-	if (V <= SAMPLE_NPT * SAMPLE_THREADS) {
-		// the row fits in registers (8194 mel codes = 9 per thread): one trip to memory for scores and noise, everything else on chip
+	if (V <= SAMPLE_MAXV) {
 		float v[SAMPLE_NPT], qv[SAMPLE_NPT];
 #pragma unroll
 		for (int j = 0; j < SAMPLE_NPT; ++j) {       // unconditional clamped loads: all 18 requests leave before the first use
 			const int i = tid + j * SAMPLE_THREADS, ic = i < V ? i : V - 1;
-			const float x = s[ic];
+			v[j] = s[ic];
 			qv[j] = qq[ic];
-			const bool sup = suppress && suppress[ic];
-			float t = sup ? -INFINITY : x;
-			t = scale ? t * inv_t : t;
+		}
+		// ---- RepetitionPenaltyLogitsProcessor: every id present in input_ids (prefix ids + tokens generated so far), once
+		if (p.penalty != 1.0f && p.history) {
+			for (int i = tid; i < SAMPLE_MAXV / 32; i += SAMPLE_THREADS) seen[i] = 0;
+			__syncthreads();
+			const int64_t* hrow = p.history + (int64_t)b * p.hist_ld;
+			const int64_t n = p.hist_off + c0;
+			for (int64_t i = tid; i < n; i += SAMPLE_THREADS) {
+				const int64_t t = hrow[i];
+				if (t >= 0 && t < V) atomicOr(&seen[t >> 5], 1u << (t & 31));
+			}
+			__syncthreads();
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) {
+				const int i = tid + j * SAMPLE_THREADS;
+				if (i < V && ((seen[i >> 5] >> (i & 31)) & 1)) v[j] = v[j] < 0.f ? v[j] * p.penalty : v[j] * p.inv_penalty;
+			}
+		}
+		// ---- SuppressTokensLogitsProcessor, TemperatureLogitsWarper
+#pragma unroll
+		for (int j = 0; j < SAMPLE_NPT; ++j) {
+			const int i = tid + j * SAMPLE_THREADS, ic = i < V ? i : V - 1;
+			float t = (p.suppress && p.suppress[ic]) ? -INFINITY : v[j];
+			t = scale ? t * p.inv_t : t;
 			v[j] = i < V ? t : -INFINITY;
+		}
+		// ---- TopKLogitsWarper: scores < (k-th largest) -> -inf
+		if (p.top_k > 0 && p.top_k < V) {
+			unsigned prefix = 0, mask = 0, remaining = (unsigned)p.top_k;
+			for (int pass = 3; pass >= 0; --pass) {
+				const int shift = 8 * pass;
+				if (tid < 256) hist32[tid] = 0;
+				__syncthreads();
+#pragma unroll
+				for (int j = 0; j < SAMPLE_NPT; ++j) {
+					const int i = tid + j * SAMPLE_THREADS;
+					const unsigned k = fkey(v[j]);
+					if (i < V && (k & mask) == prefix) atomicAdd(&hist32[(k >> shift) & 255], 1u);
+				}
+				__syncthreads();
+				if (tid < 64) {
+					int bin; unsigned before;
+					pick_bin<unsigned, true>(hist32, remaining, lane, bin, before);
+					if (tid == 0) { s_bin = bin; s_before = before; }
+				}
+				__syncthreads();
+				prefix |= (unsigned)s_bin << shift;
+				mask |= 0xffu << shift;
+				remaining -= (unsigned)s_before;
+			}
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j)
+				if (fkey(v[j]) < prefix) v[j] = -INFINITY;
 		}
 		float m = -INFINITY;
 #pragma unroll
 		for (int j = 0; j < SAMPLE_NPT; ++j) m = fmaxf(m, v[j]);
 		m = block_max(m, red, tid);
+		// ---- TopPLogitsWarper: ascending cumulative softmax <= 1 - top_p -> -inf (the largest score always stays)
+		if (p.top_p > 0.f && p.top_p < 1.0f) {
+			float e[SAMPLE_NPT], sum = 0.f;
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) { e[j] = expf(v[j] - m); sum += e[j]; }
+			sum = block_sum(sum, red, tid);
+			unsigned long long w[SAMPLE_NPT], tot = 0;
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) { w[j] = (unsigned long long)((e[j] / sum) * 1099511627776.0f); tot += w[j]; }
+			// block total of the integer masses (exact), to keep the target below it: the largest score is never removed
+			if (tid < 256) hist64[tid] = 0;
+			__syncthreads();
+			atomicAdd(&hist64[0], tot);
+			__syncthreads();
+			const unsigned long long total = hist64[0];
+			unsigned long long target = (unsigned long long)((1.0f - p.top_p) * 1099511627776.0f);
+			if (total > 0 && target >= total) target = total - 1;
+			__syncthreads();
+			unsigned prefix = 0, mask = 0;
+			unsigned long long below = 0;
+			for (int pass = 3; pass >= 0; --pass) {
+				const int shift = 8 * pass;
+				if (tid < 256) hist64[tid] = 0;
+				__syncthreads();
+#pragma unroll
+				for (int j = 0; j < SAMPLE_NPT; ++j) {
+					const unsigned k = fkey(v[j]);
+					if (w[j] && (k & mask) == prefix) atomicAdd(&hist64[(k >> shift) & 255], w[j]);
+				}
+				__syncthreads();
+				if (tid < 64) {
+					int bin; unsigned long long before;
+					pick_bin<unsigned long long, false>(hist64, target - below, lane, bin, before);
+					if (tid == 0) { s_bin = bin; s_before = before; }
+				}
+				__syncthreads();
+				prefix |= (unsigned)s_bin << shift;
+				mask |= 0xffu << shift;
+				below += s_before;
+			}
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j)
+				if (fkey(v[j]) < prefix) v[j] = -INFINITY;
+		}
+		// ---- softmax, multinomial(1) = argmax(p / q)
 		float sum = 0.f;
 #pragma unroll
-		for (int j = 0; j < SAMPLE_NPT; ++j) { v[j] = expf(v[j] - m); sum += v[j]; }      // exp(-inf) = 0 for the padding lanes
+		for (int j = 0; j < SAMPLE_NPT; ++j) { v[j] = expf(v[j] - m); sum += v[j]; }      // exp(-inf) = 0 for removed / padding lanes
 		sum = block_sum(sum, red, tid);
 #pragma unroll
 		for (int j = 0; j < SAMPLE_NPT; ++j) {
@@ -80,6 +246,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* sco
 			if (i < V && r > best) { best = r; besti = i; }          // strict: the lowest index wins a tie, as in ATen's argmax
 		}
 	} else {
+		const unsigned char* suppress = p.suppress;
+		const float inv_t = p.inv_t;
 		float m = -INFINITY;
 		for (int i = tid; i < V; i += SAMPLE_THREADS) { float v = (suppress && suppress[i]) ? -INFINITY : s[i]; v = scale ? v * inv_t : v; m = fmaxf(m, v); }
 		m = block_max(m, red, tid);
@@ -106,22 +274,57 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* sco
 		for (int w = 1; w < SAMPLE_THREADS / 64; ++w)
 			if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
 		if (besti >= V) besti = 0;                       // all-NaN / empty row: ATen returns index 0 as well
-		const int64_t live = unfinished[b];
-		const int64_t nxt = (int64_t)besti * live + stop_token * (1 - live);
-		tok[b] = nxt;
-		const int64_t c = col[b];
-		if (c < ids_cols) ids[(int64_t)b * ids_ld + c] = nxt;
-		if (history) history[(int64_t)b * hist_ld + hist_off + c] = nxt;
-		col[b] = c + 1;
-		const int64_t still = live * (nxt != stop_token ? 1 : 0);
-		unfinished[b] = still;
+		const int64_t live = p.unfinished[b];
+		const int64_t nxt = (int64_t)besti * live + p.stop_token * (1 - live);
+		p.tok[b] = nxt;
+		if (c0 < p.ids_cols) p.ids[(int64_t)b * p.ids_ld + c0] = nxt;
+		if (p.history) p.history[(int64_t)b * p.hist_ld + p.hist_off + c0] = nxt;
+		p.col[b] = c0 + 1;
+		const int64_t still = live * (nxt != p.stop_token ? 1 : 0);
+		p.unfinished[b] = still;
+		s_next = nxt;
 		// stopping criterion without a host round trip per token: the row that finishes last raises a flag the host can poll (the
 		// flag may live in pinned host memory; it only ever goes 0 -> 1 within a generation, so a late read is merely late)
-		if (live_rows && live != 0 && still == 0) {
-			if (__hip_atomic_fetch_add(live_rows, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1 && all_done)
-				__hip_atomic_store(all_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (p.live_rows && live != 0 && still == 0) {
+			if (__hip_atomic_fetch_add(p.live_rows, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1 && p.all_done)
+				__hip_atomic_store(p.all_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 	}
+	if (p.x_out) {
+		// the row the following decode step starts from: mel_embedding[next] + mel_pos_embedding[k + 1], k = c0 + 1 tokens generated
+		// (unified_voice.py:212-214) -- what a separate gather launch did before the first layer
+		__syncthreads();
+		const int64_t nxt = s_next;
+		int64_t pi = c0 + 2;
+		pi = pi < p.pos_rows ? pi : p.pos_rows - 1;      // guard; the host validates lengths up front
+		const float4* e = (const float4*)(p.emb + nxt * p.d);
+		const float4* w = (const float4*)(p.pos + pi * p.d);
+		float4* o = (float4*)(p.x_out + (int64_t)b * p.d);
+		for (int i = tid; i < p.d / 4; i += SAMPLE_THREADS) {
+			const float4 a = e[i], c = w[i];
+			o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+		}
+	}
+}
+
+int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* pos, float* x_out, int d, int pos_rows, hipStream_t stream, const char* who) {
+	TTK_REQUIRE(a && a->scores && a->q && a->unfinished && a->tok && a->ids && a->col, TTK_E_ARG, "%s: null argument", who);
+	TTK_REQUIRE(a->B >= 1 && a->V >= 1 && a->ld >= a->V && a->ldq >= a->V, TTK_E_ARG, "%s: bad shape (B %d, V %d)", who, a->B, a->V);
+	TTK_REQUIRE(a->temperature > 0.f, TTK_E_ARG, "%s: temperature must be positive", who);
+	const bool warp = a->top_k > 0 || (a->top_p > 0.f && a->top_p < 1.0f) || (a->repetition_penalty > 0.f && a->repetition_penalty != 1.0f);
+	TTK_REQUIRE(!warp || a->V <= SAMPLE_MAXV, TTK_E_ARG, "%s: top-k / top-p / repetition penalty need V <= %d (V %d)", who, SAMPLE_MAXV, a->V);
+	TTK_REQUIRE(a->top_p >= 0.f && a->repetition_penalty >= 0.f, TTK_E_ARG, "%s: negative top_p / repetition_penalty", who);
+	TTK_REQUIRE(!(a->repetition_penalty > 0.f && a->repetition_penalty != 1.0f) || a->history, TTK_E_ARG, "%s: the repetition penalty needs the history buffer", who);
+	SampleParams p = {};
+	p.scores = a->scores; p.ld = a->ld; p.V = a->V; p.q = a->q; p.ldq = a->ldq; p.suppress = a->suppress; p.inv_t = 1.0f / a->temperature;
+	p.top_k = a->top_k; p.top_p = a->top_p;
+	p.penalty = a->repetition_penalty > 0.f ? a->repetition_penalty : 1.0f; p.inv_penalty = 1.0f / p.penalty;
+	p.stop_token = a->stop_token; p.unfinished = a->unfinished; p.tok = a->tok; p.ids = a->ids; p.ids_ld = a->ids_ld; p.ids_cols = a->ids_cols;
+	p.col = a->col; p.history = a->history; p.hist_ld = a->hist_ld; p.hist_off = a->hist_off; p.live_rows = a->live_rows; p.all_done = a->all_done;
+	p.emb = emb; p.pos = pos; p.x_out = x_out; p.d = d; p.pos_rows = pos_rows;
+	hipLaunchKernelGGL(k_sample_step, dim3(a->B), dim3(SAMPLE_THREADS), 0, stream, p);
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
 }
 
 }  // namespace ttk
@@ -129,12 +332,13 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(const float* sco
 extern "C" int ttk_sample_step(const float* scores, int64_t ld, int B, int V, const float* q, int64_t ldq, const unsigned char* suppress, float temperature,
 		int64_t stop_token, int64_t* unfinished, int64_t* tok, int64_t* ids, int64_t ids_ld, int64_t ids_cols, int64_t* col, int64_t* history, int64_t hist_ld,
 		int64_t hist_off, int* live_rows, int* all_done, void* stream) {
-	using namespace ttk;
-	TTK_REQUIRE(scores && q && unfinished && tok && ids && col, TTK_E_ARG, "ttk_sample_step: null argument");
-	TTK_REQUIRE(B >= 1 && V >= 1 && ld >= V && ldq >= V, TTK_E_ARG, "ttk_sample_step: bad shape (B %d, V %d)", B, V);
-	TTK_REQUIRE(temperature > 0.f, TTK_E_ARG, "ttk_sample_step: temperature must be positive");
-	hipLaunchKernelGGL(k_sample_step, dim3(B), dim3(SAMPLE_THREADS), 0, (hipStream_t)stream, scores, ld, V, q, ldq, suppress, 1.0f / temperature, stop_token, unfinished, tok,
-					   ids, ids_ld, ids_cols, col, history, hist_ld, hist_off, live_rows, all_done);
-	TTK_HIP(hipGetLastError());
-	return TTK_OK;
+	ttk_sample_args a = {};
+	a.scores = scores; a.ld = ld; a.B = B; a.V = V; a.q = q; a.ldq = ldq; a.suppress = suppress; a.temperature = temperature; a.top_k = 0; a.top_p = 1.0f;
+	a.repetition_penalty = 1.0f; a.stop_token = stop_token; a.unfinished = unfinished; a.tok = tok; a.ids = ids; a.ids_ld = ids_ld; a.ids_cols = ids_cols;
+	a.col = col; a.history = history; a.hist_ld = hist_ld; a.hist_off = hist_off; a.live_rows = live_rows; a.all_done = all_done;
+	return ttk::launch_sample_step(&a, nullptr, nullptr, nullptr, 0, 0, (hipStream_t)stream, "ttk_sample_step");
+}
+
+extern "C" int ttk_sample_step_warped(const ttk_sample_args* a, void* stream) {
+	return ttk::launch_sample_step(a, nullptr, nullptr, nullptr, 0, 0, (hipStream_t)stream, "ttk_sample_step_warped");
 }

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		}
 	};
 	TTK_STAMP(0);
+	// the cache row the c_attn epilogue appends at: requested now (first in the vmcnt order), not as one more dependent round trip at the end
+	int kv_pos = 0;
+	if (p.mode == SK_QKV) kv_pos = *p.d_pos;
+	// mel_head launch of a decode step: one thread advances the cache length for the next step (nothing in this launch reads it)
+	if (p.mode == SK_STORE_F32 && p.d_pos && blockIdx.x == 0 && threadIdx.x == 0) *(int*)p.d_pos += 1;
 	// Epilogue role of the first 256 threads: element (row 4*(l2>>4)+r of each m-tile, column l2&15) of the 16-wide output tile.  Its
 	// bias and, for the residual modes, the current value of the output are requested now, ahead of everything else, so the epilogue
 	// finds them in registers instead of paying one more dependent L2 round trip after the reduction.
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			} else {
 				const int h = c >> 6, dd = c & 63;
 				T* cache = (T*)(which == 1 ? p.kcache : p.vcache);
-				const int pos = *p.d_pos;
+				const int pos = kv_pos;
 				if (pos < p.max_ctx) cache[(((int64_t)m * p.H + h) * p.max_ctx + pos) * 64 + dd] = cvt<T>(v);   // guard: never write past the cache
 			}
 		}

@@ -94,6 +94,9 @@ struct Mat {
 int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, int layout,
 			   int N, int K, bool frag, Mat* out, int ntap = 0);   // ntap: kernel size for PK_CONVK / PK_CONVT
 
+// sample.hip: the fused per-token sampling launch; emb / pos / x_out non-null = also write the next decode step's input rows
+int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* pos, float* x_out, int d, int pos_rows, hipStream_t stream, const char* who);
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 }  // namespace ttk

@@ -287,12 +287,11 @@ class SpacedDiffusion:
 					for _ in range(n):
 						torch.randn_like(x)
 			else:
-				_lib.check(model.lib.ttk_diff_begin(model._h, E.data_ptr(), b, T, _lib.stream_ptr()), "ttk_diff_begin")
-				for i in reversed(range(n)):
-					nz = torch.randn_like(x)                                   # p_sample :545
-					st = self.step_coefs(i, "p")
-					_lib.check(model.lib.ttk_diff_step(model._h, x.data_ptr(), _lib.C.byref(st), nz.data_ptr(), _lib.stream_ptr()),
-							   "ttk_diff_step")
+				# p_sample draws one randn_like(x) per step (:545), in loop order: drawn here, consumed by the whole-loop entry
+				nz = torch.stack([torch.randn_like(x) for _ in range(n)])
+				steps = (_lib.StepC * n)(*[self.step_coefs(i, "p") for i in range(n)])
+				_lib.check(model.lib.ttk_diff_sample_p(model._h, x.data_ptr(), E.data_ptr(), b, T, steps, n, nz.data_ptr(), _lib.stream_ptr()),
+						   "ttk_diff_sample_p")
 		return x
 
 
