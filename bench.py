@@ -12,8 +12,14 @@ workload configs[1]: one utterance per GPU, 64 text tokens, 16 AR candidates x 2
 step     one utterance through the whole hot path (tortoise_tts_amd/inference.py: inference.py:331-413 of the reference).
 N > 1    weak scaling: every rank runs its own utterance (BASELINE configs[2]); the only exchange is one RCCL all-gather of
          the sampled candidate ids per utterance (the hand-off to candidate scoring); value = N * audio / max-rank time.
-Also reported: `roofline` of the dominant kernel (HIP events inside libttk, see ttk_prof_*) and `cpu_baseline` (the CPU
-oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+Also reported: `roofline` of the dominant kernel (HIP events inside libttk, see ttk_prof_*) with `roofline.phases` (AR decode
+against the HBM peak, latent pass and DDIM loop against the MFMA peak, from device events around the phases of one more
+un-instrumented step and SURVEY.md section 8d's algorithmic work), and `cpu_baseline` (the CPU oracle on a bounded sample of the
+same workload, rank 0, N = 1 only).
+
+--shard candidates   BASELINE configs[3] instead (not the headline line): ONE long-form utterance at a time, 2 lines x 256 text
+         tokens, 32 candidates per GPU (256 at N = 8) x 500 mel tokens, 200 DDIM steps at T = 2176; candidates sharded over the ranks
+         (tortoise_tts_amd/dist.py: ids all-gathered over RCCL, scores all-gathered, the winner's owner diffuses, mel broadcast).
 """
 import argparse
 import json
@@ -40,14 +46,19 @@ def parse():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-roofline", action="store_true")
 	ap.add_argument("--small", action="store_true", help="tiny models (plumbing check only; the number is NOT the metric)")
+	ap.add_argument("--shard", default="utterances", choices=["utterances", "candidates"],
+					help="utterances: configs[1]/[2], one utterance per GPU (the headline metric); candidates: configs[3], one utterance's candidates over the GPUs")
 	return ap.parse_args()
 
 
 def cpu_baseline(seed):
-	"""The CPU oracle (oracle/tortoise_oracle.py, kind 'port') on a bounded sample of the same workload, on this box's host
-	cores: 16 KV-cached decode steps at B=16 after a prefill (scaled to 250), and 4 DDIM steps (cond + cond-free evaluation)
-	at T = 544 frames, scaled by the network's flop model F(T) to T = 1088 and to 80 steps."""
+	"""The CPU oracle (oracle/tortoise_oracle.py, kind 'port') on a bounded sample of the same workload, on this box's host cores, as
+	BASELINE.md section 3 lays out: phases timed separately with time.perf_counter after a warm-up, medians of repeated samples --
+	prefill at B=16 (second run timed), KV-cached decode steps at B=16 (median of 3 groups of 8 steps, scaled to 250), the latent
+	pass on the 16 candidates at its full length (one run), DDIM steps at the FULL T = 1088 (1 warm-up + median of 8 steps, each a
+	conditioned + a conditioning-free evaluation, scaled to 80)."""
 	sys.path.insert(0, os.path.join(ROOT, "oracle"))
+	import statistics
 	import tortoise_oracle as O
 	from tortoise_tts_amd import weights as W
 	# the GPU box gives a 1-GPU job a 16-core share whatever os.cpu_count() says; oversubscribing it is pathologically slow
@@ -58,38 +69,91 @@ def cpu_baseline(seed):
 	cores = max(1, min(cores, 16))
 	torch.set_num_threads(cores)
 	g = torch.Generator().manual_seed(seed)
+	T = MEL_TOKENS * 4 * 24000 // 22050
 	with torch.inference_mode():
 		ar = O.AROracle(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL)
 		text = torch.randint(1, 255, (1, TEXT_TOKENS), generator=g)
 		cond = torch.randn(1, 1024, generator=g)
+		prefix = ar.prefix_embeddings(cond, text)
+		ar.prefill(prefix, CANDIDATES)                                   # warm-up
 		t0 = time.perf_counter()
-		logits, past, _ = ar.prefill(ar.prefix_embeddings(cond, text), CANDIDATES)
+		logits, past, _ = ar.prefill(prefix, CANDIDATES)
 		t_prefill = time.perf_counter() - t0
 		tok = torch.randint(0, 8192, (CANDIDATES,), generator=g)
-		n_dec = 16
-		t0 = time.perf_counter()
-		for k in range(1, n_dec + 1):
+		k = 0
+		for _ in range(2):                                               # warm-up steps
+			k += 1
 			_, past, _ = ar.decode(tok, k, past)
-		t_dec = (time.perf_counter() - t0) / n_dec
-		del ar, past
-		d = O.DiffusionOracle(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL)
-		Ts, n_st = 544, 4
-		x = torch.randn(1, 100, Ts, generator=g)
-		E = torch.randn(1, 1024, Ts, generator=g)
-		sched = O.SpacedSchedule(steps=DDIM_STEPS)
+		groups = []
+		for _ in range(3):
+			t0 = time.perf_counter()
+			for _ in range(8):
+				k += 1
+				_, past, _ = ar.decode(tok, k, past)
+			groups.append((time.perf_counter() - t0) / 8)
+		t_dec = statistics.median(groups)
+		del past
+		codes = torch.randint(0, 8192, (CANDIDATES, MEL_TOKENS), generator=g)
 		t0 = time.perf_counter()
-		for i in range(n_st):
-			x = sched.ddim_step(d, x, DDIM_STEPS - 1 - i, E)
-		t_step = (time.perf_counter() - t0) / n_st
-
-	def F(T):   # flop per evaluation, SURVEY.md section 8d
-		return 236 * 1024 ** 2 * T + 52 * 1024 * T * T + 1_843_200 * T
-	T = MEL_TOKENS * 4 * 24000 // 22050
-	est = t_prefill + MEL_TOKENS * t_dec + DDIM_STEPS * t_step * F(T) / F(Ts)
+		ar.forward_latents(cond.repeat(CANDIDATES, 1), text.repeat(CANDIDATES, 1), codes)
+		t_lat = time.perf_counter() - t0
+		del ar
+		d = O.DiffusionOracle(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL)
+		x = torch.randn(1, 100, T, generator=g)
+		E = torch.randn(1, 1024, T, generator=g)
+		sched = O.SpacedSchedule(steps=DDIM_STEPS)
+		x = sched.ddim_step(d, x, DDIM_STEPS - 1, E)                      # warm-up
+		steps = []
+		for i in range(8):
+			t0 = time.perf_counter()
+			x = sched.ddim_step(d, x, DDIM_STEPS - 2 - i, E)
+			steps.append(time.perf_counter() - t0)
+		t_step = statistics.median(steps)
+	est = t_prefill + MEL_TOKENS * t_dec + t_lat + DDIM_STEPS * t_step
 	audio = T * 256 / 24000
 	return {"value": audio / est, "unit": "audio-sec/wall-sec", "cores": cores, "kind": "port",
-			"sample": f"prefill + {n_dec} decode steps at B=16 (scaled to 250) + {n_st} DDIM steps at T={Ts} scaled by F(T) to T={T} and to 80 steps; "
-					  f"measured {t_prefill:.2f}s + {t_dec * 1e3:.0f} ms/decode-step + {t_step:.2f} s/DDIM-step; latent pass not included"}
+			"torch": torch.__version__, "seconds_per_utterance": est,
+			"sample": f"B=16: prefill (2nd run) {t_prefill:.2f} s + decode {t_dec * 1e3:.0f} ms/step (median of 3 groups of 8, scaled to {MEL_TOKENS}) + "
+					  f"latent pass on 16 candidates x {MEL_TOKENS} tokens {t_lat:.2f} s (one run) + DDIM {t_step:.2f} s/step at T={T} "
+					  f"(cond + cond-free evaluation; 1 warm-up, median of 8 steps, scaled to {DDIM_STEPS}); fp32, {cores} threads"}
+
+
+def phase_roofline(marks, dtype_name):
+	"""Per-phase roofline fractions (SURVEY.md section 8d / BASELINE.md section 4): AR decode is HBM-bound (weights streamed once per
+	token + the KV cache read), the latent pass and the DDIM loop are MFMA-bound.  `marks`: (name, event) pairs from
+	TTSHotPath.inference(phase_marks=...) of one step run exactly as the timed ones (captured graph, no instrumentation)."""
+	ms = {marks[i + 1][0]: marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)}
+	e_w = {"bf16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
+	e_kv = 4 if dtype_name == "f32" else 2
+	peak_f = 157.3e12 if dtype_name == "f32" else 2.5e15
+	P1 = TEXT_TOKENS + 4                                    # prefix rows incl. start_mel
+	# prefill: dense pass over P1 rows x B; decode step k (k = 1..M-1) reads a cache of P1 + k - 1 rows and writes one
+	blocks, head = 377_886_720, 8_398_850 + 4_096
+	ar_bytes = 0.0
+	for k in range(1, MEL_TOKENS):
+		ctx = P1 + k
+		ar_bytes += blocks * e_w + head * (2 if e_w == 1 else e_w) + CANDIDATES * 30 * 2 * ctx * 1024 * e_kv + CANDIDATES * 8194 * 4
+	prefill_flop = 2.0 * blocks * P1 * CANDIDATES + 2.0 * P1 * P1 * 1024 * 30 * CANDIDATES
+	S = TEXT_TOKENS + MEL_TOKENS + 5
+	lat_flop = 2.0 * blocks * S * CANDIDATES + 2.0 * S * S * 1024 * 30 * CANDIDATES
+	T = MEL_TOKENS * 4 * 24000 // 22050
+	F = 236 * 1024 ** 2 * T + 52 * 1024 * T * T + 1_843_200 * T
+	ddim_flop = DDIM_STEPS * 2.0 * F
+	ar_floor = ar_bytes / 8.0e12 * 1e3 + prefill_flop / peak_f * 1e3
+	out = {
+		"ar_decode": {"bound": "hbm", "algorithmic_bytes": ar_bytes, "prefill_flop": prefill_flop, "ms": ms["ar_decode"],
+					  "achieved_GBps": ar_bytes / (ms["ar_decode"] * 1e-3) / 1e9, "frac": ar_bytes / (ms["ar_decode"] * 1e-3) / 8.0e12,
+					  "floor_ms": ar_floor, "note": "prefill + 250 sampled tokens; bytes = 249 KV-cached steps (weights once per step + KV read + logits)"},
+		"latent_pass": {"bound": "mfma", "flop": lat_flop, "ms": ms["latent_pass"], "achieved_TFLOPs": lat_flop / (ms["latent_pass"] * 1e-3) / 1e12,
+						"frac": lat_flop / (ms["latent_pass"] * 1e-3) / peak_f, "floor_ms": lat_flop / peak_f * 1e3},
+		"ddim": {"bound": "mfma", "flop": ddim_flop, "ms": ms["ddim"], "achieved_TFLOPs": ddim_flop / (ms["ddim"] * 1e-3) / 1e12,
+				 "frac": ddim_flop / (ms["ddim"] * 1e-3) / peak_f, "floor_ms": ddim_flop / peak_f * 1e3,
+				 "note": "timestep-independent conditioning + 80 steps x (cond + cond-free evaluation); flop = 160 F(T)"},
+	}
+	out["whole_step_floor_ms"] = out["ar_decode"]["floor_ms"] + out["latent_pass"]["floor_ms"] + out["ddim"]["floor_ms"]
+	out["whole_step_ms"] = sum(ms.values())
+	out["whole_step_frac_of_floor"] = out["whole_step_floor_ms"] / out["whole_step_ms"]
+	return out
 
 
 def log(msg):
@@ -125,8 +189,16 @@ def main():
 	from tortoise_tts_amd.inference import TTSHotPath
 	_lib.load()
 	ar_cfg, df_cfg = (W.AR_SMALL, W.DIFF_SMALL) if a.small else (W.AR_FULL, W.DIFF_FULL)
-	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(ar_cfg), 0), ar_cfg, dtype=a.dtype, device=dev, max_batch=CANDIDATES,
-					  max_ctx=TEXT_TOKENS + 4 + MEL_TOKENS + 8)
+	by_cand = a.shard == "candidates"
+	# configs[3]: per-GPU shard of 32 candidates, 2 lines x 256 text tokens, 500 mel tokens (T = 2176), 200 DDIM steps
+	n_text, n_cand, n_mel, n_ddim, n_lines = (256, 32, 500, 200, 2) if by_cand else (TEXT_TOKENS, CANDIDATES, MEL_TOKENS, DDIM_STEPS, 1)
+	if by_cand and world == 1:
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		os.environ.setdefault("MASTER_PORT", "29533")
+		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+		dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))      # the sharded entry runs on a group of any size
+	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(ar_cfg), 0), ar_cfg, dtype=a.dtype, device=dev, max_batch=n_cand,
+					  max_ctx=n_text + 4 + n_mel + 8)
 	df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(df_cfg), 0), df_cfg, dtype=a.dtype, device=dev)
 	voc = None
 	if a.with_vocoder:
@@ -134,17 +206,25 @@ def main():
 		vcfg = W.VOC_SMALL if a.small else W.VOC_FULL
 		voc = BigVGAN(W.synth_state_dict(W.vocoder_shapes(vcfg), 0), vcfg, dtype="f32" if a.dtype == "f32" else "bf16", device=dev)
 	tts = TTSHotPath(ar, df, vocoder=voc)
-	g = torch.Generator().manual_seed(1234 + rank)
-	text = torch.randint(1, 255, (1, TEXT_TOKENS), generator=g).to(dev)
+	g = torch.Generator().manual_seed(1234 + (0 if by_cand else rank))     # candidate shards: every rank holds the SAME utterance
+	lines = [torch.randint(1, 255, (1, n_text), generator=g).to(dev) for _ in range(n_lines)]
+	text = lines[0]
 	ar_lat = torch.randn(1, ar_cfg.model_dim, generator=g).to(dev)
 	df_lat = torch.randn(1, 2 * df_cfg.model_channels, generator=g).to(dev)
-	kw = dict(max_ar_steps=MEL_TOKENS, max_diffusion_steps=DDIM_STEPS, ar_temp=0.8, candidates=CANDIDATES,
+	kw = dict(max_ar_steps=n_mel, max_diffusion_steps=n_ddim, ar_temp=0.8, candidates=n_cand,
 			  suppress_tokens=[ar_cfg.stop_mel_token], return_all=True)
 	gdev = "cpu" if rehearsal else dev
-	gathered = [torch.empty((CANDIDATES, MEL_TOKENS), dtype=torch.long, device=gdev) for _ in range(world)] if world > 1 else None
+	gathered = [torch.empty((CANDIDATES, MEL_TOKENS), dtype=torch.long, device=gdev) for _ in range(world)] if world > 1 and not by_cand else None
 
-	def step(exchange=True):
-		mels, seconds, aux = tts.inference(text, ar_lat, df_lat, **kw)
+	def step(exchange=True, marks=None):
+		if by_cand:     # one long-form utterance: its lines one after the other, each with its candidates sharded over the ranks
+			skw = {k: v for k, v in kw.items() if k != "candidates"}
+			total = 0.0
+			for line in lines:
+				mels, seconds, aux = tts.inference_sharded(line, ar_lat, df_lat, candidates=n_cand * world, **skw)
+				total += seconds
+			return total
+		mels, seconds, aux = tts.inference(text, ar_lat, df_lat, phase_marks=marks, **kw)
 		if voc is not None:
 			voc.inference(mels)
 		if world > 1 and exchange:   # hand the candidate ids to the scoring rank (RCCL all-gather over xGMI, 32 KB per rank)
@@ -174,13 +254,18 @@ def main():
 
 	log(f"timed {a.steps} steps in {dt:.3f}s")
 	roof = None
-	if rank == 0 and not a.no_roofline:
+	if rank == 0 and not a.no_roofline and not by_cand:
 		from tortoise_tts_amd import profiling
+		marks = []
+		step(exchange=False, marks=marks)                  # one more step, run exactly as the timed ones, with events at the phase boundaries
+		torch.cuda.synchronize()
 		roof = profiling.dominant_kernel_roofline(lambda: step(exchange=False), ar, df)   # rank 0 alone: no collective in here
+		if not a.small:
+			roof["phases"] = phase_roofline(marks, a.dtype)
 	# informational, never `value`: a stream of utterances with line i's diffusion overlapped with line i+1's sampling
 	# (TTSHotPath.inference_lines; identical results).  `value` above stays the one-utterance-at-a-time figure of configs[1].
 	piped = None
-	if rank == 0 and world == 1 and not a.no_roofline:
+	if rank == 0 and world == 1 and not a.no_roofline and not by_cand:
 		n_lines = 4
 		lkw = {k: v for k, v in kw.items() if k != "return_all"}
 		tts.inference_lines([text] * 2, ar_lat, df_lat, **lkw)
@@ -193,24 +278,32 @@ def main():
 				 "note": "software-pipelined stream of utterances; not the headline metric"}
 	log("roofline pass done; cpu baseline")
 	cpu = None
-	if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:
+	if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small and not by_cand:
 		cpu = cpu_baseline(1234)
 
 	if rank == 0:
+		cfg_line = {"workload": "configs[1]: 1 utterance/GPU, 64 text tokens, 16 AR candidates x 250 mel tokens (KV-cached decode), "
+								"latent pass on 16 candidates, 80 DDIM steps with cond-free guidance at T=1088 (11.6 s audio)",
+					"text_tokens": TEXT_TOKENS, "candidates": CANDIDATES, "mel_tokens": MEL_TOKENS, "ddim_steps": DDIM_STEPS,
+					"mel_frames": MEL_TOKENS * 4 * 24000 // 22050, "parallelism": f"utterances x{world}" if world > 1 else "single GPU",
+					"small_models": bool(a.small), "vocoder_in_step": bool(a.with_vocoder)}
+		if by_cand:
+			cfg_line = {"workload": f"configs[3]: one long-form utterance = 2 lines x 256 text tokens, {n_cand * world} AR candidates ({n_cand} per GPU) x 500 mel "
+									"tokens, latent pass + candidate choice on every shard, 200 DDIM steps with cond-free guidance at T=2176 (23.2 s audio per line) "
+									"on the winner's GPU; ids / scores all-gathered and the mel broadcast over RCCL",
+						"text_tokens": n_text, "candidates": n_cand * world, "mel_tokens": n_mel, "ddim_steps": n_ddim, "lines": n_lines,
+						"mel_frames": n_mel * 4 * 24000 // 22050, "parallelism": f"candidates x{world}", "small_models": bool(a.small)}
 		line = {
-			"metric": "audio-sec/wall-sec (RTF^-1), 16 AR candidates x 80 DDIM steps", "value": world * audio / dt,
+			"metric": "audio-sec/wall-sec (RTF^-1), 16 AR candidates x 80 DDIM steps" if not by_cand else "audio-sec/wall-sec (RTF^-1), 32 AR candidates per GPU x 200 DDIM steps (configs[3])",
+			"value": (1 if by_cand else world) * audio / dt,
 			"unit": "audio-sec/wall-sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
 			"ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": a.dtype, "data": "synthetic",
-			"config": {"workload": "configs[1]: 1 utterance/GPU, 64 text tokens, 16 AR candidates x 250 mel tokens (KV-cached decode), "
-								   "latent pass on 16 candidates, 80 DDIM steps with cond-free guidance at T=1088 (11.6 s audio)",
-					   "text_tokens": TEXT_TOKENS, "candidates": CANDIDATES, "mel_tokens": MEL_TOKENS, "ddim_steps": DDIM_STEPS,
-					   "mel_frames": MEL_TOKENS * 4 * 24000 // 22050, "parallelism": f"utterances x{world}" if world > 1 else "single GPU",
-					   "small_models": bool(a.small), "vocoder_in_step": bool(a.with_vocoder)},
+			"config": cfg_line,
 			"roofline": roof, "cpu_baseline": cpu, "pipelined_lines": piped,
 		}
 		print(json.dumps(line), flush=True)
-	if world > 1:
+	if dist.is_initialized():
 		dist.destroy_process_group()
 
 

@@ -84,6 +84,11 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
  *   new row, what `sample_stream` yields (stream_generator.py:1172).                                               */
 int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidden_out, void* stream);
 
+/* final_norm(ln_f(h)) [B, D] f32 of the newest row: after ttk_ar_prefill the prefix's last row, after a decode step that step's row
+ * (valid until the next ttk_ar_sample_next / decode call reuses the row buffer).  `sample_stream` yields this next to the token sampled
+ * from the same forward's logits (stream_generator.py:1172) -- for the first token that is the prefill's row.                     */
+int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream);
+
 /* One sampled token per candidate, the body of HF `_sample` that stream_generator.py drives (warpers :56-101; HF:generation/
  * utils.py:2894-2937): probs = softmax(scores / temperature); next = multinomial(probs, 1) = argmax(probs / q) with q the caller's
  * Exp(1) noise [B, V] (torch `exponential_`, so the generator stream is the reference's); finished rows get `stop_token`;

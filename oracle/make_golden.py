@@ -200,6 +200,79 @@ def wrapper_case(uv_mod):
 	return out
 
 
+SAMPLE_STREAM_CASES = (
+	# name, weight seed, stop-token bias added to mel_head.bias, B, Tt, max new tokens, generation keywords
+	("temperature", 11, 0.0, 3, 9, 10, dict(temperature=0.8, suppress_tokens=[8193])),
+	("early_stop", 11, 4.5, 4, 7, 40, dict(temperature=0.8)),
+	("cand16", 12, 0.0, 16, 5, 6, dict(temperature=1.0)),
+	("warpers", 11, 0.0, 2, 6, 12, dict(temperature=0.7, top_k=16, top_p=0.9, repetition_penalty=2.0, suppress_tokens=[8193])),
+	("stop_first", 11, 60.0, 2, 5, 8, dict(temperature=1.0)),
+	("all_stop", 11, 7.0, 3, 7, 80, dict(temperature=0.8)),
+)
+
+
+class _ScalarMaxLength:
+	"""`stopping_criteria(input_ids, scores)` as the transformers releases the reference targets answered it: ONE bool,
+	`input_ids.shape[-1] >= max_length` (MaxLengthCriteria).  The installed 5.15 returns a per-row tensor there, whose truth value
+	`sample_stream`'s `or` (stream_generator.py:1186) cannot take."""
+
+	def __init__(self, max_length):
+		self.max_length = max_length
+
+	def __call__(self, input_ids, scores, **kw):
+		return input_ids.shape[-1] >= self.max_length
+
+
+def sample_stream_case(uv_mod):
+	"""The reference's OWN sampling loop, `NewGenerationMixin.sample_stream` (stream_generator.py:911-1190), driven directly on the
+	reference's GPT2InferenceModel: `generate()` cannot run on the installed transformers (AttributeError at :305), the loop can.  The
+	processors / warpers are the HF classes `generate` would build (`_get_logits_processor`; `_get_logits_warper` :56-101, called here),
+	max_length = trunc_index + max_generate_length (unified_voice.py:660), seed 0 (:296).  Stored per case: every yielded
+	(tokens, latent) pair -- this pins a6's yield semantics (which hidden state goes with which token, whether the last token is
+	yielded), the unfinished_sequences / padding rule, the stopping rule, and the CPU generator stream."""
+	import importlib
+	import json
+	from transformers import (GenerationConfig, LogitsProcessorList, RepetitionPenaltyLogitsProcessor, StoppingCriteriaList,
+							  SuppressTokensLogitsProcessor)
+	sg = importlib.import_module("tortoise_tts.models.stream_generator")
+	cfg = W.AR_SMALL
+	out = {}
+	for name, wseed, stop_bias, B, Tt, max_new, kw in SAMPLE_STREAM_CASES:
+		sd = W.synth_state_dict(W.ar_shapes(cfg), wseed)
+		if stop_bias:
+			sd["mel_head.bias"] = sd["mel_head.bias"].clone()
+			sd["mel_head.bias"][cfg.stop_mel_token] += stop_bias
+		m = uv_mod.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, checkpointing=False)
+		load_into(m, sd)
+		text = torch.randint(1, 255, (1, Tt), generator=gen(wseed + 1))
+		cond = torch.randn(1, cfg.model_dim, generator=gen(wseed + 2))
+		with torch.inference_mode():
+			ids = m.compute_embeddings(cond, text).repeat(B, 1)
+			im = m.inference_model
+			procs = LogitsProcessorList()
+			if kw.get("repetition_penalty", 1.0) != 1.0:
+				procs.append(RepetitionPenaltyLogitsProcessor(penalty=kw["repetition_penalty"]))
+			if kw.get("suppress_tokens"):
+				procs.append(SuppressTokensLogitsProcessor(kw["suppress_tokens"]))
+			gc = GenerationConfig(do_sample=True, num_beams=1, temperature=kw.get("temperature", 1.0), top_k=kw.get("top_k", 0), top_p=kw.get("top_p", 1.0))
+			warpers = sg.NewGenerationMixin._get_logits_warper(im, gc)
+			sg.setup_seed(0)
+			toks, lats = [], []
+			for tok, lat in sg.NewGenerationMixin.sample_stream(
+					im, ids, logits_processor=procs, logits_warper=warpers,
+					stopping_criteria=_ScalarMaxLength(ids.shape[1] + max_new), pad_token_id=cfg.stop_mel_token,
+					eos_token_id=cfg.stop_mel_token, output_hidden_states=True, return_dict_in_generate=False, use_cache=True,
+					attention_mask=torch.ones_like(ids)):
+				toks.append(tok.clone())
+				lats.append(lat.clone())
+		out[f"{name}::text"], out[f"{name}::cond"] = text.numpy(), cond.numpy()
+		out[f"{name}::ids"] = torch.stack(toks, 1).numpy()                      # [B, n]
+		out[f"{name}::latents"] = torch.stack(lats, 1).numpy()                  # [B, n, d]
+		out[f"{name}::meta"] = np.array(json.dumps(dict(weight_seed=wseed, stop_bias=stop_bias, B=B, Tt=Tt, max_new=max_new, kw=kw)))
+		print(f"  {name}: {len(toks)} yields, ids[0] = {out[f'{name}::ids'][0].tolist()}")
+	return out
+
+
 def vocoder_case(cfg, seed, T):
 	"""The reference BigVGAN generator (models/bigvgan.py) on synthetic weights: the anti-aliasing filter it builds, the weight-normed
 	state_dict key names, one AMP block, `forward` internals and `inference` (waveform)."""
@@ -369,6 +442,7 @@ def main():
 		("lora_small", lambda: lora_case(uv_mod, W.AR_SMALL, 13, rank=4, alpha=8)),
 		("hf_sample_loop", hf_sample_loop_case),
 		("wrapper", lambda: wrapper_case(uv_mod)),
+		("sample_stream", lambda: sample_stream_case(uv_mod)),
 		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
 		("clvp_small", lambda: clvp_case(W.CLVP_SMALL, 61)),
 		("tokenizer", tokenizer_case),

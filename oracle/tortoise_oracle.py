@@ -294,6 +294,47 @@ def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_ret
 	return gen
 
 
+def sample_stream(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return_sequences=1, max_generate_length=None,
+				  temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0, suppress_tokens=None, sample_device="cpu", seed=0):
+	"""a6: `NewGenerationMixin.sample_stream` (stream_generator.py:911-1190) as `get_generator` drives it (unified_voice.py:670-679),
+	a generator of (next_tokens [B], latent [B, d]).  Pinned by tests/golden/sample_stream.npz, which the REFERENCE's own loop produced
+	(oracle/make_golden.py: sample_stream_case).  What that pin fixes:
+	  * the latent yielded with token k is final_norm(hidden[-1][:, -1]) of the forward whose logits token k was SAMPLED FROM
+	    (:1172 reads `outputs` of the same iteration): the prefill's last row for the first token, the step that consumed token k-1
+	    afterwards -- not the step that consumes token k;
+	  * every sampled token is yielded, the last one included (the yield sits in front of the stopping test :1186);
+	  * finished rows yield the pad token (:1165-1171) and the loop ends right after the token with which the last row finishes,
+	    or when input_ids reaches max_length.
+	Logits are not upcast before the processors here (the model is f32 already)."""
+	c = ar.cfg
+	B = num_return_sequences * text.shape[0]
+	prefix = ar.prefix_embeddings(cond_latent, text)
+	trunc_index = prefix.shape[1] + 1
+	max_len = trunc_index + (c.max_mel_tokens - 1 if max_generate_length is None else max_generate_length)
+	torch.manual_seed(seed)
+	if sample_device != "cpu":
+		torch.cuda.manual_seed_all(seed)
+	input_ids = torch.ones((B, trunc_index), dtype=torch.long)
+	input_ids[:, -1] = c.start_mel_token
+	unfinished = torch.ones(B, dtype=torch.long)
+	logits, past, hidden = ar.prefill(prefix, B)
+	logits, hidden = logits[:, -1], hidden[:, -1]
+	k = 0
+	while True:
+		scores = process_logits(input_ids, logits, temperature=temperature, top_k=top_k, top_p=top_p,
+								repetition_penalty=repetition_penalty, suppress_tokens=suppress_tokens)
+		probs = F.softmax(scores.to(sample_device), dim=-1)
+		nxt = torch.multinomial(probs, num_samples=1).squeeze(1).cpu()
+		nxt = nxt * unfinished + c.stop_mel_token * (1 - unfinished)
+		yield nxt, layer_norm(hidden, ar.w["final_norm.weight"], ar.w["final_norm.bias"])
+		input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
+		k += 1
+		unfinished = unfinished * (nxt != c.stop_mel_token).long()
+		if unfinished.max() == 0 or input_ids.shape[1] >= max_len:
+			return
+		logits, past, hidden = ar.decode(nxt, k, past)
+
+
 def fix_stop_tokens(codes: Tensor, stop_mel_token: int) -> Tensor:
 	"""inference.py:353-366.  The reference calls `.min()` on a possibly empty index set before the
 	emptiness check (:355 vs :357) and would raise; rows without a stop token are left untouched here,

@@ -4,8 +4,8 @@
       python profiles/summarize.py trace DIR profiles/rNN_bench
           -> rNN_bench_kernel_stats.csv  (top 40 rows of rocprofv3's own *_kernel_stats.csv)
           -> rNN_bench_per_shape.csv     (the trace grouped by kernel, grid, workgroup: calls, total ms, median/min/p90 us)
-  PMC passes (two separate runs, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv -d DIR -- python3 tests/diag/run_ar.py 12):
-      python profiles/summarize.py pmc FETCH_DIR WRITE_DIR profiles/rNN_pmc_traffic.json
+  PMC passes (two separate runs, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv -d DIR -- python3 bench.py --steps 1 ...):
+      python profiles/summarize.py pmc FETCH_DIR WRITE_DIR profiles/rNN_pmc_traffic.json ["workload text"]
           -> per (kernel, grid) average FETCH_SIZE / WRITE_SIZE per launch, read side corrected as MI355X_MICROARCH.md prescribes for
              gfx950 (FETCH_SIZE counts KB and under-reports 16-byte-per-lane coalesced streams by 2x), plus the launch-weighted
              k_skinny average bench.py reports as roofline.traffic.
@@ -67,7 +67,7 @@ def _counter(d, name):
 	return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-def pmc(fetch_dir, write_dir, out):
+def pmc(fetch_dir, write_dir, out, workload="tests/diag/run_ar.py 12 (bf16, B=16, prefill + 11 decode tokens)"):
 	fetch, calls = _counter(fetch_dir, "FETCH_SIZE")
 	write, _ = _counter(write_dir, "WRITE_SIZE")
 	per = []
@@ -82,8 +82,9 @@ def pmc(fetch_dir, write_dir, out):
 		if "k_skinny" in k[0]:
 			sk_bytes += (rd + wr) * calls[k]
 			sk_calls += calls[k]
-	res = {"how": "rocprofv3 --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE over tests/diag/run_ar.py 12 (bf16, B=16, prefill + 11 "
-				  "decode tokens); counter units KB; read side doubled per the guide's gfx950 correction for 16-byte-per-lane coalesced streams",
+	res = {"how": f"rocprofv3 --pmc FETCH_SIZE and, in a separate run, --pmc WRITE_SIZE over {workload}; counter units KB; read side doubled per "
+				  "the guide's gfx950 correction for 16-byte-per-lane coalesced streams",
+		   "workload": workload,
 		   "k_skinny_avg_hbm_bytes_per_launch": int(sk_bytes / max(sk_calls, 1)), "k_skinny_launches": sk_calls, "per_kernel": per[:24]}
 	json.dump(res, open(out, "w"), indent=1)
 	print("k_skinny avg HBM bytes / launch:", res["k_skinny_avg_hbm_bytes_per_launch"], "over", sk_calls, "launches")
@@ -117,7 +118,7 @@ if __name__ == "__main__":
 		mfma(sys.argv[2], sys.argv[3], sys.argv[4])
 	elif len(sys.argv) == 4 and sys.argv[1] == "trace":
 		trace(sys.argv[2], sys.argv[3])
-	elif len(sys.argv) == 5 and sys.argv[1] == "pmc":
-		pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+	elif len(sys.argv) in (5, 6) and sys.argv[1] == "pmc":
+		pmc(*sys.argv[2:])
 	else:
 		raise SystemExit(__doc__)

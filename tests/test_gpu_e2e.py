@@ -87,6 +87,98 @@ def test_pipelined_lines_equal_sequential_calls(small):
 		assert s0 == s1 and torch.equal(m0, m1)           # same kernels, same inputs, same RNG draws => identical bits
 
 
+def test_pipelined_lines_cold_with_growing_lengths_and_default_warpers():
+	"""a COLD `inference_lines` (fresh handles: every workspace still has to grow, the token-step graph is captured inside the
+	call) over lines whose text and mel lengths grow, with the CLI's default warpers (top-k 16, __main__.py:20) and a live stop token.
+	The worker thread's hipMalloc / hipFree must not break the capture on the main thread (thread-local capture mode; one graph serves
+	every text length), a failure in the worker must surface here, and the results must equal the sequential calls."""
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	from tortoise_tts_amd.inference import TTSHotPath
+	asd = W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 31)
+	asd["mel_head.bias"] = asd["mel_head.bias"].clone()
+	asd["mel_head.bias"][W.AR_SMALL.stop_mel_token] = 3.0               # rows end on their own, at different lengths per line
+	dsd = W.synth_state_dict(W.diffusion_shapes(W.DIFF_SMALL), 32)
+
+	def fresh():
+		return TTSHotPath(UnifiedVoice(asd, W.AR_SMALL, dtype="f32", device=DEV, max_batch=4, max_ctx=160),
+						  DiffusionTTS(dsd, W.DIFF_SMALL, dtype="f32", device=DEV))
+	lines = [_inputs(600 + i, Tt)[0] for i, Tt in enumerate((3, 9, 21, 40))]
+	_, al, dl = _inputs(700, 4)
+	kw = dict(max_ar_steps=60, max_diffusion_steps=3, candidates=3, top_k=16)
+	with torch.inference_mode():
+		pipe = fresh().inference_lines(lines, al.to(DEV), dl.to(DEV), **kw)          # raises if the worker's future holds an exception
+		tts = fresh()
+		seq = [tts.inference(t, al.to(DEV), dl.to(DEV), **kw) for t in lines]
+	torch.cuda.synchronize()
+	assert len({m.shape[-1] for m, _ in seq}) > 1                       # the lines really have different lengths
+	for (m0, s0), (m1, s1, _codes) in zip(seq, pipe):
+		assert s0 == s1 and torch.equal(m0, m1)
+	assert len(tts.autoregressive._states) == 1                         # one generation state / captured step for all four text lengths
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_candidate_shards_are_the_rows_of_the_unsharded_run(dtype):
+	"""RNG contract of tortoise_tts_amd/dist.py: every shard of a candidate-sharded `inference_speech` equals, bit for bit, its rows of the
+	single-GPU call for all candidates (stop token live, so shards end at different steps and are padded), and after `align_rng` the
+	generator stands where the unsharded loop leaves it -- so the winner's diffusion noise is the same too."""
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	from tortoise_tts_amd.inference import HotPathStages, TTSHotPath
+	cfg = W.AR_SMALL
+	sd = W.synth_state_dict(W.ar_shapes(cfg), 31)
+	sd["mel_head.bias"] = sd["mel_head.bias"].clone()
+	sd["mel_head.bias"][cfg.stop_mel_token] += 5.0
+	ar = UnifiedVoice(sd, cfg, dtype=dtype, device=DEV, max_batch=8, max_ctx=128)
+	text, al, _ = _inputs(800, 6)
+	C = 7
+	kw = dict(do_sample=True, temperature=0.8, top_k=16, max_generate_length=50)
+	with torch.inference_mode():
+		full = ar.inference_speech(al.to(DEV), text.to(DEV), num_return_sequences=C, **kw)
+		after_full = torch.rand(5, device=DEV)
+		L = full.shape[1]
+		for world in (2, 3):
+			from tortoise_tts_amd.dist import candidate_shard
+			for r in range(world):
+				lo, hi = candidate_shard(C, r, world)
+				part = ar.inference_speech(al.to(DEV), text.to(DEV), num_return_sequences=C, candidate_shard=(lo, hi), **kw)
+				assert part.shape[0] == hi - lo and part.shape[1] <= L
+				assert torch.equal(part, full[lo:hi, :part.shape[1]]), (world, r)
+				assert bool((full[lo:hi, part.shape[1]:] == cfg.stop_mel_token).all())       # what the gather pads with
+				st = HotPathStages(TTSHotPath(ar, None), text, al.to(DEV), None, ar_temp=0.8, top_k=16, max_ar_steps=50)
+				st.align_rng(L)
+				assert torch.equal(torch.rand(5, device=DEV), after_full), (world, r)
+		with pytest.raises(ValueError):
+			ar.inference_speech(al.to(DEV), text.to(DEV), num_return_sequences=C, candidate_shard=(3, 3), **kw)
+
+
+def test_inference_sharded_equals_inference_on_one_rank(small):
+	"""`TTSHotPath.inference_sharded` through a real (1-rank, RCCL) process group: same mel, ids and candidate choice as `inference`."""
+	import torch.distributed as dist
+	import clvp_oracle  # noqa: F401  (only to fail early if the oracle tree is missing)
+	from tortoise_tts_amd.clvp import CLVP
+	from tortoise_tts_amd.inference import TTSHotPath
+	tts, _, _ = small
+	ccfg = W.CLVPConfig(dim=128, depth=2, heads=2, num_speech_tokens=8194)
+	full = TTSHotPath(tts.autoregressive, tts.diffusion, clvp=CLVP(W.synth_state_dict(W.clvp_shapes(ccfg), 34), ccfg, dtype="f32", device=DEV))
+	text, al, dl = _inputs(900, 8)
+	kw = dict(max_ar_steps=14, max_diffusion_steps=3, candidates=5, top_k=16, suppress_tokens=[W.AR_SMALL.stop_mel_token])
+	import os, socket
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+	os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+	dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+	try:
+		with torch.inference_mode():
+			m0, s0, a0 = full.inference(text, al.to(DEV), dl.to(DEV), return_all=True, **kw)
+			m1, s1, a1 = full.inference_sharded(text, al.to(DEV), dl.to(DEV), return_all=True, **kw)
+		torch.cuda.synchronize()
+	finally:
+		dist.destroy_process_group()
+	assert s0 == s1 and torch.equal(m0, m1) and torch.equal(a0["codes"], a1["codes"]) and a0["best"] == a1["best"]
+	assert torch.equal(a0["scores"], a1["scores"])
+
+
 def test_tokens_to_waveform_with_the_vocoder(small):
 	"""text tokens + latents -> mel (hot path) -> waveform (BigVGAN on libttk), against the same chain through the two oracles"""
 	import bigvgan_oracle as BO

@@ -77,25 +77,41 @@ def test_decode_batch_sizes_teacher_forced(small_ar, B):
 			assert maxerr(logits, ref) < 2e-4, k
 
 
-def test_streaming_generator_matches_oracle_tokens_and_latents(small_ar):
-	"""a6: get_generator yields (codes, final_norm(hidden)) per token (stream_generator.py:1172)."""
+@pytest.mark.parametrize("kw", [dict(temperature=0.8, suppress_tokens=[8193]), dict(temperature=0.7, top_k=16, top_p=0.9, repetition_penalty=2.0)])
+def test_streaming_generator_matches_oracle_tokens_and_latents(small_ar, kw):
+	"""a6: get_generator yields (codes, final_norm(hidden)) per token with the semantics the reference's own `sample_stream` has
+	(stream_generator.py:1172; pinned in tests/test_oracle_sampling.py against tests/golden/sample_stream.npz): the latent of the
+	forward the token was sampled from, every token yielded."""
 	model, oracle = small_ar
 	text = torch.randint(1, 255, (1, 6), generator=gen(40))
 	cond = torch.randn(1, 128, generator=gen(41))
 	ids = model.compute_embeddings(cond.to(DEV), text.to(DEV))
-	out = list(model.get_generator(inputs=ids, max_length=ids.shape[1] + 8, temperature=0.8, do_sample=True, num_return_sequences=1,
-								   suppress_tokens=[8193]))
-	got_tok = torch.stack([t for t, _ in out], 1).cpu()
+	out = list(model.get_generator(inputs=ids, max_length=ids.shape[1] + 8, do_sample=True, num_return_sequences=2, **kw))
 	with torch.inference_mode():
-		ref_tok = O.inference_speech(oracle, cond, text, num_return_sequences=1, max_generate_length=8, temperature=0.8,
-									 suppress_tokens=[8193], sample_device="cuda")
-		assert torch.equal(got_tok, ref_tok[:, :got_tok.shape[1]])
-		# latent yielded with token k is final_norm(ln_f(h)) of the step that consumed it
-		logits, past, _ = oracle.prefill(oracle.prefix_embeddings(cond, text), 1)
-		for k in range(1, got_tok.shape[1] + 1):
-			_, past, hidden = oracle.decode(ref_tok[:, k - 1], k, past)
-			lat = O.layer_norm(hidden, oracle.w["final_norm.weight"], oracle.w["final_norm.bias"])
-			assert maxerr(out[k - 1][1], lat) < 2e-4
+		ref = list(O.sample_stream(oracle, cond, text, num_return_sequences=2, max_generate_length=8, sample_device="cuda", **kw))
+	assert len(out) == len(ref) == 8
+	for (tok, lat), (rtok, rlat) in zip(out, ref):
+		assert torch.equal(tok.cpu(), rtok) and maxerr(lat, rlat) < 2e-4
+
+
+def test_streaming_generator_stops_with_the_last_row(small_ar):
+	"""rows that finish yield the pad token; the stream ends right after the token with which the last row finishes"""
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	cfg = W.AR_SMALL
+	sd = W.synth_state_dict(W.ar_shapes(cfg), 31)
+	sd["mel_head.bias"] = sd["mel_head.bias"].clone()
+	sd["mel_head.bias"][cfg.stop_mel_token] += 7.0
+	model, oracle = UnifiedVoice(sd, cfg, dtype="f32", device=DEV, max_batch=4, max_ctx=128), O.AROracle(sd, cfg)
+	text = torch.randint(1, 255, (1, 7), generator=gen(42))
+	cond = torch.randn(1, 128, generator=gen(43))
+	ids = model.compute_embeddings(cond.to(DEV), text.to(DEV))
+	out = list(model.get_generator(inputs=ids, max_length=ids.shape[1] + 80, temperature=0.8, top_k=0, do_sample=True, num_return_sequences=3))
+	with torch.inference_mode():
+		ref = list(O.sample_stream(oracle, cond, text, num_return_sequences=3, max_generate_length=80, temperature=0.8, top_k=0, sample_device="cuda"))
+	assert 1 <= len(out) == len(ref) < 80
+	for (tok, lat), (rtok, rlat) in zip(out, ref):
+		assert torch.equal(tok.cpu(), rtok) and maxerr(lat, rlat) < 2e-4
+	assert bool((out[-1][0] == cfg.stop_mel_token).all())
 
 
 @pytest.mark.parametrize("b,M,T", [(1, 1, 4), (2, 7, 30), (1, 40, 174), (3, 70, 129)])

@@ -120,3 +120,32 @@ def test_setup_seed_equals_reference(golden):
 	setup_seed(-1)
 	assert np.array_equal(torch.rand(4).numpy(), g["torch_keep"])
 	assert g["fake_ids"].shape == (2, 5 + 4) and (g["fake_ids"][:, :-1] == 1).all() and (g["fake_ids"][:, -1] == W.AR_SMALL.start_mel_token).all()
+
+
+def test_sample_stream_equals_the_references_own_loop(golden):
+	"""a5/a6 pinned by the reference's own loop code: `NewGenerationMixin.sample_stream` (stream_generator.py:911-1190) driven on the
+	reference's GPT2InferenceModel (oracle/make_golden.py: sample_stream_case) -- yielded tokens AND latents of every case; and
+	`inference_speech`, which restates `generate()`'s sample branch over the same loop body, must give those ids too."""
+	import json
+	g = golden("sample_stream")
+	names = sorted({k.split("::")[0] for k in g})
+	assert len(names) >= 6
+	cfg = W.AR_SMALL
+	for name in names:
+		meta = json.loads(str(g[f"{name}::meta"]))
+		sd = W.synth_state_dict(W.ar_shapes(cfg), meta["weight_seed"])
+		if meta["stop_bias"]:
+			sd["mel_head.bias"] = sd["mel_head.bias"].clone()
+			sd["mel_head.bias"][cfg.stop_mel_token] += meta["stop_bias"]
+		ar = O.AROracle(sd, cfg)
+		text, cond = torch.from_numpy(g[f"{name}::text"]), torch.from_numpy(g[f"{name}::cond"])
+		kw = dict(meta["kw"])
+		kw.setdefault("top_k", 0)
+		with torch.inference_mode():
+			pairs = list(O.sample_stream(ar, cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], **kw))
+			ids = O.inference_speech(ar, cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], **kw)
+		want_ids, want_lat = torch.from_numpy(g[f"{name}::ids"]), torch.from_numpy(g[f"{name}::latents"])
+		assert len(pairs) == want_ids.shape[1], name                                 # every token is yielded, the last one too
+		assert torch.equal(torch.stack([t for t, _ in pairs], 1), want_ids), name
+		assert (torch.stack([l for _, l in pairs], 1) - want_lat).abs().max() < 2e-5, name
+		assert torch.equal(ids, want_ids), name

@@ -138,9 +138,16 @@ class UnifiedVoice:
 	__call__ = forward
 
 	def inference_speech(self, speech_conditioning_latent, text_inputs, input_tokens=None, num_return_sequences=1,
-						 max_generate_length=None, typical_sampling=False, typical_mass=.9, kv_cache=True, **hf_generate_kwargs):
+						 max_generate_length=None, typical_sampling=False, typical_mass=.9, kv_cache=True, candidate_shard=None,
+						 **hf_generate_kwargs):
 		"""unified_voice.py:632-668 + the sample branch of `generate` (stream_generator.py:213-639, HF `_sample`).
-		Returns int64 [B, L <= max_generate_length], rows padded with stop_mel_token after their EOS."""
+		Returns int64 [B, L <= max_generate_length], rows padded with stop_mel_token after their EOS.
+
+		candidate_shard=(lo, hi) (no reference counterpart; tortoise_tts_amd/dist.py): sample only candidates lo..hi-1 of the
+		`num_return_sequences`, as one rank of a candidate-sharded run.  RNG contract: the rank draws the multinomial noise of ALL
+		candidates per token (the same Philox stream on every rank: `generate` reseeds to 0) and consumes its own rows, so the ids it
+		returns are bit for bit the rows lo..hi-1 of the unsharded call -- up to the length, which here ends with the shard's own last
+		row (the gather pads with the stop token, as the unsharded loop does for finished rows)."""
 		if input_tokens is not None:
 			raise NotImplementedError("input_tokens (prompted continuation) is not on the inference hot path")
 		if text_inputs.shape[0] != 1:
@@ -150,7 +157,7 @@ class UnifiedVoice:
 		if hf_generate_kwargs.get("num_beams", 1) not in (None, 1) or not hf_generate_kwargs.get("do_sample", False):
 			raise NotImplementedError("only the sampling branch (do_sample=True, num_beams=1) is implemented; pass do_sample=True")
 		gen, _ = self._generate(speech_conditioning_latent, text_inputs, num_return_sequences, max_generate_length,
-								typical_mass if typical_sampling else None, hf_generate_kwargs, stream=False)
+								typical_mass if typical_sampling else None, hf_generate_kwargs, stream=False, shard=candidate_shard)
 		return gen
 
 	def compute_embeddings(self, cond_latents, text_inputs, kv_cache=True):
@@ -172,9 +179,15 @@ class UnifiedVoice:
 		return self._generate(cond, text, B, n_new, None, hf_generate_kwargs, stream=True)
 
 	# ------------------------------------------------------------------ the token loop
-	def _generate(self, cond, text, num_return_sequences, max_generate_length, typical_mass, kw, stream):
+	def _generate(self, cond, text, num_return_sequences, max_generate_length, typical_mass, kw, stream, shard=None):
 		c = self.cfg
-		B = num_return_sequences * text.shape[0]
+		C = num_return_sequences * text.shape[0]          # candidates the noise is drawn for
+		lo, hi = (0, C) if shard is None else (int(shard[0]), int(shard[1]))
+		if not (0 <= lo < hi <= C):
+			raise ValueError(f"candidate_shard {shard} is not a non-empty range inside [0, {C})")
+		if stream and shard is not None:
+			raise NotImplementedError("the streaming generator is not sharded")
+		B = hi - lo
 		if B > self.max_batch:
 			raise _lib.TTKError(f"{B} candidates exceed max_batch={self.max_batch}")
 		Tt = text.shape[1]
@@ -192,8 +205,10 @@ class UnifiedVoice:
 			return self._loop_stream(cond, text, B, max_new, pipe)
 		can_stop = c.stop_mel_token not in suppress
 		with torch.cuda.device(self.device):
-			st = self._gen_state(B, max_new, pipe_key)
+			st = self._gen_state(B, max_new, pipe_key, C, lo)
 			setup_seed(kw.get("seed", 0))
+			gen = torch.cuda.default_generators[self.device.index or 0]
+			off_start = gen.get_offset()
 			st.reset(c)
 			st.logits.copy_(self._prefill(cond, text, B))
 			n = 0
@@ -214,11 +229,9 @@ class UnifiedVoice:
 				# always has work queued.  The <= LAG tokens generated past the true end are all padding; they are cut off below
 				# and the generator offset they consumed is handed back, so ids AND the RNG stream equal the reference's.
 				LAG = 2
-				gen = torch.cuda.default_generators[self.device.index or 0]
-				off0 = gen.get_offset()
 				st.sample(0)
 				if st.rng_step is None:
-					st.rng_step = gen.get_offset() - off0
+					st.rng_step = gen.get_offset() - off_start
 				n = 1
 				events = []
 				stopped = can_stop and int(st.unfinished.max()) == 0
@@ -258,27 +271,34 @@ class UnifiedVoice:
 						if n_true < n:
 							gen.set_offset(gen.get_offset() - (n - n_true) * st.rng_step)
 							n = n_true
+			# what the sampling consumed from the generator: dist.py aligns a shard's stream with the unsharded run's from this
+			self.last_generate = dict(steps=n, rng_start=off_start, rng_step=(gen.get_offset() - off_start) // max(n, 1))
 			return st.ids[:, :n].clone(), None
 
-	def _gen_state(self, B, max_new, pipe_key):
+	def _gen_state(self, B, max_new, pipe_key, C=None, lo=0):
 		"""generation states (device buffers + the captured token step) keyed by what is baked into them; a few are kept so that
 		alternating shapes (e.g. `TTS.inference` lines with different max lengths) do not re-capture every call"""
-		key = (B, max_new, pipe_key)
+		C = B if C is None else C
+		key = (B, max_new, pipe_key, C, lo)
 		states = self._states
 		if key in states:
 			states[key] = states.pop(key)             # most recently used last
 		else:
 			while len(states) >= 4:
 				states.pop(next(iter(states)))
-			states[key] = _GenState(self, B, max_new, pipe_key)
+			states[key] = _GenState(self, B, max_new, pipe_key, C, lo)
 		return states[key]
 
 	def _loop_stream(self, cond, text, B, max_new, pipe):
+		"""stream_generator.py:1106-1190, pinned by the reference's own loop (tests/golden/sample_stream.npz): token k is yielded with
+		final_norm(hidden) of the forward it was sampled from -- the prefill's last row for the first token -- and every token is
+		yielded, the last one included; the loop ends after the token with which the last row finishes or after max_new tokens."""
 		c = self.cfg
 		with torch.cuda.device(self.device):
 			setup_seed(0)
 			logits = self._prefill(cond, text, B)
 			hidden = torch.empty((B, c.model_dim), device=self.device, dtype=torch.float32)
+			_lib.check(self.lib.ttk_ar_last_hidden(self._h, hidden.data_ptr(), _lib.stream_ptr()), "ttk_ar_last_hidden")
 			unfinished = torch.ones(B, dtype=torch.long, device=self.device)
 			hist = torch.ones((B, text.shape[1] + 4), dtype=torch.long, device=self.device)
 			hist[:, -1] = c.start_mel_token
@@ -286,22 +306,22 @@ class UnifiedVoice:
 				scores = pipe(hist if pipe.needs_history else None, logits)
 				nxt = multinomial1(torch.nn.functional.softmax(scores, dim=-1))
 				nxt = nxt * unfinished + c.stop_mel_token * (1 - unfinished)
+				yield nxt, hidden.clone()
 				unfinished = unfinished * (nxt != c.stop_mel_token).long()
 				if pipe.needs_history:
 					hist = torch.cat([hist, nxt[:, None]], dim=-1)
 				if n + 1 >= max_new or int(unfinished.max()) == 0:
-					# the reference yields (tokens, final_norm(hidden of the row that produced them)); the last row needs no decode
 					return
 				self._decode(nxt, logits, hidden)
-				yield nxt, hidden.clone()
 
 
 class _GenState:
 	"""Persistent device buffers of one generation shape, so a captured token step can be replayed across calls (and across text
 	lengths: nothing in it depends on the prefix length)."""
 
-	def __init__(self, model: UnifiedVoice, B, max_new, pipe_key):
+	def __init__(self, model: UnifiedVoice, B, max_new, pipe_key, C=None, lo=0):
 		c, dev = model.cfg, model.device
+		C = B if C is None else C
 		self.model = model
 		self.B, self.max_new = B, max_new
 		self.pipe = LogitsPipeline(temperature=pipe_key[0], top_k=pipe_key[1], top_p=pipe_key[2], repetition_penalty=pipe_key[3],
@@ -312,7 +332,9 @@ class _GenState:
 		self.tok = torch.empty(B, dtype=torch.long, device=dev)
 		self.unfinished = torch.ones(B, dtype=torch.long, device=dev)
 		self.col = torch.zeros(B, dtype=torch.long, device=dev)         # per-row output column (all rows move together)
-		self.q = torch.empty((B, c.number_mel_codes), device=dev, dtype=torch.float32)   # Exp(1) noise of multinomial
+		# Exp(1) noise of multinomial for ALL C candidates of the call (C == B unless this is one shard of a candidate-sharded run:
+		# every rank draws the same [C, V] block and reads its rows lo..lo+B-1, see inference_speech)
+		self.q = torch.empty((C, c.number_mel_codes), device=dev, dtype=torch.float32)
 		self.live = torch.zeros(1, dtype=torch.int32, device=dev)        # unfinished rows, decremented on the device
 		self.done = torch.zeros(1, dtype=torch.int32).pin_memory()       # raised by the row that finishes last; polled by the host
 		self.rng_step = None                                             # generator offset consumed by one sample() call
@@ -329,7 +351,7 @@ class _GenState:
 		self.graphable = self.in_kernel or not p.needs_history      # torch-op penalty: its history slice grows with the host's step count
 		a = _lib.SampleArgs()
 		a.ld, a.B, a.V = self.logits.stride(0), B, c.number_mel_codes
-		a.q, a.ldq = self.q.data_ptr(), self.q.stride(0)
+		a.q, a.ldq = self.q[lo].data_ptr(), self.q.stride(0)
 		a.stop_token = self.stop
 		a.unfinished, a.tok, a.ids = self.unfinished.data_ptr(), self.tok.data_ptr(), self.ids.data_ptr()
 		a.ids_ld, a.ids_cols, a.col = self.ids.stride(0), self.ids.shape[1], self.col.data_ptr()

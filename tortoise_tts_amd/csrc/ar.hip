@@ -382,6 +382,16 @@ int ttk_ar_sample_next(ttk_ar* h, const ttk_sample_args* a, void* stream) {
 	return launch_sample_step(a, h->mel_emb, h->mel_pos, h->x, h->cfg.model_dim, h->cfg.max_mel_seq_len, (hipStream_t)stream, "ttk_ar_sample_next");
 }
 
+int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream) {
+	TTK_REQUIRE(h && hidden_out, TTK_E_ARG, "ttk_ar_last_hidden: null argument");
+	TTK_REQUIRE(h->ready, TTK_E_STATE, "ttk_ar_last_hidden: call ttk_ar_prefill first");
+	const int d = h->cfg.model_dim;
+	// h->x holds the residual stream of the newest row after the last block; enc = final_norm(ln_f(x))   (unified_voice.py:106, HF GPT2Model ln_f)
+	launch_layernorm(h->dt, h->x, d, h->B, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, hidden_out, d, 1, (hipStream_t)stream);
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
 int ttk_ar_latents(ttk_ar* h, const float* cond, const int64_t* text, int Tt, const int64_t* codes, int M, int B, float* latents_out, void* stream) {
 	TTK_REQUIRE(h && cond && text && codes && latents_out, TTK_E_ARG, "ttk_ar_latents: null argument");
 	const ttk_ar_config& c = h->cfg;

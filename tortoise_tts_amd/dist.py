@@ -3,11 +3,19 @@
 of the one exchange: `gather_candidate_ids` (an all-gather of the sampled ids, for a scorer that lives on one rank -- the reference
 path's CLVP) and `pick_best_candidate` (every rank scores its own shard with its CLVP replica -- scores are per candidate, so no ids
 need to travel -- and only the scores are all-gathered; the owner of the winner runs the diffusion).
+`sharded_candidates` is the product entry for ONE utterance whose candidates are spread over the ranks (BASELINE configs[3]: 256 candidates
+over 8 GPUs); `TTSHotPath.inference_sharded` binds it to the libttk-backed stages.
 The reference itself has no multi-GPU inference ("Inference multi-GPU: none"): this is new design.
+
+RNG contract of a candidate shard (defined here because the reference has none): every rank reseeds to 0 (`generate`,
+stream_generator.py:296), draws the multinomial noise of ALL C candidates for every token -- the identical Philox stream on every rank --
+and consumes the rows of its own candidates; after the id gather every rank advances its generator to where the unsharded loop would
+have left it (the longest shard's step count).  The union of the shards is therefore bit for bit the single-GPU result for C candidates,
+the winner's diffusion start noise included, for any number of ranks.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -71,3 +79,65 @@ def pick_best_candidate(local_scores: torch.Tensor, n_candidates: int) -> Tuple[
 			return r, best - lo, scores
 		lo += c
 	raise AssertionError("unreachable")
+
+
+class ShardStages:
+	"""The per-rank pieces `sharded_candidates` strings together.  `tortoise_tts_amd.inference.HotPathStages` implements them on libttk;
+	the CPU tests implement them on plain tensors to run the control flow under gloo."""
+
+	pad_token: int = 0
+
+	def sample(self, lo: int, hi: int, n_candidates: int) -> torch.Tensor:
+		"""ids [hi - lo, L_r] of candidates lo..hi-1 (rows lo..hi-1 of the unsharded sampling, ending with this shard's last row)"""
+		raise NotImplementedError
+
+	def align_rng(self, steps: int) -> None:
+		"""leave the generator where the unsharded loop of `steps` tokens would"""
+		raise NotImplementedError
+
+	def latents(self, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+		"""(codes after the stop-token fix-up, latents [c, L, d]) of this rank's candidates"""
+		raise NotImplementedError
+
+	def score(self, codes: torch.Tensor) -> Optional[torch.Tensor]:
+		"""CLVP scores [c] of this rank's candidates, or None when no scorer is attached (candidate 0 is diffused then)"""
+		return None
+
+	def diffuse(self, codes: torch.Tensor, latents: torch.Tensor) -> torch.Tensor:
+		"""mel [1, 100, T] of ONE candidate (codes [1, L], latents [1, L, d]); only the winner's owner calls this"""
+		raise NotImplementedError
+
+
+def sharded_candidates(stages: ShardStages, n_candidates: int, group=None):
+	"""One utterance, candidates sharded over the ranks of `group` (weights replicated, no data-path collective):
+	   every rank samples its `candidate_shard` -> all-gather of the ids (the only payload that is not a scalar per candidate; 8 B x L
+	   per candidate) -> every rank runs the latent pass and its CLVP replica on its own candidates -> all-gather of the scores ->
+	   the owner of the best candidate diffuses it -> the mel is broadcast.
+	Returns (mel [1, 100, T], ids [C, L], scores [C] or None, best) on every rank, equal to the single-rank result for C candidates."""
+	world = dist.get_world_size(group)
+	rank = dist.get_rank(group)
+	lo, hi = candidate_shard(n_candidates, rank, world)
+	if hi <= lo:
+		raise ValueError(f"{n_candidates} candidates over {world} ranks leaves rank {rank} without work")
+	local = stages.sample(lo, hi, n_candidates)
+	ids = gather_candidate_ids(local, n_candidates, stages.pad_token)
+	stages.align_rng(ids.shape[1])
+	codes, lat = stages.latents(ids[lo:hi].contiguous())
+	sc = stages.score(codes)
+	if sc is None:
+		owner, idx, scores, best = 0, 0, None, 0
+	else:
+		owner, idx, scores = pick_best_candidate(sc, n_candidates)
+		best = candidate_shard(n_candidates, owner, world)[0] + idx
+	dev = ids.device
+	shape = torch.zeros(3, dtype=torch.long, device=dev)
+	mel = None
+	if rank == owner:
+		mel = stages.diffuse(codes[idx:idx + 1], lat[idx:idx + 1]).to(torch.float32).contiguous()
+		shape = torch.tensor(mel.shape, dtype=torch.long, device=dev)
+	src = dist.get_global_rank(group, owner) if group is not None else owner
+	dist.broadcast(shape, src=src, group=group)
+	if rank != owner:
+		mel = torch.empty([int(v) for v in shape], dtype=torch.float32, device=dev)
+	dist.broadcast(mel, src=src, group=group)
+	return mel, ids, scores, best

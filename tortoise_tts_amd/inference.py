@@ -46,9 +46,70 @@ def trim_calm_tokens(codes: torch.Tensor, latents: torch.Tensor) -> torch.Tensor
 	return latents
 
 
+class HotPathStages:
+	"""`dist.ShardStages` on the libttk-backed modules: what one rank of a candidate-sharded utterance runs (dist.sharded_candidates)."""
+
+	def __init__(self, tts: "TTSHotPath", text_tokens, autoregressive_latents, diffusion_latents, *, max_ar_steps=500,
+				 max_diffusion_steps=80, ar_temp=0.8, diffusion_temp=1.0, top_p=1.0, top_k=0, repetition_penalty=1.0, length_penalty=1.0,
+				 diffusion_sampler="ddim", cond_free=True, suppress_tokens=None):
+		self.tts, self.ar, self.diff = tts, tts.autoregressive, tts.diffusion
+		self.text = text_tokens.to(self.ar.device)
+		self.al, self.dl = autoregressive_latents, diffusion_latents
+		self.kw = dict(do_sample=True, top_k=top_k, top_p=top_p, temperature=ar_temp, num_beams=1, length_penalty=length_penalty,
+					   repetition_penalty=repetition_penalty, max_generate_length=max_ar_steps)
+		if suppress_tokens:
+			self.kw["suppress_tokens"] = suppress_tokens
+		self.diffuser = get_diffuser(steps=max_diffusion_steps, cond_free=cond_free)
+		self.diffusion_temp, self.sampler = diffusion_temp, diffusion_sampler
+		self.pad_token = self.ar.stop_mel_token
+
+	def sample(self, lo, hi, n_candidates):
+		return self.ar.inference_speech(self.al, self.text, num_return_sequences=n_candidates, candidate_shard=(lo, hi), **self.kw)
+
+	def align_rng(self, steps):
+		g = self.ar.last_generate
+		torch.cuda.default_generators[self.ar.device.index or 0].set_offset(g["rng_start"] + steps * g["rng_step"])
+
+	def latents(self, ids):
+		codes = fix_stop_tokens(ids, self.ar.stop_mel_token)
+		B, M = codes.shape
+		al = self.al.expand(B, -1) if self.al.shape[0] != B else self.al
+		lat = self.ar.forward(al, self.text.expand(B, -1), torch.tensor([self.text.shape[1]], dtype=torch.int32).expand(B), codes,
+							  torch.tensor([M * self.ar.mel_length_compression]).expand(B), return_latent=True, clip_inputs=False)
+		return codes, lat
+
+	def score(self, codes):
+		return None if self.tts.clvp is None else self.tts.clvp(self.text, codes, return_loss=False)
+
+	def diffuse(self, codes, latents):
+		latents = trim_calm_tokens(codes, latents)
+		T = latents.shape[1] * 4 * 24000 // 22050
+		E = self.diff.timestep_independent(latents, self.dl, T, False)
+		noise = torch.randn((1, 100, T), device=self.ar.device) * self.diffusion_temp
+		return self.diffuser.sample_loop(self.diff, (1, 100, T), sampler=self.sampler, noise=noise,
+										 model_kwargs={"precomputed_aligned_embeddings": E}, progress=False)
+
+
 class TTSHotPath:
 	def __init__(self, autoregressive: UnifiedVoice, diffusion: DiffusionTTS, vocoder=None, clvp=None):
 		self.autoregressive, self.diffusion, self.vocoder, self.clvp = autoregressive, diffusion, vocoder, clvp
+
+	@torch.inference_mode()
+	def inference_sharded(self, text_tokens, autoregressive_latents, diffusion_latents, *, candidates, group=None, return_all=False, **kw):
+		"""`inference` for ONE utterance whose `candidates` are sharded over the ranks of `group` (torch.distributed: RCCL over xGMI on
+		the GPU box): BASELINE configs[3].  Every rank calls this with the same arguments and gets the same result, which equals the
+		single-GPU `inference(..., candidates=candidates)` of a TTSHotPath with the same attachments (tortoise_tts_amd/dist.py states
+		the RNG contract that makes it so).  Candidate choice as in `inference`: the best CLVP score when a scorer is attached, else
+		candidate 0."""
+		from . import dist as D
+		st = HotPathStages(self, text_tokens, autoregressive_latents, diffusion_latents, **kw)
+		mel, ids, scores, best = D.sharded_candidates(st, candidates, group)
+		T = mel.shape[-1]
+		mels = denormalize_tacotron_mel(mel)[:, :, :T]
+		seconds = T * HOP / SAMPLE_RATE
+		if return_all:
+			return mels, seconds, dict(codes=fix_stop_tokens(ids, self.autoregressive.stop_mel_token), mel=mel, scores=scores, best=best)
+		return mels, seconds
 
 	@torch.inference_mode()
 	def inference_to_wav(self, text_tokens, autoregressive_latents, diffusion_latents, **kw):
@@ -62,11 +123,20 @@ class TTSHotPath:
 	def inference(self, text_tokens: torch.Tensor, autoregressive_latents: torch.Tensor, diffusion_latents: torch.Tensor, *,
 				  max_ar_steps=500, max_diffusion_steps=80, ar_temp=0.8, diffusion_temp=1.0, top_p=1.0, top_k=0,
 				  repetition_penalty=1.0, length_penalty=1.0, diffusion_sampler="ddim", cond_free=True, candidates=1,
-				  suppress_tokens=None, return_all=False):
+				  suppress_tokens=None, return_all=False, phase_marks=None):
 		"""text_tokens [1, Tt] int64; latents from the reference's conditioning encoders ([1,1024], [1,2048]).
-		Returns the denormalised mel [1, 100, T] (input of the vocoder) and the audio seconds it represents."""
+		Returns the denormalised mel [1, 100, T] (input of the vocoder) and the audio seconds it represents.
+		phase_marks (measurement only): a list that receives (name, torch.cuda.Event) at the phase boundaries -- start, after the AR
+		sampling, after the latent pass, after the diffusion -- for bench.py's per-phase roofline."""
 		ar, diff = self.autoregressive, self.diffusion
 		dev = ar.device
+
+		def mark(name):
+			if phase_marks is not None:
+				ev = torch.cuda.Event(enable_timing=True)
+				ev.record()
+				phase_marks.append((name, ev))
+		mark("start")
 		text_tokens = text_tokens.to(dev)
 		diffuser = get_diffuser(steps=max_diffusion_steps, cond_free=cond_free)
 		extra = {"suppress_tokens": suppress_tokens} if suppress_tokens else {}
@@ -74,6 +144,7 @@ class TTSHotPath:
 									temperature=ar_temp, num_return_sequences=candidates, num_beams=1,
 									length_penalty=length_penalty, repetition_penalty=repetition_penalty,
 									max_generate_length=max_ar_steps, **extra)
+		mark("ar_decode")
 		codes = fix_stop_tokens(codes, ar.stop_mel_token)
 		B, M = codes.shape
 		wav_lengths = torch.tensor([M * ar.mel_length_compression])
@@ -85,6 +156,7 @@ class TTSHotPath:
 		# latents computed BEFORE that, in generation order (its own to-do at :370), trimmed where row 0 goes calm (:381-389).  Without
 		# a CLVP model this path keeps that observable behaviour for the first candidate: row 0, trimmed by row 0.  With one
 		# (`TTSHotPath(..., clvp=)`) it does what the to-do asks for: the best-scoring candidate's latents, trimmed by its own codes.
+		mark("latent_pass")
 		best, scores = 0, None
 		if self.clvp is not None and B > 1:
 			scores = self.clvp(text_tokens, codes, return_loss=False)
@@ -95,6 +167,7 @@ class TTSHotPath:
 		noise = torch.randn((1, 100, T), device=dev) * diffusion_temp
 		mel = diffuser.sample_loop(diff, (1, 100, T), sampler=diffusion_sampler, noise=noise,
 								   model_kwargs={"precomputed_aligned_embeddings": E}, progress=False)
+		mark("ddim")
 		mels = denormalize_tacotron_mel(mel)[:, :, :T]
 		seconds = T * HOP / SAMPLE_RATE
 		if return_all:

@@ -38,15 +38,18 @@ def collect(step_fn, ar=None):
 
 
 def _pmc_traffic(kind):
-	"""HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json); PMC counters cannot be
-	read from inside a running benchmark, so this is the last measured value, or None for kernels without a PMC pass."""
+	"""HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json,
+	written by profiles/collect.sh + summarize.py).  PMC counters cannot be read from inside a running benchmark, so this is NOT a
+	measurement of this run: it is returned together with the file and the workload it was taken on, and the bench line labels it
+	`traffic_from_profiles`."""
 	import glob
 	import json
 	import os
 	files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r*_pmc_traffic.json")))
 	if not files or kind != "skinny_gemm":
-		return None
-	return json.load(open(files[-1])).get("k_skinny_avg_hbm_bytes_per_launch")
+		return None, None
+	d = json.load(open(files[-1]))
+	return d.get("k_skinny_avg_hbm_bytes_per_launch"), {"file": "profiles/" + os.path.basename(files[-1]), "workload": d.get("workload", "tests/diag/run_ar.py 12 (prefill + 11 decode steps, bf16, B=16)")}
 
 
 def dominant_kernel_roofline(step_fn, ar, df):
@@ -59,6 +62,10 @@ def dominant_kernel_roofline(step_fn, ar, df):
 		achieved, peak, unit, bound = r["work"] / sec / 1e12, PEAK_TFLOPS[df.dtype], "TFLOP/s", "mfma"
 	else:
 		achieved, peak, unit, bound = r["work"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-	return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": _pmc_traffic(kind),
+	traffic, source = _pmc_traffic(kind)
+	# `traffic`: HBM bytes per launch from PMC counters.  They cannot be collected inside this process (rocprofv3 has to own it), so the
+	# live line carries null and the committed PMC summary is quoted beside it with its source.
+	return {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak, "traffic": None,
+			"traffic_from_profiles": traffic, "traffic_source": source,
 			"kernel": KERNEL_NAMES[kind], "launches_per_step": r["launches"], "avg_launch_us": 1e3 * r["ms"] / max(r["launches"], 1),
 			"algorithmic_work_per_launch": r["work"] / max(r["launches"], 1), "per_kernel_ms": breakdown}
