@@ -117,6 +117,34 @@ def diff_case(d_mod, cfg, seed, b, M, full):
 	return out
 
 
+def diff_cfg1_case(d_mod):
+	"""configs[1] at its own size through the REFERENCE: full-size DiffusionTTS, 250 mel tokens -> T = 1088 frames; timestep_independent,
+	one conditioned + one conditioning-free evaluation, and the LAST 8 steps of the 80-step DDIM schedule (`ddim_sample` :646-694 with the
+	ramped conditioning-free weight) started from x as x_8.  Stored subsampled (the full tensors are megabytes of noise-like floats): E and
+	the evaluations on every 8th frame, the final mel whole.  tests/test_gpu_bench_shapes.py regenerates the inputs from the same seeds."""
+	cfg = W.DIFF_FULL
+	sd = W.synth_state_dict(W.diffusion_shapes(cfg), 1)
+	m = d_mod.DiffusionTTS(model_channels=cfg.model_channels, num_layers=cfg.num_layers, in_channels=cfg.in_channels,
+						   in_latent_channels=cfg.in_latent_channels, out_channels=cfg.out_channels, num_heads=cfg.num_heads)
+	load_into(m, sd)
+	M, T = 250, 250 * 4 * 24000 // 22050
+	lat = torch.randn(1, M, 1024, generator=gen(11))
+	dcond = torch.randn(1, 2048, generator=gen(12))
+	x = torch.randn(1, 100, T, generator=gen(13))
+	t = torch.tensor([1500])
+	diffuser = d_mod.get_diffuser(steps=80, cond_free=True)
+	with torch.inference_mode():
+		E = m.timestep_independent(lat, dcond, T, False)
+		yc = m(x, t, precomputed_aligned_embeddings=E)
+		yu = m(x, t, precomputed_aligned_embeddings=E, conditioning_free=True)
+		xm = x
+		torch.manual_seed(0)
+		for i in reversed(range(8)):
+			xm = diffuser.ddim_sample(m, xm, torch.tensor([i]), clip_denoised=True, model_kwargs={"precomputed_aligned_embeddings": E}, eta=0.0)["sample"]
+	return dict(T=np.int64(T), M=np.int64(M), stride=np.int64(8), E_sub=E[:, :, ::8].numpy(), y_cond_sub=yc[:, :, ::8].numpy(),
+				y_uncond_sub=yu[:, :, ::8].numpy(), mel=xm.numpy())
+
+
 def schedule_case(d_mod):
 	out = {}
 	for steps in (4, 30, 80, 200):
@@ -439,6 +467,7 @@ def main():
 		("diff_small", lambda: diff_case(d_mod, W.DIFF_SMALL, 21, b=2, M=10, full=False)),
 		("ar_full", lambda: ar_case(uv_mod, W.AR_FULL, 12, B=1, Tt=8, n_dec=2, M=6, full=True)),
 		("diff_full", lambda: diff_case(d_mod, W.DIFF_FULL, 22, b=1, M=6, full=True)),
+		("diff_cfg1", lambda: diff_cfg1_case(d_mod)),
 		("lora_small", lambda: lora_case(uv_mod, W.AR_SMALL, 13, rank=4, alpha=8)),
 		("hf_sample_loop", hf_sample_loop_case),
 		("wrapper", lambda: wrapper_case(uv_mod)),

@@ -122,57 +122,55 @@ def diff_sd():
 
 
 @pytest.fixture(scope="module")
-def cfg1_diff_case(diff_sd):
-	"""configs[1]: 250 mel tokens -> T = 1088 frames."""
-	M, T = 250, O.mel_frames_for(250)
-	assert T == 1088
+def cfg1_diff_case(golden):
+	"""configs[1]: 250 mel tokens -> T = 1088 frames.  Expected values come from the REFERENCE run at this size in the build container
+	(tests/golden/diff_cfg1.npz, oracle/make_golden.py: diff_cfg1_case): E and the two evaluations on every 8th frame, and the final
+	mel of the last 8 steps of the 80-step DDIM schedule started from x as x_8.  Inputs are regenerated from the same seeds."""
+	g = golden("diff_cfg1")
+	M, T = int(g["M"]), int(g["T"])
+	assert T == O.mel_frames_for(M) == 1088
 	lat = torch.randn(1, M, 1024, generator=gen(11))
 	dcond = torch.randn(1, 2048, generator=gen(12))
 	x = torch.randn(1, 100, T, generator=gen(13))
 	t = torch.tensor([1500])
-	dor = O.DiffusionOracle(diff_sd, W.DIFF_FULL)
-	sched = O.SpacedSchedule(steps=80, cond_free=True)
-	with torch.inference_mode():
-		E = dor.timestep_independent(lat, dcond, T)
-		yc = dor.forward(x, t, E)
-		yu = dor.forward(x, t, None, conditioning_free=True)
-		xm = x
-		for i in reversed(range(8)):          # the last 8 steps of the 80-step schedule, started from x as x_8
-			xm = sched.ddim_step(dor, xm, i, E)
-	return lat, dcond, x, t, E, yc, yu, xm
+	tt = lambda k: torch.from_numpy(g[k])
+	return lat, dcond, x, t, int(g["stride"]), tt("E_sub"), tt("y_cond_sub"), tt("y_uncond_sub"), tt("mel")
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_config1_evaluation_and_ddim_slice_at_T1088(diff_sd, cfg1_diff_case, dtype):
 	from tortoise_tts_amd import _lib
 	from tortoise_tts_amd.diffusion import DiffusionTTS, get_diffuser
-	lat, dcond, x, t, E, yc, yu, xm = cfg1_diff_case
+	lat, dcond, x, t, st, E_sub, yc_sub, yu_sub, xm = cfg1_diff_case
 	T = x.shape[-1]
 	model = DiffusionTTS(diff_sd, W.DIFF_FULL, dtype=dtype, device=DEV)
 	gE = model.timestep_independent(lat.to(DEV), dcond.to(DEV), T, False)
-	gc = model(x.to(DEV), t.to(DEV), precomputed_aligned_embeddings=E.to(DEV))
+	# the evaluations and the loop take the oracle's E (f32, equal to the reference's) as their input in both arithmetic modes, so each stage
+	# is compared on its own
+	with torch.inference_mode():
+		E = O.DiffusionOracle(diff_sd, W.DIFF_FULL).timestep_independent(lat, dcond, T).to(DEV)
+	assert maxerr(E[:, :, ::st], E_sub) < 1e-4
+	gc = model(x.to(DEV), t.to(DEV), precomputed_aligned_embeddings=E)
 	gu = model(x.to(DEV), t.to(DEV), conditioning_free=True)
 	# last 8 steps of the 80-step schedule through the whole-loop entry (two-stream, cond + cond-free as one batch of 2)
 	d = get_diffuser(steps=80, cond_free=True)
 	steps = (_lib.StepC * 8)(*[d.step_coefs(i, "ddim") for i in range(8)])
 	gx = x.to(DEV).clone()
-	Ed = E.to(DEV).contiguous()
+	Ed = E.contiguous()
 	_lib.check(model.lib.ttk_diff_sample_ddim(model._h, gx.data_ptr(), Ed.data_ptr(), 1, T, steps, 8, _lib.stream_ptr()), "ttk_diff_sample_ddim")
 	torch.cuda.synchronize()
 	if dtype == "f32":
-		assert maxerr(gE, E) < F32_EVAL_ABS and maxerr(gc, yc) < F32_EVAL_ABS and maxerr(gu, yu) < F32_EVAL_ABS
+		assert maxerr(gE[:, :, ::st], E_sub) < F32_EVAL_ABS and maxerr(gc[:, :, ::st], yc_sub) < F32_EVAL_ABS and maxerr(gu[:, :, ::st], yu_sub) < F32_EVAL_ABS
 		assert maxerr(gx, xm) < F32_MEL_ABS
 	else:
-		assert relerr(gE, E) < BF16_LOGITS
-		assert relerr(gc, yc) < BF16_EVAL and relerr(gu, yu) < BF16_EVAL, (relerr(gc, yc), relerr(gu, yu))
+		assert relerr(gE[:, :, ::st], E_sub) < BF16_LOGITS
+		assert relerr(gc[:, :, ::st], yc_sub) < BF16_EVAL and relerr(gu[:, :, ::st], yu_sub) < BF16_EVAL, (relerr(gc[:, :, ::st], yc_sub), relerr(gu[:, :, ::st], yu_sub))
 		assert relerr(gx, xm) < BF16_MEL, relerr(gx, xm)
 	assert gx.abs().max() <= 1.0 + 1e-5        # step 0: alpha_bar_prev = 1, so the result is the clamped x0
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
-def test_config3_evaluation_at_T2176(diff_sd, dtype):
-	"""500 mel tokens -> T = 2176 frames: 34 key tiles, the relative-position bias saturated over most of them, M = 4352 GEMM rows."""
-	from tortoise_tts_amd.diffusion import DiffusionTTS
+@pytest.fixture(scope="module")
+def cfg3_diff_case(diff_sd):
 	T = O.mel_frames_for(500)
 	assert T == 2176
 	x = torch.randn(1, 100, T, generator=gen(21))
@@ -182,6 +180,14 @@ def test_config3_evaluation_at_T2176(diff_sd, dtype):
 		dor = O.DiffusionOracle(diff_sd, W.DIFF_FULL)
 		yc = dor.forward(x, t, E)
 		yu = dor.forward(x, t, None, conditioning_free=True)
+	return x, E, t, yc, yu
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_config3_evaluation_at_T2176(diff_sd, cfg3_diff_case, dtype):
+	"""500 mel tokens -> T = 2176 frames: 34 key tiles, the relative-position bias saturated over most of them, M = 4352 GEMM rows."""
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	x, E, t, yc, yu = cfg3_diff_case
 	model = DiffusionTTS(diff_sd, W.DIFF_FULL, dtype=dtype, device=DEV)
 	gc = model(x.to(DEV), t.to(DEV), precomputed_aligned_embeddings=E.to(DEV))
 	gu = model(x.to(DEV), t.to(DEV), conditioning_free=True)
