@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
 			if (sh.resid) { g.residual = Cf; g.ldr = sh.N; g.C = Cf; g.ldc = sh.N; g.out_f32 = 1; } else { g.C = Cb; g.ldc = sh.N; }
 			return g;
 		};
-		for (int tile = 0; tile < 5; ++tile) {
+		for (int tile = 0; tile < 8; ++tile) {
 			if (only_tile >= 0 && tile != only_tile) continue;
 			g_force_tile = 100 + tile;
 			for (int i = 0; i < 5; ++i) launch_gemm(DT_BF16, params(i % nset), s);
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
 			CK(hipEventSynchronize(e1));
 			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 			const double us = ms * 1e3 / reps, tf = 2.0 * sh.M * sh.N * (double)sh.K * sh.nseg / (us * 1e-6) / 1e12;
-			printf("%-38s %s tile %s  %8.2f us  %7.1f TF/s\n", sh.name, cold ? "cold" : "hot ", tile == 0 ? "128x128 8w" : tile == 1 ? "128x64  4w" : tile == 3 ? "128x128 8w 4st" : tile == 4 ? "128x64 4w 5st" : "64x64   4w", us, tf);
+			printf("%-38s %s tile %s  %8.2f us  %7.1f TF/s\n", sh.name, cold ? "cold" : "hot ", tile == 0 ? "128x128 8w" : tile == 1 ? "128x64  4w" : tile == 3 ? "128x128 8w 4st" : tile == 4 ? "128x64 4w 5st" : tile == 5 ? "128x64 8w(4x2)" : tile == 6 ? "128x64 8w(2x4)" : tile == 7 ? "256x64 8w" : "64x64   4w", us, tf);
 		}
 		CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(Cb)); CK(hipFree(Cf)); CK(hipFree(bias));
 	}

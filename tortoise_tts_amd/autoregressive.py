@@ -246,10 +246,23 @@ class UnifiedVoice:
 							g = torch.cuda.CUDAGraph()
 							# thread-local capture mode: another host thread may be enqueuing (and allocating for) the previous
 							# line's diffusion meanwhile (TTSHotPath.inference_lines); in the default global mode its hipMalloc /
-							# hipFree would invalidate this capture
-							with torch.cuda.graph(g, capture_error_mode="thread_local"):
+							# hipFree would invalidate this capture.
+							# capture_begin / capture_end run OUTSIDE inference mode whatever the caller's mode: torch creates the
+							# generator's graph-side seed / offset tensors at the first capture and updates them in place at every
+							# later capture and replay -- created under inference_mode they would make any later capture from a
+							# caller without it fail ("inplace update to inference tensor outside InferenceMode").
+							ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
+							with torch.inference_mode(False):
+								ctx.__enter__()
+							try:
 								self._decode_next(st.logits)
 								st.sample(0)
+							except BaseException:
+								with torch.inference_mode(False):
+									ctx.__exit__(*__import__("sys").exc_info())
+								raise
+							with torch.inference_mode(False):
+								ctx.__exit__(None, None, None)
 							st.graph = g
 						continue
 					st.graph.replay()

@@ -87,6 +87,11 @@ struct ttk_ar {
 	int* d_pos;             // device scalar: number of valid cache rows
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
+	void* x_frag = nullptr; // T copy of x in A-fragment order [m_tile][d/32][64][8]: operand of the folded-LayerNorm launches
+	int shared_rows = 0;    // leading cache rows that are identical for all candidates of the current generation (AttnDecodeParams.shared_rows)
+	int share_prefix = 1;   // TTK_AR_SHARE_PREFIX=0: every candidate reads its own copy
+	int head_split = 1;     // decode head as LayerNorm launch + plain GEMV (TTK_AR_HEAD_SPLIT=0: norms inside the GEMV)
+	int lnfold = 1;         // ln_1 + c_attn and ln_2 + c_fc of the decode step with the LayerNorm folded into the matrix (TTK_AR_LNFOLD=0: LN prologue)
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
 	int wv_proj = 8, wv_proj2 = 16;   // waves per workgroup of the two plain decode GEMVs (TTK_AR_WV_PROJ / TTK_AR_WV_PROJ2)
 	int wv_head = 4;                  // waves per workgroup of the ln_f + final_norm + mel_head launch (TTK_AR_WV_HEAD): 513 n-tiles; with 8-wave
@@ -167,30 +172,34 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	char* hbuf = (char*)h->hbuf + (size_t)r0 * 4 * d * es;
 	const size_t kv_row = (size_t)H * c.max_ctx * 64 * es;
 	const int wv_small = d >= 1024 ? 8 : 4;   // waves per workgroup that split K = d
+	const bool whole = r0 == 0 && nrows == h->B;      // fragment-order activations exist for the whole batch only
+	void* xf = whole ? h->x_frag : nullptr;
 	for (int l = 0; l < c.layers; ++l) {
 		const ARLayer& L = h->L[l];
 		char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
 		char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
 		SkinnyParams p = {};
 		p.Wp = L.attn.wfrag; p.w8 = L.attn.w8; p.wscale = L.attn.wscale; p.N = 3 * d; p.K = d; p.M = nrows; p.bias = L.attn.bias;
-		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b;
+		if (h->lnfold && whole && L.attn.wfrag_fold) { p.Wp = L.attn.wfrag_fold; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
+		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b; }
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
 		launch_skinny(dt, p, wv_small, s);
 		AttnDecodeParams a = {};
-		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
+		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 ? h->shared_rows : 0;
 		launch_attn_decode(dt, a, s);
 		p = {};
 		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
-		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.narrow = h->narrow;
+		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.narrow = h->narrow; p.out_T = h->lnfold ? xf : nullptr;
 		launch_skinny(dt, p, d >= 1024 ? h->wv_proj : 4, s);
 		p = {};
 		p.Wp = L.fc.wfrag; p.w8 = L.fc.w8; p.wscale = L.fc.wscale; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
-		p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b;
+		if (h->lnfold && whole && L.fc.wfrag_fold) { p.Wp = L.fc.wfrag_fold; p.bias = L.fc.bias_fold; p.g1 = L.fc.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
+		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b; }
 		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf; p.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		launch_skinny(dt, p, wv_small, s);
 		p = {};
 		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
-		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d;
+		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.out_T = h->lnfold ? xf : nullptr;
 		p.narrow = h->narrow2;
 		if (d >= 1024 && !h->narrow2) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
 			p.ksplit = 4; p.slab = h->slab + (size_t)gi * (d / 16) * 4 * 4 * 256; p.tickets = h->tickets + (size_t)gi * (d / 16);
@@ -199,13 +208,22 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	}
 	SkinnyParams p = {};
 	p.Wp = h->head.wfrag; p.N = c.number_mel_codes; p.K = d; p.M = nrows; p.bias = h->head.bias;
-	p.ln_count = 2; p.x = x; p.ldx = d;
-	p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hidden_out ? hidden_out + (size_t)r0 * d : nullptr;
 	p.mode = SK_STORE_F32; p.out_f32 = logits_out + (size_t)r0 * c.number_mel_codes; p.ldc = c.number_mel_codes;
 	// the last launch of the step advances the cache length: every reader of *d_pos (c_attn epilogues, attention) is behind it on the
 	// stream, the next reader is the next step -- one 1-thread launch per token less (an otherwise unused field carries the pointer)
 	if (bump_pos) p.d_pos = h->d_pos;
-	launch_skinny(dt, p, d >= 1024 ? h->wv_head : 4, s);
+	float* hid = hidden_out ? hidden_out + (size_t)r0 * d : nullptr;
+	if (h->head_split && whole) {
+		// ln_f + final_norm ONCE (4 workgroups), the mel head as a plain 513-tile GEMV over the normalised rows in fragment order: with the
+		// norms inside the GEMV every one of the 513 workgroups normalised all 16 rows, two passes each -- 17 us for 16.8 MB of weights
+		launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, hid);
+		p.a = h->attn_out; p.lda = d; p.a_frag = 1;
+		launch_skinny(dt, p, 4, s);      // 4-wave workgroups: five fit a CU, so the 513 tiles run as one round (two 8-wave ones fit: 512 slots)
+	} else {
+		p.ln_count = 2; p.x = x; p.ldx = d;
+		p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hid;
+		launch_skinny(dt, p, d >= 1024 ? h->wv_head : 4, s);
+	}
 }
 
 extern "C" {
@@ -241,6 +259,10 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "attn.c_proj.weight", p + "attn.c_proj.bias", PK_KN, d, d, true, &L.proj));
 		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", PK_KN, 4 * d, d, true, &L.fc));
 		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", PK_KN, d, 4 * d, true, &L.proj2));
+		if (h->wdt == h->dt) {   // not for fp8 weights: folding gamma in would change what gets rounded (TTK_FP8W is defined on the reference's matrices)
+			AR_TRY(fold_layernorm(h->arena, wm, h->dt, p + "attn.c_attn.weight", p + "attn.c_attn.bias", p + "ln_1.weight", p + "ln_1.bias", &L.attn));
+			AR_TRY(fold_layernorm(h->arena, wm, h->dt, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", p + "ln_2.weight", p + "ln_2.bias", &L.fc));
+		}
 	}
 	AR_TRY(upload_f32(h->arena, wm, "gpt.ln_f.weight", d, &h->lnf_g));
 	AR_TRY(upload_f32(h->arena, wm, "gpt.ln_f.bias", d, &h->lnf_b));
@@ -262,6 +284,8 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	// 16-row tiles: the decode path keeps the MLP activations in fragment order, whose padding rows must exist and hold zeros
 	AR_TRY(h->arena.alloc(&h->hbuf, (size_t)round_up(cfg->max_batch, 16) * 4 * d * h->es));
 	if (hipMemset(h->hbuf, 0, (size_t)round_up(cfg->max_batch, 16) * 4 * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
+	AR_TRY(h->arena.alloc(&h->x_frag, (size_t)round_up(cfg->max_batch, 16) * d * h->es));
+	if (hipMemset(h->x_frag, 0, (size_t)round_up(cfg->max_batch, 16) * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->slab, (size_t)4 * (d / 16) * 4 * 4 * 256 * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)4 * (d / 16) * sizeof(int)));
 	if (hipMemset(h->tickets, 0, (size_t)4 * (d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
@@ -279,6 +303,12 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 		if (e2 && atoi(e2) >= 4 && atoi(e2) <= 16) h->wv_proj2 = atoi(e2);
 		const char* e3 = getenv("TTK_AR_WV_HEAD");
 		if (e3 && (atoi(e3) == 4 || atoi(e3) == 8)) h->wv_head = atoi(e3);
+		const char* es = getenv("TTK_AR_SHARE_PREFIX");
+		h->share_prefix = es ? (atoi(es) != 0) : 1;
+		const char* eh = getenv("TTK_AR_HEAD_SPLIT");
+		h->head_split = eh ? (atoi(eh) != 0) : 1;
+		const char* el = getenv("TTK_AR_LNFOLD");
+		h->lnfold = el ? (atoi(el) != 0) : 1;
 		const char* e = getenv("TTK_AR_SPLIT");
 		h->nsplit = e ? atoi(e) : 1;
 		if (h->nsplit != 1 && h->nsplit != 2 && h->nsplit != 4) h->nsplit = 1;
@@ -325,6 +355,7 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, S, s);
 	h->B = B; h->P = Tt + 3; h->k = 0; h->ready = 1;
+	h->shared_rows = (Bc == 1 && B > 1 && h->share_prefix) ? S : 0;      // one latent, one text line: all B prefixes are the same rows
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }
@@ -339,7 +370,7 @@ static int decode_impl(ttk_ar* h, const int64_t* tok, float* logits_out, float* 
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)
 	// (tok == null: ttk_ar_sample_next has written the rows already)
-	if (tok) launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s);
+	if (tok) launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s, h->lnfold ? h->x_frag : nullptr, h->dt == DT_F32);
 	// Experiment kept behind TTK_AR_SPLIT (default 1 = off): cut the candidates into row groups whose launch chains run on forked
 	// streams.  Rows are independent, so results are unchanged -- but on MI355X it LOSES (B=16, 250 tokens: 283 ms -> 340 ms with
 	// 2 groups, 517 ms with 4): the LayerNorm kernels already hold one 8-wave workgroup per CU, so the second chain cannot
@@ -379,7 +410,8 @@ int ttk_ar_sample_next(ttk_ar* h, const ttk_sample_args* a, void* stream) {
 	TTK_REQUIRE(h->ready, TTK_E_STATE, "ttk_ar_sample_next: call ttk_ar_prefill first");
 	TTK_REQUIRE(a->B == h->B && a->V == h->cfg.number_mel_codes, TTK_E_ARG, "ttk_ar_sample_next: shape (B %d, V %d) is not the prefilled one (B %d, V %d)",
 				a->B, a->V, h->B, h->cfg.number_mel_codes);
-	return launch_sample_step(a, h->mel_emb, h->mel_pos, h->x, h->cfg.model_dim, h->cfg.max_mel_seq_len, (hipStream_t)stream, "ttk_ar_sample_next");
+	return launch_sample_step(a, h->mel_emb, h->mel_pos, h->x, h->cfg.model_dim, h->cfg.max_mel_seq_len, h->lnfold ? h->x_frag : nullptr, h->dt == DT_F32,
+							  (hipStream_t)stream, "ttk_ar_sample_next");
 }
 
 int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream) {

@@ -324,9 +324,13 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	const int h = blockIdx.x, b = blockIdx.y;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int slot = lane >> 3, dg = lane & 7;
+#ifdef TTK_ABL      // diagnostic builds only (tests/diag/ar_ablate.sh): 256 = the whole kernel, 128 = the K / V loads
+	if (TTK_ABL & 256) return;
+#endif
 	const int n = min(*p.d_pos + 1, p.max_ctx);
 	const T* Kc = (const T*)p.kcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
 	const T* Vc = (const T*)p.vcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
+	const int64_t to_shared = -(int64_t)b * p.H * p.max_ctx * HD;      // element offset from this candidate's slice to candidate 0's
 	float q[8];
 	{
 		const float* qp = p.qbuf + ((int64_t)b * p.H + h) * HD + 8 * dg;
@@ -343,8 +347,12 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 		for (int u = 0; u < UN; ++u) {     // unconditional, clamped: all 2*UN requests leave before the first use
 			int key = (gb + u * NW) * 8 + slot;
 			key = key < n ? key : n - 1;
-			kf[u] = *(const FragT*)(Kc + (int64_t)key * HD + 8 * dg);
-			vf[u] = *(const FragT*)(Vc + (int64_t)key * HD + 8 * dg);
+#ifdef TTK_ABL
+			if (TTK_ABL & 128) { kf[u] = FragT{}; vf[u] = FragT{}; continue; }
+#endif
+			const int64_t off = (int64_t)key * HD + 8 * dg + (key < p.shared_rows ? to_shared : 0);
+			kf[u] = *(const FragT*)(Kc + off);
+			vf[u] = *(const FragT*)(Vc + off);
 		}
 #pragma unroll
 		for (int u = 0; u < UN; ++u) {

@@ -27,7 +27,9 @@ void launch_gather_add(const float* A, const int* ia, const float* Bt, const int
 
 // decode: x[b] = mel_embedding[tok[b]] + mel_pos_embedding[*d_pos + pos_off]
 // (unified_voice.py:213-214; with d_pos = cache length before this step = P + k, pos_off = 1 - P gives the k + 1 quirk)
-__global__ void k_decode_embed(const float* emb, const int64_t* tok, const float* pos, const int* d_pos, int pos_off, int pos_rows, float* out, int B, int d) {
+// frag (optional): the same rows, T-typed, in A-fragment order [m_tile][d/32][lane][8] for a folded-LayerNorm launch (skinny.hip)
+__global__ void k_decode_embed(const float* emb, const int64_t* tok, const float* pos, const int* d_pos, int pos_off, int pos_rows, float* out, int B, int d,
+							   void* frag, int frag_f32) {
 	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
 	const int d4 = d / 4;
 	if (idx >= B * d4) return;
@@ -35,10 +37,17 @@ __global__ void k_decode_embed(const float* emb, const int64_t* tok, const float
 	int pi = *d_pos + pos_off;
 	pi = pi < 0 ? 0 : (pi >= pos_rows ? pos_rows - 1 : pi);   // guard; the host validates lengths up front
 	const float4 e = *(const float4*)(emb + tok[b] * d + c), w = *(const float4*)(pos + (int64_t)pi * d + c);
-	*(float4*)(out + (int64_t)b * d + c) = make_float4(e.x + w.x, e.y + w.y, e.z + w.z, e.w + w.w);
+	const float4 v = make_float4(e.x + w.x, e.y + w.y, e.z + w.z, e.w + w.w);
+	*(float4*)(out + (int64_t)b * d + c) = v;
+	if (frag) {
+		const int64_t fi = ((((int64_t)(b >> 4) * (d / 32) + (c >> 5)) * 64 + ((c >> 3) & 3) * 16 + (b & 15)) * 8 + (c & 7));
+		if (frag_f32) *(float4*)((float*)frag + fi) = v;
+		else { union { bf16x4 h; uint2 u; } pk; pk.h = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w}; *(uint2*)((bf16*)frag + fi) = pk.u; }
+	}
 }
-void launch_decode_embed(const float* emb, const int64_t* tok, const float* pos, const int* d_pos, int pos_off, int pos_rows, float* out, int B, int d, hipStream_t s) {
-	hipLaunchKernelGGL(k_decode_embed, dim3((B * (d / 4) + 255) / 256), dim3(256), 0, s, emb, tok, pos, d_pos, pos_off, pos_rows, out, B, d);
+void launch_decode_embed(const float* emb, const int64_t* tok, const float* pos, const int* d_pos, int pos_off, int pos_rows, float* out, int B, int d, hipStream_t s,
+						 void* frag, int frag_f32) {
+	hipLaunchKernelGGL(k_decode_embed, dim3((B * (d / 4) + 255) / 256), dim3(256), 0, s, emb, tok, pos, d_pos, pos_off, pos_rows, out, B, d, frag, frag_f32);
 }
 
 __global__ void k_copy_rows(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int d) {

@@ -391,6 +391,9 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 	else if (tile == 1) launch_tile<T, 128, 64, 2, 2, 3>(p, s, ea, eb);   // 4 waves, wave block 64 x 32, two workgroups per CU
 	else if (tile == 3) launch_tile<T, 128, 128, 2, 4, 4>(p, s, ea, eb);  // as 0 with a 4-stage ring (128 KiB: one workgroup per CU)
 	else if (tile == 4) launch_tile<T, 128, 64, 2, 2, 5>(p, s, ea, eb);   // as 1 with a 5-stage ring (120 KiB: one workgroup per CU)
+	else if (tile == 5) launch_tile<T, 128, 64, 4, 2, 3>(p, s, ea, eb);   // as 1 with 8 waves (wave block 32 x 32): twice the waves issuing the LDS-DMA pieces
+	else if (tile == 6) launch_tile<T, 128, 64, 2, 4, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 16
+	else if (tile == 7) launch_tile<T, 256, 64, 4, 2, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 32, 120 KiB: one workgroup per CU
 	else launch_tile<T, 64, 64, 2, 2, 3>(p, s, ea, eb);
 }
 

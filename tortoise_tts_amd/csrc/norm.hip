@@ -5,6 +5,7 @@
 //                used by ResBlock diffusion.py:1338-1372 and AttentionBlock arch_utils.py:163,186
 // Internal layout is channels-last [nb][T][C], so a group is (T rows) x (C/32 contiguous channels).
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ttk_common.h"
 #include "ttk_kernels.h"
@@ -12,9 +13,10 @@
 namespace ttk {
 
 // one wave per row; d <= 4096
+// frag != 0: `out` is written in the MFMA A-fragment order of the skinny decode GEMV ([m_tile][d/32][lane][8], skinny.hip) instead of row-major
 template <typename OT>
 __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
-							const float* g2, const float* b2, OT* out, int64_t ldo) {
+							const float* g2, const float* b2, OT* out, int64_t ldo, int frag, float* out2) {
 	const int lane = threadIdx.x & 63;
 	const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (row >= rows) return;
@@ -56,20 +58,22 @@ __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const 
 	for (int i = 0; i < 16; ++i) {
 		const int c = lane + 64 * i;
 		if (c < nchunk) {
-			OT* o = out + (int64_t)row * ldo + 4 * c;
+			const int n = 4 * c;
+			OT* o = frag ? out + ((((int64_t)(row >> 4) * (d / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (row & 15)) * 8 + (n & 7)) : out + (int64_t)row * ldo + n;
 			o[0] = (OT)v[i].x; o[1] = (OT)v[i].y; o[2] = (OT)v[i].z; o[3] = (OT)v[i].w;
+			if (out2) *(float4*)(out2 + (int64_t)row * d + n) = v[i];
 		}
 	}
 }
 
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
-					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s) {
+					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s, int frag, float* out2) {
 	ProfScope prof(PROF_LAYERNORM, (double)rows * d * (4.0 + (out_f32 ? 4.0 : dtype_size(dt))), s);
 	const int grid = (rows + 3) / 4;
 	if (out_f32 || dt == DT_F32)
-		hipLaunchKernelGGL((k_layernorm<float>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (float*)out, ldo);
+		hipLaunchKernelGGL((k_layernorm<float>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (float*)out, ldo, frag, out2);
 	else
-		hipLaunchKernelGGL((k_layernorm<bf16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (bf16*)out, ldo);
+		hipLaunchKernelGGL((k_layernorm<bf16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (bf16*)out, ldo, frag, out2);
 }
 
 // ---------------------------------------------------------------- GroupNorm32
@@ -120,8 +124,9 @@ void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStrea
 
 // apply: a block owns a strip of output rows of ONE batch element.  It first merges that element's 32 groups' chunk statistics
 // (Chan et al.) into LDS, then streams its rows: thread = 4 consecutive channels (one group, since C/32 % 4 == 0).
-constexpr int GN_PASSES = 2;
-template <typename OT>
+// GN_PASSES rows per thread: a block's fixed cost (merging 32 groups x nchunks triples, the barrier) is paid once per strip of 256 / (C/4) * GN_PASSES
+// rows; 2 = 1088 blocks of 2 rows at T = 1088, 8 = 272 blocks of 8 rows (TTK_GN_PASSES, decided by tests/diag/ddim_ab.py)
+template <typename OT, int GN_PASSES>
 __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	__shared__ float s_mean[32], s_rstd[32];
 	const int c4n = p.C / 4;                    // threads per row
@@ -194,13 +199,22 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	}
 }
 
+template <int PASSES>
+static void launch_gn_apply_p(int dt, const GnApplyParams& p, hipStream_t s) {
+	const int strip = (256 / (p.C / 4)) * PASSES;
+	const int grid = p.nb * ((p.Tout + strip - 1) / strip);
+	if (p.out_f8) hipLaunchKernelGGL((k_gn_apply<f8, PASSES>), dim3(grid), dim3(256), 0, s, p);
+	else if (p.out_f32 || dt == DT_F32) hipLaunchKernelGGL((k_gn_apply<float, PASSES>), dim3(grid), dim3(256), 0, s, p);
+	else hipLaunchKernelGGL((k_gn_apply<bf16, PASSES>), dim3(grid), dim3(256), 0, s, p);
+}
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
 	ProfScope prof(PROF_GN_APPLY, (double)p.nb * p.Tout * p.C * (4.0 + (p.out_f8 ? 1.0 : p.out_f32 ? 4.0 : dtype_size(dt))), s);
-	const int strip = (256 / (p.C / 4)) * GN_PASSES;
-	const int grid = p.nb * ((p.Tout + strip - 1) / strip);
-	if (p.out_f8) hipLaunchKernelGGL((k_gn_apply<f8>), dim3(grid), dim3(256), 0, s, p);
-	else if (p.out_f32 || dt == DT_F32) hipLaunchKernelGGL((k_gn_apply<float>), dim3(grid), dim3(256), 0, s, p);
-	else hipLaunchKernelGGL((k_gn_apply<bf16>), dim3(grid), dim3(256), 0, s, p);
+	static const int passes = [] { const char* e = getenv("TTK_GN_PASSES"); return e ? atoi(e) : 2; }();
+	// few rows in all (short clips, the latent conditioner): keep the strips small so the launch still spreads over the chip
+	const int rows = p.nb * p.Tout * (p.C / 4) / 256;
+	if (passes >= 8 && rows >= 8 * 256) launch_gn_apply_p<8>(dt, p, s);
+	else if (passes >= 4 && rows >= 4 * 256) launch_gn_apply_p<4>(dt, p, s);
+	else launch_gn_apply_p<2>(dt, p, s);
 }
 
 }  // namespace ttk

@@ -57,6 +57,45 @@ void launch_pack_frag(int dt, const void* src, int Npad, int K, void* dst, hipSt
 	else hipLaunchKernelGGL((k_pack_frag<float>), dim3(grid), dim3(256), 0, s, (const float*)src, Npad, K, (float*)dst);
 }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm folded into a decode GEMV
+// LN(x) W + b  =  rstd * (x (gamma o W) - mean * colsum(gamma o W)) + (b + beta W):  the decode step's ln_1 + c_attn and ln_2 + c_fc launches
+// multiply the UN-normalised row by W' = gamma o W and finish the LayerNorm in their epilogue from the row's (mean, rstd) -- see k_skinny's
+// FOLD path.  w is the HF Conv1D weight [K][N] (f32, device).
+__global__ void k_scale_kn(float* w, const float* gamma, int K, int N) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < (int64_t)K * N) w[i] *= gamma[i / N];
+}
+void launch_scale_kn(float* w, const float* gamma, int K, int N, hipStream_t s) {
+	hipLaunchKernelGGL(k_scale_kn, dim3((unsigned)(((int64_t)K * N + 255) / 256)), dim3(256), 0, s, w, gamma, K, N);
+}
+// csum[n] = sum_k W'[n][k] over the ROUNDED (T-typed) values the kernel multiplies with, so that mean * csum cancels exactly what the
+// MFMAs summed; one wave per row, f32 partial sums over 16 elements per lane, f64 across lanes
+template <typename T>
+__global__ void k_rowsum(const T* w, int64_t ld, int N, int K, float* out) {
+	const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (n >= N) return;
+	double acc = 0.0;
+	for (int k = lane; k < K; k += 64) acc += (double)(float)w[(int64_t)n * ld + k];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+	if (lane == 0) out[n] = (float)acc;
+}
+void launch_rowsum(int dt, const void* w, int64_t ld, int N, int K, float* out, hipStream_t s) {
+	if (dt == DT_BF16) hipLaunchKernelGGL((k_rowsum<bf16>), dim3((N + 3) / 4), dim3(256), 0, s, (const bf16*)w, ld, N, K, out);
+	else hipLaunchKernelGGL((k_rowsum<float>), dim3((N + 3) / 4), dim3(256), 0, s, (const float*)w, ld, N, K, out);
+}
+// bias'[n] = b[n] + sum_k beta[k] * W[k][n]   (f32 weights as given, f64 accumulation)
+__global__ void k_bias_fold(const float* w, const float* beta, const float* b, int K, int N, float* out) {
+	const int n = blockIdx.x * blockDim.x + threadIdx.x;
+	if (n >= N) return;
+	double acc = b ? (double)b[n] : 0.0;
+	for (int k = 0; k < K; ++k) acc += (double)beta[k] * (double)w[(int64_t)k * N + n];
+	out[n] = (float)acc;
+}
+void launch_bias_fold(const float* w, const float* beta, const float* b, int K, int N, float* out, hipStream_t s) {
+	hipLaunchKernelGGL(k_bias_fold, dim3((N + 255) / 256), dim3(256), 0, s, w, beta, b, K, N, out);
+}
+
 // ------------------------------------------------------------------------------------------------ fp8-e4m3 weights
 // Quantisation is done BY the hardware conversion instructions (v_cvt_pk_fp8_f32 / v_cvt_pk_f32_fp8: OCP e4m3, round to nearest
 // even, finite range +-448), so what the decode kernels decode is by construction what was encoded here; tests pin the format against

@@ -40,6 +40,7 @@ struct SampleParams {
 	int *live_rows, *all_done;
 	// next decode step's input row (AR-aware entry only): x[b] = emb[next] + pos[col + 2]
 	const float *emb, *pos; float* x_out; int d, pos_rows;
+	void* x_frag; int x_frag_f32;      // optional copy of the same rows in A-fragment order (T-typed: bf16 or f32) for a folded-LayerNorm first launch
 };
 
 __device__ __forceinline__ float block_max(float v, float* red, int tid) {
@@ -302,12 +303,19 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(SampleParams p) 
 		float4* o = (float4*)(p.x_out + (int64_t)b * p.d);
 		for (int i = tid; i < p.d / 4; i += SAMPLE_THREADS) {
 			const float4 a = e[i], c = w[i];
-			o[i] = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+			const float4 v = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+			o[i] = v;
+			if (p.x_frag) {   // element (m = b, n = 4i + j) of [m_tile][d/32][lane = (n>>3 & 3) * 16 + (m & 15)][n & 7]: four consecutive n are contiguous
+				const int n = 4 * i;
+				const int64_t fi = ((((int64_t)(b >> 4) * (p.d / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (b & 15)) * 8 + (n & 7));
+				if (p.x_frag_f32) *(float4*)((float*)p.x_frag + fi) = v;
+				else { union { bf16x4 h; uint2 u; } pk; pk.h = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w}; *(uint2*)((bf16*)p.x_frag + fi) = pk.u; }
+			}
 		}
 	}
 }
 
-int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* pos, float* x_out, int d, int pos_rows, hipStream_t stream, const char* who) {
+int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* pos, float* x_out, int d, int pos_rows, void* x_frag, int x_frag_f32, hipStream_t stream, const char* who) {
 	TTK_REQUIRE(a && a->scores && a->q && a->unfinished && a->tok && a->ids && a->col, TTK_E_ARG, "%s: null argument", who);
 	TTK_REQUIRE(a->B >= 1 && a->V >= 1 && a->ld >= a->V && a->ldq >= a->V, TTK_E_ARG, "%s: bad shape (B %d, V %d)", who, a->B, a->V);
 	TTK_REQUIRE(a->temperature > 0.f, TTK_E_ARG, "%s: temperature must be positive", who);
@@ -321,7 +329,7 @@ int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* 
 	p.penalty = a->repetition_penalty > 0.f ? a->repetition_penalty : 1.0f; p.inv_penalty = 1.0f / p.penalty;
 	p.stop_token = a->stop_token; p.unfinished = a->unfinished; p.tok = a->tok; p.ids = a->ids; p.ids_ld = a->ids_ld; p.ids_cols = a->ids_cols;
 	p.col = a->col; p.history = a->history; p.hist_ld = a->hist_ld; p.hist_off = a->hist_off; p.live_rows = a->live_rows; p.all_done = a->all_done;
-	p.emb = emb; p.pos = pos; p.x_out = x_out; p.d = d; p.pos_rows = pos_rows;
+	p.emb = emb; p.pos = pos; p.x_out = x_out; p.d = d; p.pos_rows = pos_rows; p.x_frag = x_frag; p.x_frag_f32 = x_frag_f32;
 	hipLaunchKernelGGL(k_sample_step, dim3(a->B), dim3(SAMPLE_THREADS), 0, stream, p);
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
@@ -336,9 +344,9 @@ extern "C" int ttk_sample_step(const float* scores, int64_t ld, int B, int V, co
 	a.scores = scores; a.ld = ld; a.B = B; a.V = V; a.q = q; a.ldq = ldq; a.suppress = suppress; a.temperature = temperature; a.top_k = 0; a.top_p = 1.0f;
 	a.repetition_penalty = 1.0f; a.stop_token = stop_token; a.unfinished = unfinished; a.tok = tok; a.ids = ids; a.ids_ld = ids_ld; a.ids_cols = ids_cols;
 	a.col = col; a.history = history; a.hist_ld = hist_ld; a.hist_off = hist_off; a.live_rows = live_rows; a.all_done = all_done;
-	return ttk::launch_sample_step(&a, nullptr, nullptr, nullptr, 0, 0, (hipStream_t)stream, "ttk_sample_step");
+	return ttk::launch_sample_step(&a, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, (hipStream_t)stream, "ttk_sample_step");
 }
 
 extern "C" int ttk_sample_step_warped(const ttk_sample_args* a, void* stream) {
-	return ttk::launch_sample_step(a, nullptr, nullptr, nullptr, 0, 0, (hipStream_t)stream, "ttk_sample_step_warped");
+	return ttk::launch_sample_step(a, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, (hipStream_t)stream, "ttk_sample_step_warped");
 }

@@ -34,6 +34,13 @@ namespace ttk {
 #define TTK_WLOAD(p) (*(p))
 #endif
 
+// Diagnostic builds only (-DTTK_ABL=<bits>, tests/diag/ar_ablate.sh): leave out one part of the kernel to price it in the real decode loop
+// (results are then wrong on purpose).  1 LayerNorm statistics + affine, 2 gamma / beta loads, 4 cross-wave reduction, 8 weight loads,
+// 16 activation loads, 32 output stores, 64 the whole kernel.  Expands to nothing in the product build.
+#ifndef TTK_ABL
+#define TTK_ABL 0
+#endif
+
 #ifdef TTK_STAMPS
 #define TTK_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -58,7 +65,11 @@ template <> struct WFrag<bf16, true> {
 
 // KC = float4 chunks of a row per lane in the LayerNorm prologue (K <= 256 * KC); LN kernels run <= 8 waves (2 per SIMD,
 // 256 VGPRs), plain ones up to 16.
-template <typename T, int MT, bool LN, int KC, bool W8>
+// FOLD (plain A operand only): the LayerNorm in front of this matrix folded into it -- see SkinnyParams.g1.  The waves sum x and x^2 of the
+// fragments they feed the MFMA (lane = one row x 8 k), the per-wave row partials go through LDS next to the accumulators, and the
+// epilogue finishes (acc - mean * csum[n]) * rstd + bias.  No normalised copy of the rows is ever written, no LayerNorm barrier, no
+// gamma / beta traffic: the launch is shaped like the plain output projections.
+template <typename T, int MT, bool LN, int KC, bool W8, bool FOLD = false>
 __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	typedef typename Frag<T>::type FragT;
 	typedef WFrag<T, W8> WF;
@@ -66,6 +77,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	constexpr int ES = sizeof(T);
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+	if (TTK_ABL & 64) return;
 	// Plain mode: ksplit workgroups share one 16-column n-tile.  Narrow mode (p.narrow = 4, or 2): that many workgroups share an n-tile, each
 	// owning 4 (8) of its columns over the whole of K -- 4x (2x) the workgroups streaming the matrix without any split-K combine.  The MFMA still runs
 	// 16 columns wide: lane (g, n) fetches the fragment of column 4*sub + (n & 3), so columns 4..15 of the product are copies that the
@@ -86,6 +98,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	const int RS = p.K * ES + 16;                       // padded LDS row stride (bytes), LN mode only
 	char* a_lds = smem;
 	float* red = (float*)(smem + (LN ? 16 * MT * RS : 0));
+	float* rstat = red + nw * MT * 64 * 4;              // FOLD: [wave][m_tile][16 rows][sum, sum of squares]
 
 	// Order of the memory requests matters (vmcnt retires in order): first the activation rows this wave normalises, then
 	// its whole first batch of weight fragments, so the HBM latency of the weights hides behind the LayerNorm arithmetic.
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 				const int c = lane + 64 * i;     // fall back to s_waitcnt vmcnt(0), which would also wait for the weight stream
 				const int cc = c < nchunk ? c : nchunk - 1;
 				const int rr = live ? r : 0;
-				const float4 t = *(const float4*)(p.x + (int64_t)rr * p.ldx + 4 * cc);
+				const float4 t = (TTK_ABL & 16) ? make_float4(1.f, 2.f, 3.f, 4.f) : *(const float4*)(p.x + (int64_t)rr * p.ldx + 4 * cc);
 				v[j][i] = (live && c < nchunk) ? t : make_float4(0, 0, 0, 0);
 			}
 		}
@@ -118,13 +131,13 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		for (int i = 0; i < KC; ++i) {
 			const int c = lane + 64 * i;
 			const int cc = c < nchunk ? c : nchunk - 1;
-			const float4 tg = *(const float4*)(p.g1 + 4 * cc), tb = *(const float4*)(p.b1 + 4 * cc);
+			const float4 tg = (TTK_ABL & 2) ? make_float4(1.f, 1.f, 1.f, 1.f) : *(const float4*)(p.g1 + 4 * cc), tb = (TTK_ABL & 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(p.b1 + 4 * cc);
 			g0[i] = c < nchunk ? tg : make_float4(0, 0, 0, 0);
 			b0[i] = c < nchunk ? tb : make_float4(0, 0, 0, 0);
 		}
 	};
 	auto ln_finish = [&](int r0) {
-		for (int pass = 0; pass < p.ln_count; ++pass) {
+		for (int pass = 0; pass < ((TTK_ABL & 1) ? 0 : p.ln_count); ++pass) {
 			float4 gg[KC], bb[KC];
 #pragma unroll
 			for (int i = 0; i < KC; ++i) {
@@ -212,15 +225,32 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	const int kw0 = (KS * kslice) / p.ksplit, kw1 = (KS * (kslice + 1)) / p.ksplit;   // this workgroup's k-steps
 	const int ks0 = kw0 + ((kw1 - kw0) * wave) / nw, ks1 = kw0 + ((kw1 - kw0) * (wave + 1)) / nw;
 	const WRaw* wp = (const WRaw*)p.Wp + ((int64_t)nt * KS) * 64 + (p.narrow ? ((lane & ~15) | (NC * sub + (lane & (NC - 1)))) : lane);
-	constexpr int PRE = 8;   // 8 x 1 KiB (bf16) in flight per wave
+	// Weight fragments requested per batch.  LN mode: 8 x 1 KiB (bf16) per wave.  Plain mode: the A fragments of the same k-steps are requested
+	// right beside them (B0 A0 B1 A1 ...), all before the first use -- fetched next to their MFMA instead, every k-step was one more
+	// dependent L2 round trip behind a full vmcnt(0) (8 in a row in mlp.c_proj: 4.7 of its 6.9 us) -- so the batch is sized to the register
+	// budget of a 1024-thread workgroup (128 VGPRs): <= 64 registers of operands in flight.
+	constexpr int OPREGS = (MT + 1) * (ES == 4 ? 8 : 4);                       // A (per m-tile) + B registers of one k-step
+	constexpr int PRE = LN ? 8 : (64 / OPREGS >= 8 ? 8 : (64 / OPREGS >= 4 ? 4 : (64 / OPREGS >= 2 ? 2 : 1)));
 	WRaw bpre[PRE];
+	FragT apre[LN ? 1 : PRE][MT];
 	const int npre = min(ks1 - ks0, PRE);
-	// (Requesting the plain-mode A fragments of this batch up front as well, before or after the weights, measured 5-7 ms per
-	// utterance SLOWER than letting them be fetched next to their MFMA.)
 	const int arow = lane & 15, ag = lane >> 4;
+	auto load_a_global = [&](int mt, int ks) -> FragT {
+		if (TTK_ABL & 16) return FragT{};
+		if (p.a_frag) return *(const FragT*)((const T*)p.a + (((int64_t)mt * KS + ks) * 64 + lane) * 8);   // rows >= M hold zeros
+		int row = mt * 16 + arow;
+		row = row < p.M ? row : p.M - 1;
+		return *(const FragT*)((const T*)p.a + (int64_t)row * p.lda + 32 * ks + 8 * ag);
+	};
 #pragma unroll
-	for (int u = 0; u < PRE; ++u)   // unconditional: slots beyond npre re-read the last fragment (never multiplied)
-		bpre[u] = TTK_WLOAD(wp + (int64_t)(ks0 + (u < npre ? u : npre - 1)) * 64);
+	for (int u = 0; u < PRE; ++u) {   // unconditional: slots beyond npre re-read the last fragment (never multiplied)
+		const int kk = max(ks0 + (u < npre ? u : npre - 1), kw0);
+		if (TTK_ABL & 8) bpre[u] = WRaw{}; else bpre[u] = TTK_WLOAD(wp + (int64_t)kk * 64);
+		if (!LN) {
+#pragma unroll
+			for (int mt = 0; mt < MT; ++mt) apre[u][mt] = load_a_global(mt, kk);
+		}
+	}
 
 	if (LN) {
 		ln_finish(wave);
@@ -233,56 +263,80 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	f32x4 acc[MT];
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-	auto load_a = [&](int mt, int ks) -> FragT {
-		if (LN) {
-			union { FragT v; uint4 q[ES / 2]; } u;
-			const char* src = a_lds + (mt * 16 + arow) * RS + (32 * ks + 8 * ag) * ES;
+	auto load_a_lds = [&](int mt, int ks) -> FragT {
+		union { FragT v; uint4 q[ES / 2]; } u;
+		const char* src = a_lds + (mt * 16 + arow) * RS + (32 * ks + 8 * ag) * ES;
 #pragma unroll
-			for (int f = 0; f < ES / 2; ++f) u.q[f] = *(const uint4*)(src + 16 * f);
-			return u.v;
-		} else {
-			if (p.a_frag) return *(const FragT*)((const T*)p.a + (((int64_t)mt * KS + ks) * 64 + lane) * 8);   // rows >= M hold zeros
-			int row = mt * 16 + arow;
-			row = row < p.M ? row : p.M - 1;
-			return *(const FragT*)((const T*)p.a + (int64_t)row * p.lda + 32 * ks + 8 * ag);
+		for (int f = 0; f < ES / 2; ++f) u.q[f] = *(const uint4*)(src + 16 * f);
+		return u.v;
+	};
+	float fs1[MT], fs2[MT];          // FOLD: this lane's sum / sum of squares over the k it multiplies (row lane & 15 of each m-tile)
+#pragma unroll
+	for (int mt = 0; mt < MT; ++mt) { fs1[mt] = 0.f; fs2[mt] = 0.f; }
+	auto mma_step = [&](int mt, const FragT& a, const WRaw& b) {
+		if (FOLD) {
+#pragma unroll
+			for (int j = 0; j < 8; ++j) { const float f = (float)a[j]; fs1[mt] += f; fs2[mt] = fmaf(f, f, fs2[mt]); }
 		}
+		acc[mt] = mma16<T>(a, WF::dec(b), acc[mt]);
 	};
 #pragma unroll
 	for (int u = 0; u < PRE; ++u)
 		if (u < npre) {
 #pragma unroll
-			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks0 + u), WF::dec(bpre[u]), acc[mt]);
+			for (int mt = 0; mt < MT; ++mt) mma_step(mt, LN ? load_a_lds(mt, ks0 + u) : apre[LN ? 0 : u][mt], bpre[u]);
 		}
-	constexpr int UN = 8;
+	constexpr int UN = PRE;
 	int ks = ks0 + npre;
 	for (; ks + UN <= ks1; ks += UN) {
 		WRaw b[UN];
+		FragT a[LN ? 1 : UN][MT];
 #pragma unroll
-		for (int u = 0; u < UN; ++u) b[u] = TTK_WLOAD(wp + (int64_t)(ks + u) * 64);
+		for (int u = 0; u < UN; ++u) {
+			if (TTK_ABL & 8) b[u] = WRaw{}; else b[u] = TTK_WLOAD(wp + (int64_t)(ks + u) * 64);
+			if (!LN) {
+#pragma unroll
+				for (int mt = 0; mt < MT; ++mt) a[u][mt] = load_a_global(mt, ks + u);
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);      // keep the requests in front: sunk next to their MFMAs they become dependent round trips again
 #pragma unroll
 		for (int u = 0; u < UN; ++u)
 #pragma unroll
-			for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks + u), WF::dec(b[u]), acc[mt]);
+			for (int mt = 0; mt < MT; ++mt) mma_step(mt, LN ? load_a_lds(mt, ks + u) : a[LN ? 0 : u][mt], b[u]);
 	}
 	for (; ks < ks1; ++ks) {
-		const WRaw b = TTK_WLOAD(wp + (int64_t)ks * 64);
+		const WRaw b = (TTK_ABL & 8) ? WRaw{} : TTK_WLOAD(wp + (int64_t)ks * 64);
 #pragma unroll
-		for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(load_a(mt, ks), WF::dec(b), acc[mt]);
+		for (int mt = 0; mt < MT; ++mt) mma_step(mt, LN ? load_a_lds(mt, ks) : load_a_global(mt, ks), b);
+	}
+	if (FOLD) {   // the four lanes of a row (k-groups) -> every one holds the wave's partial; lane group 0 publishes it
+#pragma unroll
+		for (int mt = 0; mt < MT; ++mt) {
+			fs1[mt] += __shfl_xor(fs1[mt], 16); fs2[mt] += __shfl_xor(fs2[mt], 16);
+			fs1[mt] += __shfl_xor(fs1[mt], 32); fs2[mt] += __shfl_xor(fs2[mt], 32);
+			if (lane < 16) *(float2*)(rstat + ((wave * MT + mt) * 16 + lane) * 2) = make_float2(fs1[mt], fs2[mt]);
+		}
 	}
 
 	TTK_STAMP(3);
 	// ---- cross-wave reduction through LDS, then epilogue by the first 256 threads
-#pragma unroll
-	for (int mt = 0; mt < MT; ++mt) *(f32x4*)(red + ((wave * MT + mt) * 64 + lane) * 4) = acc[mt];
-	__syncthreads();
-	TTK_STAMP(4);
 	float vsum[MT];
-	if (tid < 256) {
+	if (TTK_ABL & 4) {
 #pragma unroll
-		for (int mt = 0; mt < MT; ++mt) {
-			float v = 0.f;
-			for (int w = 0; w < nw; ++w) v += red[((w * MT + mt) * 64 + l2) * 4 + r];
-			vsum[mt] = v;
+		for (int mt = 0; mt < MT; ++mt) vsum[mt] = acc[mt][r & 3];
+	} else {
+#pragma unroll
+		for (int mt = 0; mt < MT; ++mt) *(f32x4*)(red + ((wave * MT + mt) * 64 + lane) * 4) = acc[mt];
+		__syncthreads();
+		TTK_STAMP(4);
+		if (tid < 256) {
+#pragma unroll
+			for (int mt = 0; mt < MT; ++mt) {
+				float v = 0.f;
+				for (int w = 0; w < nw; ++w) v += red[((w * MT + mt) * 64 + l2) * 4 + r];
+				vsum[mt] = v;
+			}
 		}
 	}
 	if (p.ksplit > 1) {
@@ -316,16 +370,30 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			}
 		}
 	}
+	float fmean[MT], frstd[MT];
+	if (FOLD && tid < 256) {
+#pragma unroll
+		for (int mt = 0; mt < MT; ++mt) {
+			float a1 = 0.f, a2 = 0.f;
+			for (int w = 0; w < nw; ++w) { const float2 t = *(const float2*)(rstat + ((w * MT + mt) * 16 + 4 * (l2 >> 4) + r) * 2); a1 += t.x; a2 += t.y; }
+			const float mean = a1 / (float)p.K;
+			fmean[mt] = mean;
+			frstd[mt] = rsqrtf(fmaxf(a2 / (float)p.K - mean * mean, 0.f) + 1e-5f);      // E[x^2] - mean^2 in f32, as the LN prologue does
+		}
+	}
 	if (!mine) return;
+	const float fcs = FOLD ? p.g1[n < p.N ? n : p.N - 1] : 0.f;
+	if (TTK_ABL & 32) { if (vsum[0] == 1.2345e-30f) p.out_f32[0] = vsum[0]; return; }
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) {
 		const int m = mt * 16 + 4 * (l2 >> 4) + r;
 		if (m >= p.M) continue;
-		const float v = (W8 ? vsum[mt] * p.wscale : vsum[mt]) + bias;
+		const float v = FOLD ? (vsum[mt] - fmean[mt] * fcs) * frstd[mt] + bias : (W8 ? vsum[mt] * p.wscale : vsum[mt]) + bias;
 		if (p.mode == SK_STORE_F32) {
 			p.out_f32[(int64_t)m * p.ldc + n] = v;
 		} else if (p.mode == SK_RESIDUAL) {
 			p.out_f32[(int64_t)m * p.ldc + n] = res[mt] + v;
+			if (p.out_T) ((T*)p.out_T)[((((int64_t)mt * (p.N / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (m & 15)) * 8 + (n & 7))] = cvt<T>(res[mt] + v);
 		} else if (p.mode == SK_ACT_T) {
 			const int64_t o = p.out_frag ? ((((int64_t)mt * (p.N / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (m & 15)) * 8 + (n & 7)) : (int64_t)m * p.N + n;
 			((T*)p.out_T)[o] = cvt<T>(apply_act(v, p.act));
@@ -359,6 +427,9 @@ static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s, hi
 			if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_skinny<T, MT, true, 8, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 			hipExtLaunchKernelGGL((k_skinny<T, MT, true, 8, W8>), dim3(grid), dim3(64 * waves), (unsigned)lds, s, ea, eb, 0, p);
 		}
+	} else if (p.g1 && !W8) {
+		const size_t lds = red + (size_t)waves * MT * 16 * 2 * sizeof(float);
+		hipExtLaunchKernelGGL((k_skinny<T, MT, false, 1, false, true>), dim3(grid), dim3(64 * waves), (unsigned)lds, s, ea, eb, 0, p);
 	} else {
 		hipExtLaunchKernelGGL((k_skinny<T, MT, false, 1, W8>), dim3(grid), dim3(64 * waves), (unsigned)red, s, ea, eb, 0, p);
 	}
@@ -375,6 +446,7 @@ void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
 	SkinnyParams p = p_in;
 	if (p.ksplit < 1 || !p.slab || !p.tickets) p.ksplit = 1;
 	if (p.ln_count > 0 || p.mode == SK_QKV) p.narrow = 0;      // every workgroup of an LN kernel normalises all rows: more of them only adds work
+	if (p.ln_count == 0 && p.g1) { p.narrow = 0; p.ksplit = 1; }   // folded LayerNorm: the row statistics need all of K inside the workgroup
 	if (p.narrow) { p.ksplit = 1; p.narrow = p.narrow == 2 ? 2 : 4; }
 	if (waves < 4) waves = 4;
 	// algorithmic bytes: the weight matrix once + bias + the M activation rows in and out

@@ -89,13 +89,22 @@ struct Mat {
 	int wes = 2;            // bytes per element of `w` (1: DT_FP8, the dense GEMM reads fp8 bytes and applies wscale in its epilogue)
 	float* bias = nullptr;
 	int N = 0, K = 0, Npad = 0, Kpad = 0, ntap = 1;
+	// decode path with the preceding LayerNorm folded in (fold_layernorm): fragment-order gamma o W, its column sums, b + beta W
+	void* wfrag_fold = nullptr;
+	float *csum = nullptr, *bias_fold = nullptr;
 };
 // layout: PK_NK / PK_KN / PK_CONV3 ; N, K are the logical sizes checked against the tensor
 int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, int layout,
 			   int N, int K, bool frag, Mat* out, int ntap = 0);   // ntap: kernel size for PK_CONVK / PK_CONVT
 
+// For a PK_KN matrix uploaded with a fragment copy: build the folded-LayerNorm operands of the decode launch (see SkinnyParams.g1) from the
+// LayerNorm's gamma / beta.  Not available for fp8 weights (the fold would change what gets rounded).
+int fold_layernorm(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, const std::string& gname,
+				   const std::string& betaname, Mat* m);
+
 // sample.hip: the fused per-token sampling launch; emb / pos / x_out non-null = also write the next decode step's input rows
-int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* pos, float* x_out, int d, int pos_rows, hipStream_t stream, const char* who);
+int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* pos, float* x_out, int d, int pos_rows, void* x_frag, int x_frag_f32,
+					   hipStream_t stream, const char* who);
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

@@ -69,6 +69,42 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 	return TTK_OK;
 }
 
+int fold_layernorm(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, const std::string& gname,
+				   const std::string& betaname, Mat* m) {
+	TTK_REQUIRE(!m->w8 && m->wfrag && m->ntap == 1, TTK_E_ARG, "fold_layernorm('%s'): needs a plain fragment-order matrix", wname.c_str());
+	const ttk_weight_view *vw = wm.find(wname), *vb = wm.find(bname), *vg = wm.find(gname), *vbe = wm.find(betaname);
+	TTK_REQUIRE(vw && vb && vg && vbe, TTK_E_WEIGHT, "fold_layernorm: missing one of '%s', '%s', '%s', '%s'", wname.c_str(), bname.c_str(), gname.c_str(), betaname.c_str());
+	const int N = m->N, K = m->K;
+	TTK_REQUIRE(numel(vw) == (int64_t)N * K && numel(vb) == N && numel(vg) == K && numel(vbe) == K, TTK_E_WEIGHT, "fold_layernorm('%s'): shape mismatch", wname.c_str());
+	const size_t es = dtype_size(dt);
+	float *w = nullptr, *g = nullptr, *be = nullptr, *b = nullptr;
+	void* wt = nullptr;
+	auto cleanup = [&]() { for (void* p : {(void*)w, (void*)g, (void*)be, (void*)b, wt}) if (p) (void)hipFree(p); };
+	hipError_t e = hipMalloc((void**)&w, (size_t)N * K * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&g, (size_t)K * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&be, (size_t)K * 4);
+	if (e == hipSuccess) e = hipMalloc((void**)&b, (size_t)N * 4);
+	if (e == hipSuccess) e = hipMalloc(&wt, (size_t)m->Npad * m->Kpad * es);
+	if (e == hipSuccess) e = hipMemcpy(w, vw->data, (size_t)N * K * 4, hipMemcpyDefault);
+	if (e == hipSuccess) e = hipMemcpy(g, vg->data, (size_t)K * 4, hipMemcpyDefault);
+	if (e == hipSuccess) e = hipMemcpy(be, vbe->data, (size_t)K * 4, hipMemcpyDefault);
+	if (e == hipSuccess) e = hipMemcpy(b, vb->data, (size_t)N * 4, hipMemcpyDefault);
+	if (e != hipSuccess) { cleanup(); set_error("fold_layernorm('%s'): %s", wname.c_str(), hipGetErrorString(e)); return TTK_E_HIP; }
+	int rc = ar.alloc(&m->wfrag_fold, (size_t)m->Npad * m->Kpad * es);
+	if (rc == TTK_OK) rc = ar.alloc((void**)&m->csum, (size_t)N * 4);
+	if (rc == TTK_OK) rc = ar.alloc((void**)&m->bias_fold, (size_t)N * 4);
+	if (rc != TTK_OK) { cleanup(); return rc; }
+	launch_bias_fold(w, be, b, K, N, m->bias_fold, 0);               // from the unscaled weights
+	launch_scale_kn(w, g, K, N, 0);
+	launch_pack_nk(dt, w, PK_KN, N, K, m->Npad, m->Kpad, wt, 0, 1);
+	launch_pack_frag(dt, wt, m->Npad, m->Kpad, m->wfrag_fold, 0);
+	launch_rowsum(dt, wt, m->Kpad, N, K, m->csum, 0);
+	e = hipDeviceSynchronize();
+	cleanup();
+	if (e != hipSuccess) { set_error("fold_layernorm('%s'): %s", wname.c_str(), hipGetErrorString(e)); return TTK_E_HIP; }
+	return TTK_OK;
+}
+
 bool g_prof_on = false;
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double work; };

@@ -79,12 +79,16 @@ struct SkinnyParams {
 	// A source: LN mode (ln_count 1|2) reads f32 rows and normalises; plain mode reads T rows
 	int ln_count;
 	const float* x;  int64_t ldx;
+	// LN mode: the affine parameters.  Plain mode with g1 != null = "folded LayerNorm": A holds the UN-normalised rows, Wp = gamma o W, g1 =
+	// colsum of the T-typed Wp, bias = b + beta W; the epilogue computes (acc - mean * g1[n]) * rstd + bias from the rows' statistics,
+	// which the waves gather from the A fragments they multiply anyway (needs a_frag, no narrow / ksplit)
 	const float *g1, *b1, *g2, *b2;
 	float* ln_out;              // optional f32 [M][K]: the normalised rows (block 0 writes), else null
 	const void* a;   int64_t lda;
 	int mode, act;
 	float* out_f32;  int64_t ldc;   // SK_STORE_F32 / SK_RESIDUAL (in place +=)
-	void* out_T;                    // SK_ACT_T, [M][N]
+	void* out_T;                    // SK_ACT_T, [M][N]; SK_RESIDUAL (optional): a T-typed copy of the updated rows in A-fragment order
+	                                // [m_tile][N/32][lane][8], the operand of the folded-LayerNorm launch that follows
 	// SK_QKV: n in [0,3d): q -> qbuf[m][n] f32 (pre-scaled), k/v -> cache[m][h][*pos][64]
 	float* qbuf; void* kcache; void* vcache; const int* d_pos; int max_ctx, H; float q_scale;
 	// optional split-K over workgroups: slab f32 [n_tiles][ksplit][MT][256], tickets int [n_tiles] (zero between launches)
@@ -103,9 +107,9 @@ struct SkinnyParams {
 void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s);
 
 // ---------------------------------------------------------------- norms (norm.hip)
-// y = LN2?(LN1(x)) per row; out is T or f32
+// y = LN2?(LN1(x)) per row; out is T or f32; frag: out in the skinny GEMV's A-fragment order instead of row-major; out2 (optional): also f32 [rows][d]
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
-					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s);
+					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s, int frag = 0, float* out2 = nullptr);
 // GroupNorm32 over channels-last x f32 [nb][T][C], 32 groups: per-chunk statistics part[nb][32][nchunks][3] = (count, mean, M2)
 int gn_num_chunks(int T, int C);
 void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStream_t s);
@@ -144,6 +148,9 @@ struct AttnDecodeParams {
 	int ctx_hint;             // host-side copy of the key count (profiling only; stale under graph replay)
 	void* out;                // T [B][H*64], or (out_frag) MFMA-fragment order [m_tile][H*2][lane][8] for the projection that follows
 	int out_frag;
+	int shared_rows;          // cache rows [0, shared_rows) are identical for every candidate (one conditioning latent + one text line: the
+	                          // prefill computed the same prefix B times): read them from candidate 0's slice, which the 16 workgroups of a head
+	                          // -- equal blockIdx.x, so one XCD -- then share in L2 instead of fetching B copies from HBM
 };
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s);
 
@@ -157,7 +164,7 @@ void launch_add_int(int* p, int v, hipStream_t s);
 void launch_gather_add(const float* A, const int* ia, const float* Bt, const int* ib, float* out, int rows, int d, hipStream_t s);
 // decode-time embedding: out[b] = mel_emb[tok[b]] + mel_pos[*d_pos - pos_bias]
 void launch_decode_embed(const float* emb, const int64_t* tok, const float* pos, const int* d_pos, int pos_off, int pos_rows,
-						 float* out, int B, int d, hipStream_t s);
+						 float* out, int B, int d, hipStream_t s, void* frag = nullptr, int frag_f32 = 0);
 void launch_copy_rows(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int d, hipStream_t s);
 void launch_cast(int dt, const float* src, void* dst, int64_t n, hipStream_t s);
 // [nb][C][T] f32  ->  [rep*nb*T][ldo] T, zero padded to ldo columns; the nb*T block is written `rep` times
@@ -191,5 +198,9 @@ float fp8_scale_for(float absmax);
 void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad, int Kpad, void* dst, hipStream_t s, int ntap = 0);
 // T [Npad][K] -> fragment order [Npad/16][K/32][64][8]
 void launch_pack_frag(int dt, const void* src, int Npad, int K, void* dst, hipStream_t s);
+// LayerNorm folded into a decode GEMV (pack.hip): w[k][n] *= gamma[k]; csum[n] = sum_k T-typed w[n][k]; bias'[n] = b[n] + sum_k beta[k] w[k][n]
+void launch_scale_kn(float* w, const float* gamma, int K, int N, hipStream_t s);
+void launch_rowsum(int dt, const void* w, int64_t ld, int N, int K, float* out, hipStream_t s);
+void launch_bias_fold(const float* w, const float* beta, const float* b, int K, int N, float* out, hipStream_t s);
 
 }  // namespace ttk
