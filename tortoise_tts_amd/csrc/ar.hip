@@ -93,7 +93,12 @@ struct ttk_ar {
 	int head_split = 1;     // decode head as LayerNorm launch + plain GEMV (TTK_AR_HEAD_SPLIT=0: norms inside the GEMV)
 	int lnfold = 1;         // ln_1 + c_attn and ln_2 + c_fc of the decode step with the LayerNorm folded into the matrix (TTK_AR_LNFOLD=0: LN prologue)
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
-	int wv_proj = 8, wv_proj2 = 16;   // waves per workgroup of the two plain decode GEMVs (TTK_AR_WV_PROJ / TTK_AR_WV_PROJ2)
+	// Waves per workgroup of the decode GEMVs that read their rows in fragment order (TTK_AR_WV_PROJ / _PROJ2 / _LN).  A wave requests its
+	// operands in batches of 8 k-steps (bf16; 4 in f32), so K / 32 / waves should be a multiple of that: with 8 waves on K = 1024 every wave
+	// owned 4 k-steps and half of its 16 load instructions re-read the last fragment -- on a path that is bound by what a CU can take in.
+	// More than 8 waves lose again (16 partial tiles to merge through LDS): 4 / 4 / 8 measured best in the 250-token loop (bf16, B = 16).
+	int wv_proj = 4, wv_proj2 = 8;
+	int wv_ln = 4;                    // ln_1 + c_attn and ln_2 + c_fc with the LayerNorm folded in; the LN-prologue form (fp8 weights) keeps 8
 	int wv_head = 4;                  // waves per workgroup of the ln_f + final_norm + mel_head launch (TTK_AR_WV_HEAD): 513 n-tiles; with 8-wave
 	                                  // workgroups two fit a CU (512 slots), so tile 513 ran as a second round on an empty chip; 4-wave ones fit four
 	int hfrag = 1;                // MLP activations of the decode step in MFMA-fragment order (TTK_AR_HFRAG=0: row-major)
@@ -171,7 +176,8 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	char* attn_out = (char*)h->attn_out + (size_t)r0 * d * es;
 	char* hbuf = (char*)h->hbuf + (size_t)r0 * 4 * d * es;
 	const size_t kv_row = (size_t)H * c.max_ctx * 64 * es;
-	const int wv_small = d >= 1024 ? 8 : 4;   // waves per workgroup that split K = d
+	const int wv_small = d >= 1024 ? h->wv_ln : 4;   // waves per workgroup that split K = d (folded LayerNorm: plain operand path)
+	const int wv_prologue = d >= 1024 ? 8 : 4;       // LayerNorm prologue form: 8 waves x 2 rows normalise the 16 candidates in one pass
 	const bool whole = r0 == 0 && nrows == h->B;      // fragment-order activations exist for the whole batch only
 	void* xf = whole ? h->x_frag : nullptr;
 	for (int l = 0; l < c.layers; ++l) {
@@ -180,10 +186,11 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
 		SkinnyParams p = {};
 		p.Wp = L.attn.wfrag; p.w8 = L.attn.w8; p.wscale = L.attn.wscale; p.N = 3 * d; p.K = d; p.M = nrows; p.bias = L.attn.bias;
-		if (h->lnfold && whole && L.attn.wfrag_fold) { p.Wp = L.attn.wfrag_fold; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
+		const bool fold_qkv = h->lnfold && whole && L.attn.wfrag_fold;
+		if (fold_qkv) { p.Wp = L.attn.wfrag_fold; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b; }
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
-		launch_skinny(dt, p, wv_small, s);
+		launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
 		AttnDecodeParams a = {};
 		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 ? h->shared_rows : 0;
 		launch_attn_decode(dt, a, s);
@@ -193,10 +200,11 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		launch_skinny(dt, p, d >= 1024 ? h->wv_proj : 4, s);
 		p = {};
 		p.Wp = L.fc.wfrag; p.w8 = L.fc.w8; p.wscale = L.fc.wscale; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
-		if (h->lnfold && whole && L.fc.wfrag_fold) { p.Wp = L.fc.wfrag_fold; p.bias = L.fc.bias_fold; p.g1 = L.fc.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
+		const bool fold_fc = h->lnfold && whole && L.fc.wfrag_fold;
+		if (fold_fc) { p.Wp = L.fc.wfrag_fold; p.bias = L.fc.bias_fold; p.g1 = L.fc.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b; }
 		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf; p.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
-		launch_skinny(dt, p, wv_small, s);
+		launch_skinny(dt, p, fold_fc ? wv_small : wv_prologue, s);
 		p = {};
 		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.out_T = h->lnfold ? xf : nullptr;
@@ -299,8 +307,10 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 		const char* e1 = getenv("TTK_AR_WV_PROJ");
 		const char* e2 = getenv("TTK_AR_WV_PROJ2");
 		if (e1 && atoi(e1) >= 4 && atoi(e1) <= 16) h->wv_proj = atoi(e1);
-		h->wv_proj2 = h->narrow2 ? 16 : 8;
+		if (h->dt == DT_F32) { h->wv_proj = 8; h->wv_ln = 8; h->wv_proj2 = 8; }      // batches of 4 k-steps: 32 / 4 = 8 waves; K = 4096: 4 batches each
 		if (e2 && atoi(e2) >= 4 && atoi(e2) <= 16) h->wv_proj2 = atoi(e2);
+		const char* e4 = getenv("TTK_AR_WV_LN");
+		if (e4 && atoi(e4) >= 4 && atoi(e4) <= 16) h->wv_ln = atoi(e4);
 		const char* e3 = getenv("TTK_AR_WV_HEAD");
 		if (e3 && (atoi(e3) == 4 || atoi(e3) == 8)) h->wv_head = atoi(e3);
 		const char* es = getenv("TTK_AR_SHARE_PREFIX");

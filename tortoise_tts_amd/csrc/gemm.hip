@@ -182,7 +182,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 		const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
 		tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
 	}
-	const int m0 = (tile_id % tiles_m) * BM, n0 = (tile_id / tiles_m) * BN;
+	// p.m_major: the XCD's run of tiles is a few m-tiles x ALL n-tiles instead -- its L2 then holds the whole weight matrix plus an eighth of
+	// the activations, which is the smaller working set when the matrix (N x K) is smaller than the activation panel (M x K)
+	const int tiles_n = (p.N + BN - 1) / BN;
+	const int m0 = p.m_major ? (tile_id / tiles_n) * BM : (tile_id % tiles_m) * BM;
+	const int n0 = p.m_major ? (tile_id % tiles_n) * BN : (tile_id / tiles_m) * BN;
 	const int KT = p.K / BKE;
 	const int NTILES = p.nseg * KT;
 
@@ -397,7 +401,12 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 	else launch_tile<T, 64, 64, 2, 2, 3>(p, s, ea, eb);
 }
 
-void launch_gemm(int dt, const GemmParams& p, hipStream_t s) {
+void launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
+	static const int order = [] { const char* e = getenv("TTK_GEMM_ORDER"); return e ? atoi(e) : 0; }();   // tuning knob, see GemmParams.m_major
+	GemmParams p = p_in;
+	if (order == 1) p.m_major = p.nseg == 1 && (int64_t)p.N < p.M;
+	else if (order == 2) p.m_major = (int64_t)p.N * p.nseg < p.M;
+	else if (order == 3) p.m_major = 1;
 	hipEvent_t ea = nullptr, eb = nullptr;      // kernel start / stop timestamps when profiling (prof_pair)
 	if (g_prof_on) prof_pair(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, &ea, &eb);
 	if (dt == DT_FP8) launch_gemm_t<f8>(p, s, ea, eb);          // A and W are fp8-e4m3 bytes, K % 128 == 0

@@ -62,6 +62,7 @@ struct GemmParams {
 	int transpose_out;  // C is f32 [M / rows_per_batch][N][rows_per_batch]
 	// optional fused GroupNorm32 statistics of the f32 output (see gemm_fuses_gn_stats): part[b][32][gn_T / 64][3]
 	float* gn_part; int gn_T;
+	int m_major;        // XCD-aware tile order: 0 = each XCD gets a few n-tiles x all m-tiles (its L2 keeps a weight slice), 1 = a few m-tiles x all n-tiles
 };
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s);
 // true when launch_gemm(M, N) picks a 128-row tile, i.e. each wave owns 64 rows x one or two whole 32-channel groups and can emit
