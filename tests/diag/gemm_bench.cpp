@@ -15,7 +15,45 @@ __global__ void fill(unsigned short* p, size_t n, unsigned seed) {
 	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) { unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 13; h *= 0x5bd1e995; p[i] = (unsigned short)(0x3c00 + (h & 0x3ff) - ((h >> 10) & 1) * 0x8000); }   // ~[-2, 2) bf16 bit patterns
 }
+// producer stand-in for the kernel that writes a GEMM's A operand right before it (GroupNorm-apply): rows of A re-written by workgroups whose
+// XCD (blockIdx % 8) either owns a contiguous eighth of the rows (aligned = 1: the eighth the m-major GEMM order reads on that XCD) or
+// is interleaved strip by strip (aligned = 0, what a plain blockIdx -> strip mapping gives)
+__global__ void produce_rows(unsigned short* A, int M, int K, int aligned, unsigned salt) {
+	const int strips = M / 2;                           // 2 rows per workgroup, like k_gn_apply at C = 1024
+	int strip = blockIdx.x;
+	if (aligned) { const int per = strips / 8; strip = (blockIdx.x % 8) * per + blockIdx.x / 8; if (blockIdx.x / 8 >= per) return; }
+	for (int i = threadIdx.x; i < 2 * K / 8; i += blockDim.x) {
+		uint4 v = make_uint4(0x3c003c00u + salt, 0x3c003c00u, 0xbc003c00u, 0x3c00bc00u);
+		*(uint4*)(A + (size_t)strip * 2 * K + (size_t)i * 8) = v;
+	}
+}
 int main(int argc, char** argv) {
+	if (argc > 3 && atoi(argv[3]) == 1) {
+		// affinity experiment: 1x1 conv shape, ONE A / W set (L2 / MALL resident as in the diffusion loop), A re-written before every GEMM
+		const int M = 2176, N = 1024, K = 1024;
+		char *A, *W; void* Cb; float* bias;
+		hipStream_t s; CK(hipStreamCreate(&s));
+		hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+		CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&W, (size_t)N * K * 2)); CK(hipMalloc(&Cb, (size_t)M * N * 2)); CK(hipMalloc(&bias, N * 4));
+		fill<<<(unsigned)(((size_t)N * K + 255) / 256), 256, 0, s>>>((unsigned short*)W, (size_t)N * K, 2);
+		CK(hipMemsetAsync(bias, 0, N * 4, s));
+		for (int aligned = 0; aligned < 2; ++aligned)
+			for (int order = 0; order < 2; ++order) {
+				GemmParams g = {};
+				g.nseg = 1; g.seg[0] = {A, K, 0, 0}; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.rows_per_batch = 1088; g.bias = bias; g.C = Cb; g.ldc = N; g.m_major = order;
+				g_force_tile = 101;
+				float tot = 0.f;
+				const int reps = 200;
+				for (int i = 0; i < reps + 10; ++i) {
+					produce_rows<<<M / 2, 256, 0, s>>>((unsigned short*)A, M, K, aligned, (unsigned)i & 1);
+					if (i >= 10) CK(hipEventRecord(e0, s));
+					launch_gemm(DT_BF16, g, s);
+					if (i >= 10) { CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms; }
+				}
+				printf("1x1 conv 2176x1024x1024, A just written by %s producer, GEMM tile order %s: %.2f us\n", aligned ? "an XCD-aligned" : "an interleaved", order ? "m-major" : "n-major", tot * 1e3 / reps);
+			}
+		return 0;
+	}
 	struct Shape { const char* name; int M, N, K, nseg, T, resid; } shapes[] = {
 		{"fixed-cost probe K=128 bf16 out", 2176, 1024, 128, 1, 1088, 0},
 		{"fixed-cost probe K=128 f32+res", 2176, 1024, 128, 1, 1088, 1},

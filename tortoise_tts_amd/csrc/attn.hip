@@ -56,8 +56,11 @@ template <> struct VT<float> {
 
 // QT = 16-query tiles per wave: 2 (128 queries per workgroup) when that still gives >= 2 waves per SIMD, else 1 (64 per
 // workgroup): a lone wave on a SIMD issues a wave64 VALU op every 4 cycles instead of 2 and cannot overlap its MFMAs.
-template <typename T, bool CAUSAL, bool BIAS, int QT>
-__global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
+// NWV = waves per workgroup (4 or 8), each owning 16 * QT queries: 8 x 16 = 128-query blocks halve the K / V bytes a CU takes in per query (every
+// workgroup streams all keys of its head through LDS; at T = 1088 that is 590 KB per CU and launch with 64-query blocks, against ~60 GB/s a
+// CU can pull from L2) and still leave two waves per SIMD to overlap one wave's softmax VALU work with the other's MFMAs.
+template <typename T, bool CAUSAL, bool BIAS, int QT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnParams p) {
 	typedef typename Frag<T>::type FragT;
 	constexpr int ES = sizeof(T);
 	constexpr int ROWB = HD * ES;             // LDS row bytes (128 bf16 / 256 f32)
@@ -65,23 +68,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
 	constexpr int SWM = NCH - 1;              // swizzle mask on the row index
 	constexpr int FCH = 8 * ES / 16;          // chunks per fragment
 	constexpr int TILE_CH = 64 * NCH;         // chunks per K (or V) tile
-	constexpr int CPT = TILE_CH / 256;        // chunks per thread (2 / 4)
+	constexpr int NTH = 64 * NWV;
+	constexpr int CPT = TILE_CH / NTH;        // chunks per thread (bf16 / f32: 2 / 4 with 4 waves, 1 / 2 with 8)
 	__shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
 	__shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
 	__shared__ float bias_s[132];
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int h = blockIdx.y, b = blockIdx.z;
-	constexpr int QW = 16 * QT, QB = 4 * QW;          // queries per wave / per workgroup
+	constexpr int QW = 16 * QT, QB = NWV * QW;        // queries per wave / per workgroup
 	const int q0 = blockIdx.x * QB + wave * QW;       // first query row of this wave
 	const int li = lane & 15, g = lane >> 4;
 	const T* base = (const T*)p.qkv + (int64_t)b * p.T * p.ld;
 	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
 
-	__shared__ unsigned pf_sink[64 * 4];
+	__shared__ unsigned pf_sink[64 * NWV];
 	if (p.pf) {   // the following projection's weights into L2; workgroups are numbered x-fastest over the (query block, head, batch) grid
 		const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-		l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (threadIdx.x >> 6) * 256), lin, gridDim.x * gridDim.y * gridDim.z, threadIdx.x, 256);
+		l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (threadIdx.x >> 6) * 256), lin, gridDim.x * gridDim.y * gridDim.z, threadIdx.x, NTH);
 	}
 	if (BIAS) {
 		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid] * LOG2E;   // scores live in the log2 domain (exp2 = one v_exp_f32)
@@ -114,9 +118,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
 
 	// staging registers as named scalars (indexed arrays captured by the lambdas were placed in scratch memory)
 	uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
-	rk2 = rk3 = rv2 = rv3 = make_uint4(0, 0, 0, 0);
+	rk1 = rv1 = rk2 = rk3 = rv2 = rv3 = make_uint4(0, 0, 0, 0);
 	auto ld1 = [&](int kt, int i, uint4& k, uint4& v) {
-		const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
+		const int id = tid + NTH * i, row = id / NCH, c = id % NCH;
 		int key = kt * 64 + row;
 		key = key < p.T ? key : p.T - 1;
 		const T* src = base + (int64_t)key * p.ld + c * (16 / ES);
@@ -124,17 +128,19 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd(AttnParams p) {
 		v = *(const uint4*)(src + vc);
 	};
 	auto st1 = [&](int i, const uint4& k, const uint4& v) {
-		const int id = tid + 256 * i, row = id / NCH, c = id % NCH;
+		const int id = tid + NTH * i, row = id / NCH, c = id % NCH;
 		const int off = row * ROWB + ((c ^ (row & SWM)) << 4);
 		*(uint4*)(Ks + off) = k;
 		*(uint4*)(Vs + off) = v;
 	};
 	auto load_kv = [&](int kt) {
-		ld1(kt, 0, rk0, rv0); ld1(kt, 1, rk1, rv1);
+		ld1(kt, 0, rk0, rv0);
+		if (CPT > 1) ld1(kt, 1, rk1, rv1);
 		if (CPT > 2) { ld1(kt, 2, rk2, rv2); ld1(kt, 3, rk3, rv3); }
 	};
 	auto store_kv = [&]() {
-		st1(0, rk0, rv0); st1(1, rk1, rv1);
+		st1(0, rk0, rv0);
+		if (CPT > 1) st1(1, rk1, rv1);
 		if (CPT > 2) { st1(2, rk2, rv2); st1(3, rk3, rv3); }
 	};
 
@@ -283,6 +289,17 @@ template <typename T>
 static void launch_attn_fwd_t(const AttnParams& p, hipStream_t s) {
 	static const int force_qt = [] { const char* e = getenv("TTK_ATTN_QT"); return e ? atoi(e) : 0; }();   // tuning knob
 	const bool big = force_qt ? force_qt == 2 : (int64_t)((p.T + 127) / 128) * p.H * p.nb >= 512;   // enough 128-query blocks for 2 waves per SIMD
+	// 128-query blocks as 8 waves x 16 queries once they cover most of the chip (TTK_ATTN_W8=0: off); non-causal only: a causal block of 8 waves
+	// would idle its upper waves on the diagonal tiles
+	// (measured at T = 1088: 141.3 vs 139.9 ms per DDIM loop -- 288 such blocks on 256 CUs leave 32 CUs with two, the same quantisation that
+	// costs the 64-query form 544 blocks on 768 slots; kept as a knob, off by default)
+	static const int w8 = [] { const char* e = getenv("TTK_ATTN_W8"); return e ? atoi(e) : 0; }();
+	if (w8 && !big && !force_qt && !p.causal && (int64_t)((p.T + 127) / 128) * p.H * p.nb >= 192) {
+		dim3 grid((p.T + 127) / 128, p.H, p.nb);
+		if (p.bias) hipLaunchKernelGGL((k_attn_fwd<T, false, true, 1, 8>), grid, dim3(512), 0, s, p);
+		else hipLaunchKernelGGL((k_attn_fwd<T, false, false, 1, 8>), grid, dim3(512), 0, s, p);
+		return;
+	}
 	if (big) {
 		dim3 grid((p.T + 127) / 128, p.H, p.nb);
 		if (p.causal) hipLaunchKernelGGL((k_attn_fwd<T, true, false, 2>), grid, dim3(256), 0, s, p);

@@ -214,6 +214,7 @@ void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
 	const int rows = p.nb * p.Tout * (p.C / 4) / 256;
 	if (passes >= 8 && rows >= 8 * 256) launch_gn_apply_p<8>(dt, p, s);
 	else if (passes >= 4 && rows >= 4 * 256) launch_gn_apply_p<4>(dt, p, s);
+	else if (passes == 1) launch_gn_apply_p<1>(dt, p, s);
 	else launch_gn_apply_p<2>(dt, p, s);
 }
 
