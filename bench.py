@@ -46,6 +46,7 @@ def parse():
 	ap.add_argument("--no-cpu-baseline", action="store_true")
 	ap.add_argument("--no-roofline", action="store_true")
 	ap.add_argument("--small", action="store_true", help="tiny models (plumbing check only; the number is NOT the metric)")
+	ap.add_argument("--no-graph", action="store_true", help="eager token loop (counter passes under rocprofv3 --pmc, which crashes on captured graphs); never the timed configuration")
 	ap.add_argument("--shard", default="utterances", choices=["utterances", "candidates"],
 					help="utterances: configs[1]/[2], one utterance per GPU (the headline metric); candidates: configs[3], one utterance's candidates over the GPUs")
 	return ap.parse_args()
@@ -199,6 +200,8 @@ def main():
 		dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))      # the sharded entry runs on a group of any size
 	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(ar_cfg), 0), ar_cfg, dtype=a.dtype, device=dev, max_batch=n_cand,
 					  max_ctx=n_text + 4 + n_mel + 8)
+	if a.no_graph:
+		ar.use_graph = False
 	df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(df_cfg), 0), df_cfg, dtype=a.dtype, device=dev)
 	voc = None
 	if a.with_vocoder:

@@ -355,17 +355,22 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
 	const int S = Tt + 4, d = c.model_dim;
 	TTK_REQUIRE(S + 1 <= c.max_ctx, TTK_E_ARG, "ttk_ar_prefill: prefix of %d rows does not fit max_ctx=%d", S, c.max_ctx);
 	hipStream_t s = (hipStream_t)stream;
-	TTK_TRY(h->ws_x.reserve((size_t)B * S * d * sizeof(float)));
+	// One conditioning latent and one text line for all B candidates (what inference_speech passes): the B prefixes are the same rows, so
+	// the prefix is run ONCE and its cache rows live in candidate 0's slice only -- the decode attention reads rows [0, S) there for every
+	// candidate (AttnDecodeParams.shared_rows) -- and the last row / the logits are replicated.
+	const bool shared = Bc == 1 && B > 1 && h->share_prefix && h->nsplit == 1;
+	const int Bp = shared ? 1 : B;
+	TTK_TRY(h->ws_x.reserve((size_t)Bp * S * d * sizeof(float)));
 	float* x = (float*)h->ws_x.p;
-	const int64_t total = (int64_t)B * S * (d / 4);
-	hipLaunchKernelGGL(k_build_prefill_emb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cond_latent, Bc, text, Tt, B, d,
+	const int64_t total = (int64_t)Bp * S * (d / 4);
+	hipLaunchKernelGGL(k_build_prefill_emb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cond_latent, Bc, text, Tt, Bp, d,
 					   h->text_emb, h->text_pos, h->mel_emb, h->mel_pos, c.start_text_token, c.stop_text_token, c.start_mel_token, x);
-	TTK_TRY(dense_forward(h, x, B, S, true, s));
-	launch_copy_rows(x + (size_t)(S - 1) * d, (int64_t)S * d, h->x, d, B, d, s);
+	TTK_TRY(dense_forward(h, x, Bp, S, true, s));
+	launch_copy_rows(x + (size_t)(S - 1) * d, shared ? 0 : (int64_t)S * d, h->x, d, B, d, s);      // source stride 0: one row to all candidates
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, S, s);
 	h->B = B; h->P = Tt + 3; h->k = 0; h->ready = 1;
-	h->shared_rows = (Bc == 1 && B > 1 && h->share_prefix) ? S : 0;      // one latent, one text line: all B prefixes are the same rows
+	h->shared_rows = shared ? S : 0;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }
