@@ -135,6 +135,18 @@ int ttk_sample_step_warped(const ttk_sample_args* a, void* stream);
 int ttk_ar_sample_next(ttk_ar* h, const ttk_sample_args* a, void* stream);
 int ttk_ar_decode_next(ttk_ar* h, float* logits_out, float* hidden_out, void* stream);
 
+/* The Exp(1) noise of torch.multinomial without torch in the token step.  `q.exponential_(1)` on the GPU is a pure function of (generator seed,
+ * generator offset, element index, launch geometry) -- ATen's distribution_nullary_kernel over a Philox4_32_10 state (csrc/ttk_rng.h restates
+ * the indexing; the state and the uniform conversion are rocRAND's own header code, as in torch's build).  ttk_ar_set_noise makes the mel-head
+ * launch of ttk_ar_prefill / ttk_ar_decode[_next] write q[m][n] for its logits: rng_args = device int64[5] {seed, offset before the first draw,
+ * threads of torch's launch for the full [C, V] tensor, offset step per draw, first row of this handle's candidates in that tensor}, draws =
+ * device int64[B] draws made so far per row (the `col` of ttk_sample_args), q = f32 rows [B][V].  The caller advances the torch generator by
+ * step x draws afterwards, so everything drawn later is the reference's stream too.  Pass NULLs to switch it off.
+ * ttk_exponential_like_torch fills out[li] for li < numel with the same function (draw-th draw): the bitwise comparison against
+ * torch.Tensor.exponential_ that a caller runs before relying on it (tortoise_tts_amd/autoregressive.py does).                          */
+int ttk_ar_set_noise(ttk_ar* h, const int64_t* rng_args, const int64_t* draws, float* q);
+int ttk_exponential_like_torch(float* out, int64_t numel, int64_t seed, int64_t offset0, int64_t threads, int64_t step, int64_t draw, void* stream);
+
 /* The weight rounding of TTK_FP8W applied in place to a device f32 array: x <- fp8_e4m3(x / s) * s with s = the smallest power of
  * two >= max|x| / 448, returned in *scale_out (host).  This is exactly what ttk_*_create does to a TTK_FP8W matrix, exposed so that a
  * caller (and the parity tests) can build the equivalent TTK_BF16 model.                                                     */

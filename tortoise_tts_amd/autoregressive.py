@@ -15,6 +15,7 @@ What runs where
 from __future__ import annotations
 
 import dataclasses
+import os
 from typing import Dict, Iterator, Optional, Tuple
 
 import torch
@@ -210,83 +211,97 @@ class UnifiedVoice:
 			gen = torch.cuda.default_generators[self.device.index or 0]
 			off_start = gen.get_offset()
 			st.reset(c)
-			st.logits.copy_(self._prefill(cond, text, B))
-			n = 0
-			if not (self.use_graph and st.graphable):
-				while True:
-					st.sample(n)
-					n += 1
-					if n >= max_new or (can_stop and int(st.unfinished.max()) == 0):
-						break
-					self._decode_next(st.logits)
-			else:
-				# tokens 1 and 2 eagerly (the second pass also warms every kernel before a capture), then one HIP-graph
-				# replay per token: {ttk_ar_decode_next; [typical warper]; exponential_; ttk_ar_sample_next}.  Every position-dependent
-				# quantity (cache length, mel position, output column, length of the token history the repetition penalty reads) lives in
-				# device memory, so ONE graph serves all tokens and every text length.
-				# HF's stopping test (`unfinished_sequences.max() == 0` after every token, a host round trip that idles the GPU)
-				# becomes a flag the sampling kernel raises in pinned memory; the host looks at it LAG replays late, so the GPU
-				# always has work queued.  The <= LAG tokens generated past the true end are all padding; they are cut off below
-				# and the generator offset they consumed is handed back, so ids AND the RNG stream equal the reference's.
-				LAG = 2
-				st.sample(0)
-				if st.rng_step is None:
-					st.rng_step = gen.get_offset() - off_start
-				n = 1
-				events = []
-				stopped = can_stop and int(st.unfinished.max()) == 0
-				while n < max_new and not stopped:
-					if st.graph is None:
-						self._decode_next(st.logits)
-						st.sample(n)
-						n += 1
-						stopped = can_stop and int(st.unfinished.max()) == 0
-						if n < max_new and not stopped:
-							torch.cuda.synchronize(self.device)
-							g = torch.cuda.CUDAGraph()
-							# thread-local capture mode: another host thread may be enqueuing (and allocating for) the previous
-							# line's diffusion meanwhile (TTSHotPath.inference_lines); in the default global mode its hipMalloc /
-							# hipFree would invalidate this capture.
-							# capture_begin / capture_end run OUTSIDE inference mode whatever the caller's mode: torch creates the
-							# generator's graph-side seed / offset tensors at the first capture and updates them in place at every
-							# later capture and replay -- created under inference_mode they would make any later capture from a
-							# caller without it fail ("inplace update to inference tensor outside InferenceMode").
-							ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
-							with torch.inference_mode(False):
-								ctx.__enter__()
-							try:
-								self._decode_next(st.logits)
-								st.sample(0)
-							except BaseException:
-								with torch.inference_mode(False):
-									ctx.__exit__(*__import__("sys").exc_info())
-								raise
-							with torch.inference_mode(False):
-								ctx.__exit__(None, None, None)
-							st.graph = g
-						continue
-					st.graph.replay()
-					n += 1
-					if can_stop:
-						ev = torch.cuda.Event()
-						ev.record()
-						events.append(ev)
-						if len(events) > LAG:
-							events.pop(0).synchronize()          # the replay LAG tokens back is complete: its flag is visible
-							stopped = int(st.done[0]) != 0
-				if can_stop:
-					# exact end: HF stops right after the token with which the last row finishes
-					torch.cuda.synchronize(self.device)
-					ids = st.ids[:, :n]
-					is_stop = ids == c.stop_mel_token
-					if bool(is_stop.any(dim=1).all()):
-						n_true = int(is_stop.float().argmax(dim=1).max()) + 1
-						if n_true < n:
-							gen.set_offset(gen.get_offset() - (n - n_true) * st.rng_step)
-							n = n_true
+			if st.own_rng:
+				st.arm_noise(gen, lo)
+			try:
+				n = self._token_loop(st, gen, off_start, cond, text, B, max_new, can_stop)
+			finally:
+				if st.own_rng:
+					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
+			if st.own_rng:
+				gen.set_offset(off_start + n * st.noise_step)        # what n torch draws would have consumed
 			# what the sampling consumed from the generator: dist.py aligns a shard's stream with the unsharded run's from this
 			self.last_generate = dict(steps=n, rng_start=off_start, rng_step=(gen.get_offset() - off_start) // max(n, 1))
 			return st.ids[:, :n].clone(), None
+
+	def _token_loop(self, st, gen, off_start, cond, text, B, max_new, can_stop):
+		c = self.cfg
+		st.logits.copy_(self._prefill(cond, text, B))
+		n = 0
+		if not (self.use_graph and st.graphable):
+			while True:
+				st.sample(n)
+				n += 1
+				if n >= max_new or (can_stop and int(st.unfinished.max()) == 0):
+					break
+				self._decode_next(st.logits)
+		else:
+			# tokens 1 and 2 eagerly (the second pass also warms every kernel before a capture), then one HIP-graph
+			# replay per token: {ttk_ar_decode_next; [typical warper]; exponential_; ttk_ar_sample_next}.  Every position-dependent
+			# quantity (cache length, mel position, output column, length of the token history the repetition penalty reads) lives in
+			# device memory, so ONE graph serves all tokens and every text length.
+			# HF's stopping test (`unfinished_sequences.max() == 0` after every token, a host round trip that idles the GPU)
+			# becomes a flag the sampling kernel raises in pinned memory; the host looks at it LAG replays late, so the GPU
+			# always has work queued.  The <= LAG tokens generated past the true end are all padding; they are cut off below
+			# and the generator offset they consumed is handed back, so ids AND the RNG stream equal the reference's.
+			LAG = 2
+			st.sample(0)
+			if st.rng_step is None:
+				st.rng_step = gen.get_offset() - off_start
+			n = 1
+			events = []
+			stopped = can_stop and int(st.unfinished.max()) == 0
+			while n < max_new and not stopped:
+				if st.graph is None:
+					self._decode_next(st.logits)
+					st.sample(n)
+					n += 1
+					stopped = can_stop and int(st.unfinished.max()) == 0
+					if n < max_new and not stopped:
+						torch.cuda.synchronize(self.device)
+						g = torch.cuda.CUDAGraph()
+						# thread-local capture mode: another host thread may be enqueuing (and allocating for) the previous
+						# line's diffusion meanwhile (TTSHotPath.inference_lines); in the default global mode its hipMalloc /
+						# hipFree would invalidate this capture.
+						# capture_begin / capture_end run OUTSIDE inference mode whatever the caller's mode: torch creates the
+						# generator's graph-side seed / offset tensors at the first capture and updates them in place at every
+						# later capture and replay -- created under inference_mode they would make any later capture from a
+						# caller without it fail ("inplace update to inference tensor outside InferenceMode").
+						ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
+						with torch.inference_mode(False):
+							ctx.__enter__()
+						try:
+							self._decode_next(st.logits)
+							st.sample(0)
+						except BaseException:
+							with torch.inference_mode(False):
+								ctx.__exit__(*__import__("sys").exc_info())
+							raise
+						with torch.inference_mode(False):
+							ctx.__exit__(None, None, None)
+						st.graph = g
+					continue
+				st.graph.replay()
+				n += 1
+				if can_stop:
+					ev = torch.cuda.Event()
+					ev.record()
+					events.append(ev)
+					if len(events) > LAG:
+						events.pop(0).synchronize()          # the replay LAG tokens back is complete: its flag is visible
+						stopped = int(st.done[0]) != 0
+			if can_stop:
+				# exact end: HF stops right after the token with which the last row finishes
+				torch.cuda.synchronize(self.device)
+				ids = st.ids[:, :n]
+				is_stop = ids == c.stop_mel_token
+				if bool(is_stop.any(dim=1).all()):
+					n_true = int(is_stop.float().argmax(dim=1).max()) + 1
+					if n_true < n:
+						if not st.own_rng:
+							gen.set_offset(gen.get_offset() - (n - n_true) * st.rng_step)
+						n = n_true
+		return n
 
 	def _gen_state(self, B, max_new, pipe_key, C=None, lo=0):
 		"""generation states (device buffers + the captured token step) keyed by what is baked into them; a few are kept so that
@@ -351,6 +366,10 @@ class _GenState:
 		self.live = torch.zeros(1, dtype=torch.int32, device=dev)        # unfinished rows, decremented on the device
 		self.done = torch.zeros(1, dtype=torch.int32).pin_memory()       # raised by the row that finishes last; polled by the host
 		self.rng_step = None                                             # generator offset consumed by one sample() call
+		# torch's `q.exponential_(1)` restated inside the mel-head launch (include/ttk.h: ttk_ar_set_noise) -- one launch per token less.
+		# Relied on only after a bitwise comparison with torch's own draw on this device, for this very shape (below).
+		self.rng = torch.zeros(5, dtype=torch.long, device=dev)          # RngArgs {seed, offset0, threads, step, row0}
+		self.own_rng = os.environ.get("TTK_AR_OWN_RNG", "1") != "0" and self._noise_matches_torch(model, dev)
 		# input_ids as the repetition penalty sees them: the fake prefix ids are all 1 with start_mel last (unified_voice.py:647-649),
 		# i.e. the SET {1, start_mel} whatever the text length (the penalty acts once per distinct id), then the sampled tokens
 		self.history = None
@@ -381,6 +400,44 @@ class _GenState:
 		self.args = a
 		self.graph = None
 
+	def _noise_geometry(self, dev):
+		"""(threads, offset step per draw) of ATen's launch for `self.q.exponential_()` (ATen/native/cuda/DistributionTemplates.h:
+		distribution_nullary_kernel -- 256-thread blocks, a grid capped at the resident blocks of the device, four values per Philox call)"""
+		props = torch.cuda.get_device_properties(dev)
+		numel = self.q.numel()
+		grid = min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+		threads = 256 * grid
+		return threads, ((numel - 1) // (threads * 4) + 1) * 4
+
+	def _noise_matches_torch(self, model, dev):
+		gen = torch.cuda.default_generators[dev.index or 0]
+		keep = gen.get_state()
+		try:
+			threads, step = self._noise_geometry(dev)
+			seed, off = gen.initial_seed(), gen.get_offset()
+			seed = seed - (1 << 64) if seed >= (1 << 63) else seed
+			want = [torch.empty_like(self.q).exponential_(1) for _ in range(2)]
+			if gen.get_offset() - off != 2 * step:
+				return False
+			got = torch.empty_like(self.q)
+			for draw in range(2):
+				_lib.check(model.lib.ttk_exponential_like_torch(got.data_ptr(), got.numel(), seed, off, threads, step, draw, _lib.stream_ptr()),
+						   "ttk_exponential_like_torch")
+				if not torch.equal(got.view(torch.int32), want[draw].view(torch.int32)):
+					return False
+			self.noise_threads, self.noise_step = threads, step
+			return True
+		finally:
+			gen.set_state(keep)
+
+	def arm_noise(self, gen, lo):
+		"""point the mel-head launches of this call at q, starting from the generator's current state"""
+		seed = gen.initial_seed()
+		seed = seed - (1 << 64) if seed >= (1 << 63) else seed
+		self.rng.copy_(torch.tensor([seed, gen.get_offset(), self.noise_threads, self.noise_step, lo], dtype=torch.long))
+		m = self.model
+		_lib.check(m.lib.ttk_ar_set_noise(m._h, self.rng.data_ptr(), self.col.data_ptr(), self.q[lo].data_ptr()), "ttk_ar_set_noise")
+
 	def reset(self, c):
 		self.ids.fill_(self.stop)
 		self.unfinished.fill_(1)
@@ -401,5 +458,7 @@ class _GenState:
 			self.scores = scores if scores.is_contiguous() else scores.contiguous()      # kept alive until the launch has run
 			a.scores, a.ld = self.scores.data_ptr(), self.scores.stride(0)
 		# multinomial(softmax(scores), 1) == argmax(softmax(scores) / q), q ~ Exp(1) from the torch generator (see sampling.multinomial1)
-		self.q.exponential_(1)
+		# (own_rng: the mel-head launch that produced self.logits has written q already)
+		if not self.own_rng:
+			self.q.exponential_(1)
 		_lib.check(self.model.lib.ttk_ar_sample_next(self.model._h, _lib.C.byref(a), _lib.stream_ptr()), "ttk_ar_sample_next")

@@ -90,6 +90,8 @@ struct ttk_ar {
 	void* x_frag = nullptr; // T copy of x in A-fragment order [m_tile][d/32][64][8]: operand of the folded-LayerNorm launches
 	int shared_rows = 0;    // leading cache rows that are identical for all candidates of the current generation (AttnDecodeParams.shared_rows)
 	int share_prefix = 1;   // TTK_AR_SHARE_PREFIX=0: every candidate reads its own copy
+	// multinomial noise drawn by the mel-head launch (ttk_ar_set_noise): device RngArgs, per-row draw counters, q rows of this handle's candidates
+	const int64_t* rng_args = nullptr; const int64_t* rng_draws = nullptr; float* rng_q = nullptr;
 	int head_split = 1;     // decode head as LayerNorm launch + plain GEMV (TTK_AR_HEAD_SPLIT=0: norms inside the GEMV)
 	int lnfold = 1;         // ln_1 + c_attn and ln_2 + c_fc of the decode step with the LayerNorm folded into the matrix (TTK_AR_LNFOLD=0: LN prologue)
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
@@ -162,6 +164,7 @@ static void head_launch(ttk_ar* h, int B, float* logits, float* hidden_out, hipS
 	p.ln_count = 2; p.x = h->x; p.ldx = h->cfg.model_dim;
 	p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hidden_out;
 	p.mode = SK_STORE_F32; p.out_f32 = logits; p.ldc = h->cfg.number_mel_codes;
+	if (h->rng_q) { p.qbuf = h->rng_q; p.slab = (float*)h->rng_args; p.tickets = (int*)h->rng_draws; }
 	launch_skinny(h->dt, p, h->cfg.model_dim >= 1024 ? h->wv_head : 4, s);
 }
 
@@ -192,7 +195,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
 		launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
 		AttnDecodeParams a = {};
-		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 ? h->shared_rows : 0;
+		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 && h->share_prefix && h->nsplit == 1;
 		launch_attn_decode(dt, a, s);
 		p = {};
 		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
@@ -220,6 +223,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	// the last launch of the step advances the cache length: every reader of *d_pos (c_attn epilogues, attention) is behind it on the
 	// stream, the next reader is the next step -- one 1-thread launch per token less (an otherwise unused field carries the pointer)
 	if (bump_pos) p.d_pos = h->d_pos;
+	if (h->rng_q) { p.qbuf = h->rng_q + (size_t)r0 * c.number_mel_codes; p.slab = (float*)h->rng_args; p.tickets = (int*)(h->rng_draws + r0); p.max_ctx = r0; }
 	float* hid = hidden_out ? hidden_out + (size_t)r0 * d : nullptr;
 	if (h->head_split && whole) {
 		// ln_f + final_norm ONCE (4 workgroups), the mel head as a plain 513-tile GEMV over the normalised rows in fragment order: with the
@@ -369,6 +373,7 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
 	launch_copy_rows(x + (size_t)(S - 1) * d, shared ? 0 : (int64_t)S * d, h->x, d, B, d, s);      // source stride 0: one row to all candidates
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, S, s);
+	launch_set_int(h->d_pos + 1, shared ? S : 0, s);      // rows of the shared prefix (AttnDecodeParams.shared_rows): device-resident, like the cache length
 	h->B = B; h->P = Tt + 3; h->k = 0; h->ready = 1;
 	h->shared_rows = shared ? S : 0;
 	TTK_HIP(hipGetLastError());
@@ -427,6 +432,13 @@ int ttk_ar_sample_next(ttk_ar* h, const ttk_sample_args* a, void* stream) {
 				a->B, a->V, h->B, h->cfg.number_mel_codes);
 	return launch_sample_step(a, h->mel_emb, h->mel_pos, h->x, h->cfg.model_dim, h->cfg.max_mel_seq_len, h->lnfold ? h->x_frag : nullptr, h->dt == DT_F32,
 							  (hipStream_t)stream, "ttk_ar_sample_next");
+}
+
+int ttk_ar_set_noise(ttk_ar* h, const int64_t* rng_args, const int64_t* draws, float* q) {
+	TTK_REQUIRE(h, TTK_E_ARG, "ttk_ar_set_noise: null handle");
+	TTK_REQUIRE((rng_args && draws && q) || (!rng_args && !draws && !q), TTK_E_ARG, "ttk_ar_set_noise: pass all three pointers or none");
+	h->rng_args = rng_args; h->rng_draws = draws; h->rng_q = q;
+	return TTK_OK;
 }
 
 int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream) {

@@ -344,7 +344,10 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 #ifdef TTK_ABL      // diagnostic builds only (tests/diag/ar_ablate.sh): 256 = the whole kernel, 128 = the K / V loads
 	if (TTK_ABL & 256) return;
 #endif
-	const int n = min(*p.d_pos + 1, p.max_ctx);
+	const int n = min(p.d_pos[0] + 1, p.max_ctx);
+	// rows [0, shared) are read from candidate 0's slice.  The count sits next to the cache length in device memory, not in the kernel
+	// arguments: a captured token step is replayed for later calls with other prefix lengths
+	const int shared = p.shared_rows ? p.d_pos[1] : 0;
 	const T* Kc = (const T*)p.kcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
 	const T* Vc = (const T*)p.vcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
 	const int64_t to_shared = -(int64_t)b * p.H * p.max_ctx * HD;      // element offset from this candidate's slice to candidate 0's
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 #ifdef TTK_ABL
 			if (TTK_ABL & 128) { kf[u] = FragT{}; vf[u] = FragT{}; continue; }
 #endif
-			const int64_t off = (int64_t)key * HD + 8 * dg + (key < p.shared_rows ? to_shared : 0);
+			const int64_t off = (int64_t)key * HD + 8 * dg + (key < shared ? to_shared : 0);
 			kf[u] = *(const FragT*)(Kc + off);
 			vf[u] = *(const FragT*)(Vc + off);
 		}

@@ -20,6 +20,7 @@
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 #include "ttk_host.h"
+#include "ttk_rng.h"
 
 namespace ttk {
 
@@ -349,4 +350,20 @@ extern "C" int ttk_sample_step(const float* scores, int64_t ld, int B, int V, co
 
 extern "C" int ttk_sample_step_warped(const ttk_sample_args* a, void* stream) {
 	return ttk::launch_sample_step(a, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, (hipStream_t)stream, "ttk_sample_step_warped");
+}
+
+namespace ttk {
+__global__ void k_exponential_like_torch(float* out, int64_t numel, RngArgs a, int64_t draw) {
+	const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (li < numel) out[li] = torch_exponential_at(a, draw, li);
+}
+}  // namespace ttk
+
+extern "C" int ttk_exponential_like_torch(float* out, int64_t numel, int64_t seed, int64_t offset0, int64_t threads, int64_t step, int64_t draw, void* stream) {
+	using namespace ttk;
+	TTK_REQUIRE(out && numel >= 1 && threads >= 1, TTK_E_ARG, "ttk_exponential_like_torch: bad argument");
+	RngArgs a = {seed, offset0, threads, step, 0};
+	hipLaunchKernelGGL(k_exponential_like_torch, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, numel, a, draw);
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
 }

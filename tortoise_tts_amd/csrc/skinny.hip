@@ -19,6 +19,7 @@
 
 #include "ttk_common.h"
 #include "ttk_kernels.h"
+#include "ttk_rng.h"
 
 namespace ttk {
 
@@ -391,6 +392,11 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		const float v = FOLD ? (vsum[mt] - fmean[mt] * fcs) * frstd[mt] + bias : (W8 ? vsum[mt] * p.wscale : vsum[mt]) + bias;
 		if (p.mode == SK_STORE_F32) {
 			p.out_f32[(int64_t)m * p.ldc + n] = v;
+			// mel head: the multinomial noise of the sampling launch that follows, one value per logit (SkinnyParams.qbuf in this mode)
+			if (p.qbuf) {
+				const RngArgs ra = *(const RngArgs*)p.slab;
+				p.qbuf[(int64_t)m * p.ldc + n] = torch_exponential_at(ra, ((const int64_t*)p.tickets)[m], (ra.row0 + p.max_ctx + m) * (int64_t)p.N + n);   // max_ctx: first row of this launch's row group
+			}
 		} else if (p.mode == SK_RESIDUAL) {
 			p.out_f32[(int64_t)m * p.ldc + n] = res[mt] + v;
 			if (p.out_T) ((T*)p.out_T)[((((int64_t)mt * (p.N / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (m & 15)) * 8 + (n & 7))] = cvt<T>(res[mt] + v);
@@ -444,7 +450,7 @@ static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s, hip
 
 void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
 	SkinnyParams p = p_in;
-	if (p.ksplit < 1 || !p.slab || !p.tickets) p.ksplit = 1;
+	if (p.ksplit < 1 || !p.slab || !p.tickets || (p.mode == SK_STORE_F32 && p.qbuf)) p.ksplit = 1;      // (mel head: slab / tickets carry the noise arguments)
 	if (p.ln_count > 0 || p.mode == SK_QKV) p.narrow = 0;      // every workgroup of an LN kernel normalises all rows: more of them only adds work
 	if (p.ln_count == 0 && p.g1) { p.narrow = 0; p.ksplit = 1; }   // folded LayerNorm: the row statistics need all of K inside the workgroup
 	if (p.narrow) { p.ksplit = 1; p.narrow = p.narrow == 2 ? 2 : 4; }

@@ -91,6 +91,8 @@ struct SkinnyParams {
 	void* out_T;                    // SK_ACT_T, [M][N]; SK_RESIDUAL (optional): a T-typed copy of the updated rows in A-fragment order
 	                                // [m_tile][N/32][lane][8], the operand of the folded-LayerNorm launch that follows
 	// SK_QKV: n in [0,3d): q -> qbuf[m][n] f32 (pre-scaled), k/v -> cache[m][h][*pos][64]
+	// SK_STORE_F32 with qbuf != null (mel head): qbuf[m][n] (row stride ldc) receives the Exp(1) noise torch.multinomial would draw for logit
+	// (m, n) -- `slab` then points to a device RngArgs and `tickets` to the per-row int64 draw counters (ttk_rng.h)
 	float* qbuf; void* kcache; void* vcache; const int* d_pos; int max_ctx, H; float q_scale;
 	// optional split-K over workgroups: slab f32 [n_tiles][ksplit][MT][256], tickets int [n_tiles] (zero between launches)
 	int ksplit; float* slab; int* tickets;
@@ -149,7 +151,7 @@ struct AttnDecodeParams {
 	int ctx_hint;             // host-side copy of the key count (profiling only; stale under graph replay)
 	void* out;                // T [B][H*64], or (out_frag) MFMA-fragment order [m_tile][H*2][lane][8] for the projection that follows
 	int out_frag;
-	int shared_rows;          // cache rows [0, shared_rows) are identical for every candidate (one conditioning latent + one text line: the
+	int shared_rows;          // != 0: cache rows [0, d_pos[1]) are identical for every candidate (one conditioning latent + one text line: the
 	                          // prefill computed the same prefix B times): read them from candidate 0's slice, which the 16 workgroups of a head
 	                          // -- equal blockIdx.x, so one XCD -- then share in L2 instead of fetching B copies from HBM
 };
