@@ -147,6 +147,11 @@ int ttk_ar_decode_next(ttk_ar* h, float* logits_out, float* hidden_out, void* st
 int ttk_ar_set_noise(ttk_ar* h, const int64_t* rng_args, const int64_t* draws, float* q);
 int ttk_exponential_like_torch(float* out, int64_t numel, int64_t seed, int64_t offset0, int64_t threads, int64_t step, int64_t draw, void* stream);
 
+/* hipGraphLaunch of an instantiated graph the caller captured around libttk launches (torch.cuda.CUDAGraph.raw_cuda_graph_exec()): the
+ * token step replayed without torch.cuda.CUDAGraph.replay()'s prologue, which fills the generator's seed / offset tensors -- two launches per
+ * token -- whether or not the captured work draws random numbers.  With ttk_ar_set_noise it does not.                                      */
+int ttk_graph_launch(void* graph_exec, void* stream);
+
 /* The weight rounding of TTK_FP8W applied in place to a device f32 array: x <- fp8_e4m3(x / s) * s with s = the smallest power of
  * two >= max|x| / 448, returned in *scale_out (host).  This is exactly what ttk_*_create does to a TTK_FP8W matrix, exposed so that a
  * caller (and the parity tests) can build the equivalent TTK_BF16 model.                                                     */

@@ -21,6 +21,7 @@ def _geometry(numel):
 @pytest.mark.parametrize("seed", [0, 1234567891011])
 def test_exponential_like_torch_is_torchs_draw(shape, seed):
 	lib = _lib.load()
+	torch.cuda.init()                                            # default_generators is empty until the lazy init has run
 	gen = torch.cuda.default_generators[0]
 	torch.cuda.manual_seed(seed)
 	torch.rand(17, device=DEV)                                   # some non-zero starting offset

@@ -280,8 +280,14 @@ class UnifiedVoice:
 						with torch.inference_mode(False):
 							ctx.__exit__(None, None, None)
 						st.graph = g
+						# no random numbers are drawn inside the captured step when the mel head draws the noise: launch the instantiated
+						# graph directly then -- CUDAGraph.replay() first refills the generator's seed / offset tensors, two launches per token
+						st.graph_exec = g.raw_cuda_graph_exec() if st.own_rng and os.environ.get("TTK_AR_RAW_REPLAY", "1") != "0" else None
 					continue
-				st.graph.replay()
+				if st.graph_exec:
+					_lib.check(self.lib.ttk_graph_launch(st.graph_exec, _lib.stream_ptr()), "ttk_graph_launch")
+				else:
+					st.graph.replay()
 				n += 1
 				if can_stop:
 					ev = torch.cuda.Event()
@@ -399,6 +405,7 @@ class _GenState:
 			a.temperature, a.top_k, a.top_p, a.repetition_penalty = 1.0, 0, 1.0, 1.0
 		self.args = a
 		self.graph = None
+		self.graph_exec = None
 
 	def _noise_geometry(self, dev):
 		"""(threads, offset step per draw) of ATen's launch for `self.q.exponential_()` (ATen/native/cuda/DistributionTemplates.h:

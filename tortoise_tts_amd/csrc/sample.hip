@@ -367,3 +367,10 @@ extern "C" int ttk_exponential_like_torch(float* out, int64_t numel, int64_t see
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }
+
+extern "C" int ttk_graph_launch(void* graph_exec, void* stream) {
+	using namespace ttk;
+	TTK_REQUIRE(graph_exec, TTK_E_ARG, "ttk_graph_launch: null graph");
+	TTK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+	return TTK_OK;
+}
