@@ -7,9 +7,11 @@ What runs where
   * GPT-2 stack, embeddings, final norms, mel head, KV cache ........ libttk  (csrc/ar.hip and kernels)
   * logits processors / warpers, softmax, multinomial(1) given its noise, stop/pad bookkeeping, the next step's input
     embedding ......................................................... libttk  (csrc/sample.hip, one launch per token)
-  * the Exp(1) noise of torch.multinomial ............................ torch `exponential_` on the same stream: the
-    generator stream is part of the reference's observable behaviour (seed 0 on every call); typical sampling (rare,
-    off by default) also stays a torch op in front of the kernel (sampling.py).
+  * the Exp(1) noise of torch.multinomial ............................ libttk, inside the mel-head launch: torch's own Philox
+    stream restated (csrc/ttk_rng.h), used only after a bitwise comparison with `exponential_` on this device and shape
+    (else torch `exponential_` on the same stream) -- the generator stream is part of the reference's observable behaviour
+    (seed 0 on every call) and is left where torch's draws would have left it; typical sampling (rare, off by default)
+    stays a torch op in front of the kernel (sampling.py).
   * the per-token loop .............................................. here; one HIP-graph replay per token.
 """
 from __future__ import annotations
