@@ -206,18 +206,22 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	const int l2 = tid & 63, r = tid >> 6;
 	const int n = p.narrow ? nt * 16 + NC * sub + (l2 & (NC - 1)) : nt * 16 + (l2 & 15);
 	const bool mine = tid < 256 && (!p.narrow || (l2 & 15) < NC) && n < p.N;
-	float bias = 0.f, res[MT];
+	float bias = 0.f, fcs = 0.f, res[MT];
+	RngArgs rng = {};           // mel head drawing the multinomial noise: generator state and this thread's draw counters
+	int64_t draw[MT];
 	{
 		const int nn = n < p.N ? n : p.N - 1;
 		if (p.bias) bias = p.bias[nn];
+		if (FOLD) fcs = p.g1[nn];            // column sum of the folded matrix (cold, like the bias: left to the epilogue it is a dependent trip to HBM)
+		const bool noise = p.mode == SK_STORE_F32 && p.qbuf;
+		if (noise) rng = *(const RngArgs*)p.slab;
 #pragma unroll
 		for (int mt = 0; mt < MT; ++mt) {
-			res[mt] = 0.f;
-			if (p.mode == SK_RESIDUAL) {
-				int m = mt * 16 + 4 * (l2 >> 4) + (r & 3);
-				m = m < p.M ? m : p.M - 1;
-				res[mt] = p.out_f32[(int64_t)m * p.ldc + nn];
-			}
+			res[mt] = 0.f; draw[mt] = 0;
+			int m = mt * 16 + 4 * (l2 >> 4) + (r & 3);
+			m = m < p.M ? m : p.M - 1;
+			if (p.mode == SK_RESIDUAL) res[mt] = p.out_f32[(int64_t)m * p.ldc + nn];
+			if (noise) draw[mt] = ((const int64_t*)p.tickets)[m];
 		}
 	}
 	if (LN) { ln_load(wave); ln_load_affine(); }
@@ -383,7 +387,6 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		}
 	}
 	if (!mine) return;
-	const float fcs = FOLD ? p.g1[n < p.N ? n : p.N - 1] : 0.f;
 	if (TTK_ABL & 32) { if (vsum[0] == 1.2345e-30f) p.out_f32[0] = vsum[0]; return; }
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) {
@@ -393,10 +396,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		if (p.mode == SK_STORE_F32) {
 			p.out_f32[(int64_t)m * p.ldc + n] = v;
 			// mel head: the multinomial noise of the sampling launch that follows, one value per logit (SkinnyParams.qbuf in this mode)
-			if (p.qbuf) {
-				const RngArgs ra = *(const RngArgs*)p.slab;
-				p.qbuf[(int64_t)m * p.ldc + n] = torch_exponential_at(ra, ((const int64_t*)p.tickets)[m], (ra.row0 + p.max_ctx + m) * (int64_t)p.N + n);   // max_ctx: first row of this launch's row group
-			}
+			if (p.qbuf) p.qbuf[(int64_t)m * p.ldc + n] = torch_exponential_at(rng, draw[mt], (rng.row0 + p.max_ctx + m) * (int64_t)p.N + n);   // max_ctx: first row of this launch's row group
 		} else if (p.mode == SK_RESIDUAL) {
 			p.out_f32[(int64_t)m * p.ldc + n] = res[mt] + v;
 			if (p.out_T) ((T*)p.out_T)[((((int64_t)mt * (p.N / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (m & 15)) * 8 + (n & 7))] = cvt<T>(res[mt] + v);
