@@ -40,7 +40,7 @@ def parse():
 	ap.add_argument("--gpus", type=int, default=1)
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
-	ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8w", "fp8"],
+	ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "fp8w", "fp8"],
 					help="BASELINE config 5 -- fp8w: bf16 arithmetic, block GEMM weights in fp8-e4m3; fp8: also fp8 activations into the diffusion block GEMMs (fp8 MFMA)")
 	ap.add_argument("--with-vocoder", action="store_true", help="BASELINE config 5's tail: the BigVGAN vocoder (bf16) inside the step; off for the headline metric")
 	ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,7 +124,7 @@ def phase_roofline(marks, dtype_name):
 	token + the KV cache read), the latent pass and the DDIM loop are MFMA-bound.  `marks`: (name, event) pairs from
 	TTSHotPath.inference(phase_marks=...) of one step run exactly as the timed ones (captured graph, no instrumentation)."""
 	ms = {marks[i + 1][0]: marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)}
-	e_w = {"bf16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
+	e_w = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
 	e_kv = 4 if dtype_name == "f32" else 2
 	peak_f = 157.3e12 if dtype_name == "f32" else 2.5e15
 	P1 = TEXT_TOKENS + 4                                    # prefix rows incl. start_mel

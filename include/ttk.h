@@ -32,8 +32,11 @@ enum { TTK_OK = 0, TTK_E_ARG = -1, TTK_E_HIP = -2, TTK_E_WEIGHT = -3, TTK_E_STAT
  * power-of-two per-tensor scale; the KV-cached decode streams them as fp8 bytes, the dense GEMMs hold the same values in bf16.
  * TTK_FP8 (diffusion handle only) = TTK_FP8W with the ACTIVATION operand of the ResBlock / AttentionBlock GEMMs rounded to fp8-e4m3 as well
  * (scale 1: they are GroupNorm outputs and attention outputs), those GEMMs running on the fp8 MFMA with f32 accumulation: the result is
- * the TTK_BF16 arithmetic applied to operands rounded that way, up to f32 summation order. */
-enum { TTK_F32 = 0, TTK_BF16 = 1, TTK_FP8W = 2, TTK_FP8 = 3 };
+ * the TTK_BF16 arithmetic applied to operands rounded that way, up to f32 summation order.
+ * TTK_F16 (autoregressive and diffusion handles) = the TTK_BF16 design with IEEE half operands on v_mfma_f32_16x16x32_f16 -- the other dtype the
+ * reference's `torch.autocast("cuda", dtype)` at inference.py:331 can be given (config.py:625-637); f32 accumulation, residual streams,
+ * norms and softmax as in every mode, so unlike autocast nothing but an operand above 65504 can overflow. */
+enum { TTK_F32 = 0, TTK_BF16 = 1, TTK_FP8W = 2, TTK_FP8 = 3, TTK_F16 = 4 };
 
 typedef struct {
 	const char* name;     /* reference state_dict key, e.g. "gpt.h.0.attn.c_attn.weight" */
@@ -63,7 +66,7 @@ typedef struct {
 	int max_mel_seq_len, max_text_seq_len;    /* rows of the two learned position tables (:405-406) */
 	int number_text_tokens_p1, number_mel_codes;
 	int start_text_token, stop_text_token, start_mel_token, stop_mel_token;
-	int dtype;                                /* TTK_F32 | TTK_BF16 | TTK_FP8W */
+	int dtype;                                /* TTK_F32 | TTK_BF16 | TTK_F16 | TTK_FP8W */
 	int max_batch;                            /* candidates decoded together (<= 64; <= 32 in TTK_F32) */
 	int max_ctx;                              /* KV-cache rows per sequence: prefix + generated tokens */
 } ttk_ar_config;
@@ -169,7 +172,7 @@ typedef struct ttk_diff ttk_diff;
 
 typedef struct {
 	int model_channels, num_layers, in_channels, in_latent_channels, out_channels, num_heads;   /* diffusion.py:1392-1400 */
-	int dtype;                                /* TTK_F32 | TTK_BF16 | TTK_FP8W | TTK_FP8 */
+	int dtype;                                /* TTK_F32 | TTK_BF16 | TTK_F16 | TTK_FP8W | TTK_FP8 */
 } ttk_diff_config;
 
 /* Besides the hot-path subset of DiffusionTTS.state_dict() (weights.py: diffusion_shapes) the caller passes two derived

@@ -22,6 +22,8 @@ DEV = "cuda:0"
 BF16_LOGITS = 3e-2     # bf16 logits / latents / E vs the f32 oracle
 BF16_EVAL = 5e-2       # one bf16 network evaluation
 BF16_MEL = 8e-2        # bf16 mel after several DDIM steps
+# fp16 operands carry 11 significand bits against bf16's 8: the same comparisons at an eighth of the bf16 bounds
+F16 = 0.125
 F32_LOGITS_ABS = 1e-3  # f32 mode, full size, long context (5e-4 at ctx <= 12 in test_gpu_parity.py)
 F32_EVAL_ABS = 2e-3
 F32_MEL_ABS = 5e-3
@@ -86,7 +88,7 @@ def cfg3_case(ar_sd):
 	return text, cond, toks, steps, rows, ref
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
 def test_config1_teacher_forced_decode_full_size(ar_sd, cfg1_case, dtype):
 	from tortoise_tts_amd.autoregressive import UnifiedVoice
 	text, cond, toks, steps, ref = cfg1_case
@@ -96,10 +98,11 @@ def test_config1_teacher_forced_decode_full_size(ar_sd, cfg1_case, dtype):
 		if dtype == "f32":
 			assert maxerr(got[:, i], ref[:, i]) < F32_LOGITS_ABS, (j, maxerr(got[:, i], ref[:, i]))
 		else:
-			assert relerr(got[:, i], ref[:, i]) < BF16_LOGITS, (j, relerr(got[:, i], ref[:, i]))
+			tol = BF16_LOGITS * (F16 if dtype == "f16" else 1.0)
+			assert relerr(got[:, i], ref[:, i]) < tol, (j, relerr(got[:, i], ref[:, i]))
 			# per candidate too: one bad row must not hide in the batch norm
 			worst = max(relerr(got[b, i], ref[b, i]) for b in range(got.shape[0]))
-			assert worst < 2 * BF16_LOGITS, (j, worst)
+			assert worst < 2 * tol, (j, worst)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
@@ -137,7 +140,7 @@ def cfg1_diff_case(golden):
 	return lat, dcond, x, t, int(g["stride"]), tt("E_sub"), tt("y_cond_sub"), tt("y_uncond_sub"), tt("mel")
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32", "f16"])
 def test_config1_evaluation_and_ddim_slice_at_T1088(diff_sd, cfg1_diff_case, dtype):
 	from tortoise_tts_amd import _lib
 	from tortoise_tts_amd.diffusion import DiffusionTTS, get_diffuser
@@ -163,9 +166,10 @@ def test_config1_evaluation_and_ddim_slice_at_T1088(diff_sd, cfg1_diff_case, dty
 		assert maxerr(gE[:, :, ::st], E_sub) < F32_EVAL_ABS and maxerr(gc[:, :, ::st], yc_sub) < F32_EVAL_ABS and maxerr(gu[:, :, ::st], yu_sub) < F32_EVAL_ABS
 		assert maxerr(gx, xm) < F32_MEL_ABS
 	else:
-		assert relerr(gE[:, :, ::st], E_sub) < BF16_LOGITS
-		assert relerr(gc[:, :, ::st], yc_sub) < BF16_EVAL and relerr(gu[:, :, ::st], yu_sub) < BF16_EVAL, (relerr(gc[:, :, ::st], yc_sub), relerr(gu[:, :, ::st], yu_sub))
-		assert relerr(gx, xm) < BF16_MEL, relerr(gx, xm)
+		k = F16 if dtype == "f16" else 1.0
+		assert relerr(gE[:, :, ::st], E_sub) < k * BF16_LOGITS
+		assert relerr(gc[:, :, ::st], yc_sub) < k * BF16_EVAL and relerr(gu[:, :, ::st], yu_sub) < k * BF16_EVAL, (relerr(gc[:, :, ::st], yc_sub), relerr(gu[:, :, ::st], yu_sub))
+		assert relerr(gx, xm) < k * BF16_MEL, relerr(gx, xm)
 	assert gx.abs().max() <= 1.0 + 1e-5        # step 0: alpha_bar_prev = 1, so the result is the clamped x0
 
 

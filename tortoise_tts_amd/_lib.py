@@ -13,9 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TTK_LIB") or os.path.join(HERE, "libttk.so")   # TTK_LIB: A/B runs of an experimental build
 
 TTK_F32, TTK_BF16 = 0, 1
+TTK_F16 = 4
 TTK_FP8W = 2
 TTK_FP8 = 3      # diffusion handle only: fp8 activations into the block GEMMs as well (fp8 MFMA); elsewhere it means fp8w
-DTYPES = {"f32": TTK_F32, "fp32": TTK_F32, "float32": TTK_F32, "bf16": TTK_BF16, "bfloat16": TTK_BF16, "fp8w": TTK_FP8W, "fp8": TTK_FP8}
+DTYPES = {"f32": TTK_F32, "fp32": TTK_F32, "float32": TTK_F32, "bf16": TTK_BF16, "bfloat16": TTK_BF16, "f16": TTK_F16, "fp16": TTK_F16, "float16": TTK_F16, "half": TTK_F16, "fp8w": TTK_FP8W, "fp8": TTK_FP8}
 
 
 class TTKError(RuntimeError):

@@ -74,7 +74,7 @@ __global__ void k_build_latent_emb(const float* cond, const int64_t* text, int T
 
 struct ttk_ar {
 	ttk_ar_config cfg;
-	int dt;                 // arithmetic type the kernels run in (DT_F32 / DT_BF16)
+	int dt;                 // arithmetic type the kernels run in (DT_F32 / DT_BF16 / DT_F16)
 	int wdt;                // storage type of the GPT-2 block matrices (== dt, or DT_FP8W)
 	size_t es;
 	Arena arena;
@@ -245,7 +245,7 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	TTK_REQUIRE(cfg->model_dim % 64 == 0 && cfg->heads * 64 == cfg->model_dim, TTK_E_ARG,
 				"ttk_ar_create: head_dim must be 64 (model_dim %d, heads %d)", cfg->model_dim, cfg->heads);
 	TTK_REQUIRE(cfg->model_dim <= 2048, TTK_E_ARG, "ttk_ar_create: model_dim %d > 2048 unsupported", cfg->model_dim);
-	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_FP8W, TTK_E_ARG, "ttk_ar_create: bad dtype %d", cfg->dtype);
+	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_F16 || cfg->dtype == TTK_FP8W, TTK_E_ARG, "ttk_ar_create: bad dtype %d", cfg->dtype);
 	TTK_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= (cfg->dtype == TTK_F32 ? 32 : 64), TTK_E_ARG,
 				"ttk_ar_create: max_batch %d out of range", cfg->max_batch);
 	TTK_REQUIRE(cfg->max_ctx >= 8, TTK_E_ARG, "ttk_ar_create: max_ctx %d too small", cfg->max_ctx);
@@ -390,7 +390,7 @@ static int decode_impl(ttk_ar* h, const int64_t* tok, float* logits_out, float* 
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)
 	// (tok == null: ttk_ar_sample_next has written the rows already)
-	if (tok) launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s, h->lnfold ? h->x_frag : nullptr, h->dt == DT_F32);
+	if (tok) launch_decode_embed(h->mel_emb, tok, h->mel_pos, h->d_pos, 1 - h->P, c.max_mel_seq_len, h->x, B, d, s, h->lnfold ? h->x_frag : nullptr, elem_kind(h->dt));
 	// Experiment kept behind TTK_AR_SPLIT (default 1 = off): cut the candidates into row groups whose launch chains run on forked
 	// streams.  Rows are independent, so results are unchanged -- but on MI355X it LOSES (B=16, 250 tokens: 283 ms -> 340 ms with
 	// 2 groups, 517 ms with 4): the LayerNorm kernels already hold one 8-wave workgroup per CU, so the second chain cannot
@@ -430,7 +430,7 @@ int ttk_ar_sample_next(ttk_ar* h, const ttk_sample_args* a, void* stream) {
 	TTK_REQUIRE(h->ready, TTK_E_STATE, "ttk_ar_sample_next: call ttk_ar_prefill first");
 	TTK_REQUIRE(a->B == h->B && a->V == h->cfg.number_mel_codes, TTK_E_ARG, "ttk_ar_sample_next: shape (B %d, V %d) is not the prefilled one (B %d, V %d)",
 				a->B, a->V, h->B, h->cfg.number_mel_codes);
-	return launch_sample_step(a, h->mel_emb, h->mel_pos, h->x, h->cfg.model_dim, h->cfg.max_mel_seq_len, h->lnfold ? h->x_frag : nullptr, h->dt == DT_F32,
+	return launch_sample_step(a, h->mel_emb, h->mel_pos, h->x, h->cfg.model_dim, h->cfg.max_mel_seq_len, h->lnfold ? h->x_frag : nullptr, elem_kind(h->dt),
 							  (hipStream_t)stream, "ttk_ar_sample_next");
 }
 

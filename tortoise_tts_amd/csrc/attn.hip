@@ -40,6 +40,21 @@ template <> struct VT<bf16> {
 		return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 	}
 };
+template <> struct VT<f16> {      // the bf16 form on the f16 flavour of the transposing read
+	static __device__ __forceinline__ f16x8 load(const char* Vs, int kb, int d0, int lane) {
+		const int i = lane & 15, g = lane >> 4;
+		const int q = i >> 2, p = i & 3;
+		const int col = d0 + 4 * p;
+		const int r0 = kb + 4 * g + q, r1 = r0 + 16;
+		const int ch = col >> 3, sub = (col & 7) * 2;
+		typedef short s16x4 __attribute__((ext_vector_type(4)));
+		typedef __attribute__((address_space(3))) s16x4 lds_v4;
+		union { s16x4 s; f16x4 h; } lo, hi;      // the builtin's f16 flavour is typed on __fp16 vectors; the 16-bit integer one moves the same bits
+		lo.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(Vs + r0 * 128 + ((ch ^ (r0 & 7)) << 4) + sub));
+		hi.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(Vs + r1 * 128 + ((ch ^ (r1 & 7)) << 4) + sub));
+		return f16x8{lo.h[0], lo.h[1], lo.h[2], lo.h[3], hi.h[0], hi.h[1], hi.h[2], hi.h[3]};
+	}
+};
 template <> struct VT<float> {
 	static __device__ __forceinline__ f32x8 load(const char* Vs, int kb, int d0, int lane) {
 		const int i = lane & 15, g = lane >> 4;
@@ -315,6 +330,7 @@ static void launch_attn_fwd_t(const AttnParams& p, hipStream_t s) {
 void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s) {
 	ProfScope prof(PROF_ATTN_FWD, 4.0 * p.nb * p.H * (double)p.T * p.T * HD * (p.causal ? 0.5 : 1.0), s);
 	if (dt == DT_BF16) launch_attn_fwd_t<bf16>(p, s);
+	else if (dt == DT_F16) launch_attn_fwd_t<f16>(p, s);
 	else launch_attn_fwd_t<float>(p, s);
 }
 
@@ -444,6 +460,8 @@ void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {
 		if (variant == 1) launch_attn_decode_t<bf16, 4, 4>(p, s, ea, eb);
 		else if (variant == 2) launch_attn_decode_t<bf16, 8, 6>(p, s, ea, eb);
 		else launch_attn_decode_t<bf16, 16, 3>(p, s, ea, eb);
+	} else if (dt == DT_F16) {
+		launch_attn_decode_t<f16, 16, 3>(p, s, ea, eb);
 	} else {
 		launch_attn_decode_t<float, 8, 6>(p, s, ea, eb);
 	}
@@ -470,6 +488,7 @@ void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcach
 	const int64_t total = (int64_t)B * S * (H * HD / 8);
 	const int grid = (int)((total + 255) / 256);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_kv_scatter<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)qkv, B, S, H, (bf16*)kcache, (bf16*)vcache, max_ctx);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_kv_scatter<f16>), dim3(grid), dim3(256), 0, s, (const f16*)qkv, B, S, H, (f16*)kcache, (f16*)vcache, max_ctx);
 	else hipLaunchKernelGGL((k_kv_scatter<float>), dim3(grid), dim3(256), 0, s, (const float*)qkv, B, S, H, (float*)kcache, (float*)vcache, max_ctx);
 }
 

@@ -230,7 +230,7 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	TTK_REQUIRE(cfg->in_latent_channels % 64 == 0, TTK_E_ARG, "ttk_diff_create: in_latent_channels %% 64 != 0");
 	TTK_REQUIRE(cfg->model_channels % 128 == 0 && cfg->model_channels <= 1024 && 1024 % cfg->model_channels == 0, TTK_E_ARG,
 				"ttk_diff_create: model_channels %d unsupported (128, 256, 512 or 1024)", cfg->model_channels);
-	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_FP8W || cfg->dtype == TTK_FP8, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
+	TTK_REQUIRE(cfg->dtype == TTK_F32 || cfg->dtype == TTK_BF16 || cfg->dtype == TTK_F16 || cfg->dtype == TTK_FP8W || cfg->dtype == TTK_FP8, TTK_E_ARG, "ttk_diff_create: bad dtype %d", cfg->dtype);
 	TTK_REQUIRE(cfg->dtype != TTK_FP8 || cfg->model_channels % 128 == 0, TTK_E_ARG, "ttk_diff_create: fp8 GEMMs need channels %% 128 == 0");
 	ttk_diff* h = new ttk_diff();
 	h->cfg = *cfg;

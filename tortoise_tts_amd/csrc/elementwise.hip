@@ -41,8 +41,7 @@ __global__ void k_decode_embed(const float* emb, const int64_t* tok, const float
 	*(float4*)(out + (int64_t)b * d + c) = v;
 	if (frag) {
 		const int64_t fi = ((((int64_t)(b >> 4) * (d / 32) + (c >> 5)) * 64 + ((c >> 3) & 3) * 16 + (b & 15)) * 8 + (c & 7));
-		if (frag_f32) *(float4*)((float*)frag + fi) = v;
-		else { union { bf16x4 h; uint2 u; } pk; pk.h = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w}; *(uint2*)((bf16*)frag + fi) = pk.u; }
+		store4_kind(frag, fi, v, frag_f32);      // frag_f32: ttk::ElemKind of the copy
 	}
 }
 void launch_decode_embed(const float* emb, const int64_t* tok, const float* pos, const int* d_pos, int pos_off, int pos_rows, float* out, int B, int d, hipStream_t s,
@@ -75,6 +74,7 @@ __global__ void k_cast(const float* src, T* dst, int64_t n) {
 void launch_cast(int dt, const float* src, void* dst, int64_t n, hipStream_t s) {
 	const unsigned grid = (unsigned)((n / 4 + 256) / 256);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_cast<bf16>), dim3(grid), dim3(256), 0, s, src, (bf16*)dst, n);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_cast<f16>), dim3(grid), dim3(256), 0, s, src, (f16*)dst, n);
 	else hipLaunchKernelGGL((k_cast<float>), dim3(grid), dim3(256), 0, s, src, (float*)dst, n);
 }
 
@@ -98,6 +98,7 @@ __global__ void k_cf_to_cl(const float* src, int nb, int C, int Tn, T* dst, int6
 void launch_cf_to_cl(int dt, const float* src, int nb, int C, int T, void* dst, int64_t ldo, int rep, hipStream_t s) {
 	dim3 grid((T + 31) / 32, (unsigned)((ldo + 31) / 32), nb);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_cf_to_cl<bf16>), grid, dim3(256), 0, s, src, nb, C, T, (bf16*)dst, ldo, rep);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_cf_to_cl<f16>), grid, dim3(256), 0, s, src, nb, C, T, (f16*)dst, ldo, rep);
 	else hipLaunchKernelGGL((k_cf_to_cl<float>), grid, dim3(256), 0, s, src, nb, C, T, (float*)dst, ldo, rep);
 }
 
@@ -130,6 +131,7 @@ void launch_bcast_rows(int dt, const float* vec, int rows, int C, void* dst, hip
 	const int64_t total = (int64_t)rows * C;
 	const unsigned grid = (unsigned)((total + 255) / 256);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_bcast_rows<bf16>), dim3(grid), dim3(256), 0, s, vec, rows, C, (bf16*)dst);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_bcast_rows<f16>), dim3(grid), dim3(256), 0, s, vec, rows, C, (f16*)dst);
 	else hipLaunchKernelGGL((k_bcast_rows<float>), dim3(grid), dim3(256), 0, s, vec, rows, C, (float*)dst);
 }
 
@@ -150,6 +152,7 @@ __global__ void k_timestep_embedding(const int64_t* t, int64_t t_host, int n, in
 void launch_timestep_embedding(int dt, const int64_t* t, int64_t t_host, int n, int C, const float* freqs, void* out, hipStream_t s) {
 	const unsigned grid = (n * (C / 2) + 255) / 256;
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_timestep_embedding<bf16>), dim3(grid), dim3(256), 0, s, t, t_host, n, C, freqs, (bf16*)out);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_timestep_embedding<f16>), dim3(grid), dim3(256), 0, s, t, t_host, n, C, freqs, (f16*)out);
 	else hipLaunchKernelGGL((k_timestep_embedding<float>), dim3(grid), dim3(256), 0, s, t, t_host, n, C, freqs, (float*)out);
 }
 
@@ -161,6 +164,7 @@ __global__ void k_silu_cast(const float* x, T* y, int64_t n) {
 void launch_silu_cast(int dt, const float* x, void* y, int64_t n, hipStream_t s) {
 	const unsigned grid = (unsigned)((n + 255) / 256);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_silu_cast<bf16>), dim3(grid), dim3(256), 0, s, x, (bf16*)y, n);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_silu_cast<f16>), dim3(grid), dim3(256), 0, s, x, (f16*)y, n);
 	else hipLaunchKernelGGL((k_silu_cast<float>), dim3(grid), dim3(256), 0, s, x, (float*)y, n);
 }
 

@@ -411,6 +411,7 @@ void launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
 	if (g_prof_on) prof_pair(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, &ea, &eb);
 	if (dt == DT_FP8) launch_gemm_t<f8>(p, s, ea, eb);          // A and W are fp8-e4m3 bytes, K % 128 == 0
 	else if (dt == DT_BF16) launch_gemm_t<bf16>(p, s, ea, eb);
+	else if (dt == DT_F16) launch_gemm_t<f16>(p, s, ea, eb);
 	else launch_gemm_t<float>(p, s, ea, eb);
 }
 

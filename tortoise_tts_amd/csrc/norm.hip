@@ -72,6 +72,8 @@ void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, cons
 	const int grid = (rows + 3) / 4;
 	if (out_f32 || dt == DT_F32)
 		hipLaunchKernelGGL((k_layernorm<float>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (float*)out, ldo, frag, out2);
+	else if (dt == DT_F16)
+		hipLaunchKernelGGL((k_layernorm<f16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (f16*)out, ldo, frag, out2);
 	else
 		hipLaunchKernelGGL((k_layernorm<bf16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (bf16*)out, ldo, frag, out2);
 }
@@ -190,9 +192,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 		if (sizeof(OT) == 1) {
 			*(unsigned*)dst = pack4_fp8(o0, o1, o2, o3);
 		} else if (sizeof(OT) == 2) {
-			union { bf16x4 v; uint2 u; } pk;
-			pk.v = bf16x4{(bf16)o0, (bf16)o1, (bf16)o2, (bf16)o3};
-			*(uint2*)dst = pk.u;
+			*(uint2*)dst = pack4_16<OT>(o0, o1, o2, o3);
 		} else {
 			*(float4*)dst = make_float4(o0, o1, o2, o3);
 		}
@@ -205,6 +205,7 @@ static void launch_gn_apply_p(int dt, const GnApplyParams& p, hipStream_t s) {
 	const int grid = p.nb * ((p.Tout + strip - 1) / strip);
 	if (p.out_f8) hipLaunchKernelGGL((k_gn_apply<f8, PASSES>), dim3(grid), dim3(256), 0, s, p);
 	else if (p.out_f32 || dt == DT_F32) hipLaunchKernelGGL((k_gn_apply<float, PASSES>), dim3(grid), dim3(256), 0, s, p);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_gn_apply<f16, PASSES>), dim3(grid), dim3(256), 0, s, p);
 	else hipLaunchKernelGGL((k_gn_apply<bf16, PASSES>), dim3(grid), dim3(256), 0, s, p);
 }
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {

@@ -36,6 +36,7 @@ void launch_pack_nk(int dt, const float* src, int layout, int N, int K, int Npad
 	const int64_t total = (int64_t)ntap * Npad * Kpad;
 	const unsigned grid = (unsigned)((total + 255) / 256);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_pack_nk<bf16>), dim3(grid), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, ntap, (bf16*)dst);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_pack_nk<f16>), dim3(grid), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, ntap, (f16*)dst);
 	else hipLaunchKernelGGL((k_pack_nk<float>), dim3(grid), dim3(256), 0, s, src, layout, N, K, Npad, Kpad, ntap, (float*)dst);
 }
 
@@ -54,6 +55,7 @@ void launch_pack_frag(int dt, const void* src, int Npad, int K, void* dst, hipSt
 	const int64_t total = (int64_t)Npad * K;
 	const unsigned grid = (unsigned)((total + 255) / 256);
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_pack_frag<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, Npad, K, (bf16*)dst);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_pack_frag<f16>), dim3(grid), dim3(256), 0, s, (const f16*)src, Npad, K, (f16*)dst);
 	else hipLaunchKernelGGL((k_pack_frag<float>), dim3(grid), dim3(256), 0, s, (const float*)src, Npad, K, (float*)dst);
 }
 
@@ -82,6 +84,7 @@ __global__ void k_rowsum(const T* w, int64_t ld, int N, int K, float* out) {
 }
 void launch_rowsum(int dt, const void* w, int64_t ld, int N, int K, float* out, hipStream_t s) {
 	if (dt == DT_BF16) hipLaunchKernelGGL((k_rowsum<bf16>), dim3((N + 3) / 4), dim3(256), 0, s, (const bf16*)w, ld, N, K, out);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_rowsum<f16>), dim3((N + 3) / 4), dim3(256), 0, s, (const f16*)w, ld, N, K, out);
 	else hipLaunchKernelGGL((k_rowsum<float>), dim3((N + 3) / 4), dim3(256), 0, s, (const float*)w, ld, N, K, out);
 }
 // bias'[n] = b[n] + sum_k beta[k] * W[k][n]   (f32 weights as given, f64 accumulation)

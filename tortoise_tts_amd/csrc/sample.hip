@@ -41,7 +41,7 @@ struct SampleParams {
 	int *live_rows, *all_done;
 	// next decode step's input row (AR-aware entry only): x[b] = emb[next] + pos[col + 2]
 	const float *emb, *pos; float* x_out; int d, pos_rows;
-	void* x_frag; int x_frag_f32;      // optional copy of the same rows in A-fragment order (T-typed: bf16 or f32) for a folded-LayerNorm first launch
+	void* x_frag; int x_frag_f32;      // optional copy of the same rows in A-fragment order (T-typed; x_frag_f32 = its ttk::ElemKind) for a folded-LayerNorm first launch
 };
 
 __device__ __forceinline__ float block_max(float v, float* red, int tid) {
@@ -309,8 +309,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(SampleParams p) 
 			if (p.x_frag) {   // element (m = b, n = 4i + j) of [m_tile][d/32][lane = (n>>3 & 3) * 16 + (m & 15)][n & 7]: four consecutive n are contiguous
 				const int n = 4 * i;
 				const int64_t fi = ((((int64_t)(b >> 4) * (p.d / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (b & 15)) * 8 + (n & 7));
-				if (p.x_frag_f32) *(float4*)((float*)p.x_frag + fi) = v;
-				else { union { bf16x4 h; uint2 u; } pk; pk.h = bf16x4{(bf16)v.x, (bf16)v.y, (bf16)v.z, (bf16)v.w}; *(uint2*)((bf16*)p.x_frag + fi) = pk.u; }
+				store4_kind(p.x_frag, fi, v, p.x_frag_f32);      // x_frag_f32: ttk::ElemKind of the copy
 			}
 		}
 	}

@@ -461,6 +461,7 @@ void launch_skinny(int dt, const SkinnyParams& p_in, int waves, hipStream_t s) {
 	hipEvent_t ea = nullptr, eb = nullptr;
 	if (g_prof_on) prof_pair(PROF_SKINNY, (double)p.N * p.K * (p.w8 ? 1 : dtype_size(dt)) + 4.0 * p.N + 4.0 * p.M * p.K + 4.0 * p.M * p.N, &ea, &eb);
 	if (dt == DT_BF16) { if (p.w8) launch_skinny_t<bf16, true>(p, waves, s, ea, eb); else launch_skinny_t<bf16, false>(p, waves, s, ea, eb); }
+	else if (dt == DT_F16) launch_skinny_t<f16, false>(p, waves, s, ea, eb);
 	else launch_skinny_t<float, false>(p, waves, s, ea, eb);
 }
 

@@ -1,7 +1,8 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libttk.
-// One arithmetic template parameter T in {float, __bf16}: T is the storage/MFMA-operand type of weights and
+// One arithmetic template parameter T in {float, __bf16, _Float16}: T is the storage/MFMA-operand type of weights and
 // of GEMM/attention input activations; accumulators, residual streams, norm statistics and softmax are f32.
 //   T = __bf16 : v_mfma_f32_16x16x32_bf16              (performance mode, BASELINE config 2)
+//   T = _Float16 : v_mfma_f32_16x16x32_f16             (the reference's other autocast dtype, inference.py:331 / config.py:625-637)
 //   T = float  : 8 x v_mfma_f32_16x16x4_f32 per k-step (exact-f32 parity mode; same tiling, same code)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -10,6 +11,9 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 
@@ -20,6 +24,7 @@ namespace ttk {
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x8 type; };
 template <> struct Frag<bf16> { typedef bf16x8 type; };
+template <> struct Frag<f16> { typedef f16x8 type; };
 // fp8-e4m3 (OCP) storage tag for the dense GEMM's operands in the fp8 mode of the diffusion network: one byte per element; a lane's
 // 16-byte LDS read then holds its k elements for TWO v_mfma_f32_16x16x32_fp8_fp8 steps (low / high 8 bytes).
 struct f8 { unsigned char v; };
@@ -40,6 +45,10 @@ template <>
 __device__ __forceinline__ f32x4 mma16<bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
 	return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+template <>
+__device__ __forceinline__ f32x4 mma16<f16>(f16x8 a, f16x8 b, f32x4 c) {
+	return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 // f32: instruction j contracts k = {8g + j : g = 0..3}; the eight instructions together cover the same 32 k as
 // the bf16 form with the same per-lane addressing (exact f32 fma chain, MI355X_MICROARCH "FP32-input MFMA").
 template <>
@@ -52,6 +61,22 @@ __device__ __forceinline__ f32x4 mma16<float>(f32x8 a, f32x8 b, f32x4 c) {
 template <typename T> __device__ __forceinline__ T cvt(float x);
 template <> __device__ __forceinline__ float cvt<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 cvt<bf16>(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
+template <> __device__ __forceinline__ f16 cvt<f16>(float x) { return (f16)x; }      // v_cvt_f16_f32, RNE; |x| > 65504 becomes inf, as in torch
+// four f32 -> four 2-byte T as one 8-byte word (element 0 lowest)
+template <typename T> __device__ __forceinline__ uint2 pack4_16(float a, float b, float c, float d) { return make_uint2(0u, 0u); }
+template <> __device__ __forceinline__ uint2 pack4_16<bf16>(float a, float b, float c, float d) {
+	union { bf16x4 v; uint2 u; } pk; pk.v = bf16x4{(bf16)a, (bf16)b, (bf16)c, (bf16)d}; return pk.u;
+}
+template <> __device__ __forceinline__ uint2 pack4_16<f16>(float a, float b, float c, float d) {
+	union { f16x4 v; uint2 u; } pk; pk.v = f16x4{(f16)a, (f16)b, (f16)c, (f16)d}; return pk.u;
+}
+// the same with the element type chosen at run time (kernels without a T parameter that write a "T-typed" copy): ttk::ElemKind
+enum ElemKind { EK_BF16 = 0, EK_F32 = 1, EK_F16 = 2 };
+__device__ __forceinline__ void store4_kind(void* base, int64_t idx, float4 v, int kind) {
+	if (kind == EK_F32) *(float4*)((float*)base + idx) = v;
+	else if (kind == EK_F16) *(uint2*)((f16*)base + idx) = pack4_16<f16>(v.x, v.y, v.z, v.w);
+	else *(uint2*)((bf16*)base + idx) = pack4_16<bf16>(v.x, v.y, v.z, v.w);
+}
 
 // Wave64 sum, result in every lane.  DPP inside each 16-lane row (quad swaps, row_half_mirror, row_mirror: VALU-rate, no LDS
 // crossbar), then the four row sums are read back through SGPRs.  ~12 instructions instead of six dependent ds_bpermute.

@@ -171,8 +171,8 @@ extern "C" int ttk_fp8_round_weights(float* x, int64_t n, float* scale_out, void
 extern "C" int ttk_gemm_nt(int dtype, const void* A, const void* W, int M, int N, int K, float out_scale, const float* bias, float* C, void* stream) {
 	using namespace ttk;
 	TTK_REQUIRE(A && W && C, TTK_E_ARG, "ttk_gemm_nt: null argument");
-	TTK_REQUIRE(dtype == TTK_F32 || dtype == TTK_BF16 || dtype == TTK_FP8, TTK_E_ARG, "ttk_gemm_nt: dtype must be TTK_F32, TTK_BF16 or TTK_FP8 (fp8-e4m3 bytes), got %d", dtype);
-	const int kmul = dtype == TTK_FP8 ? 128 : (dtype == TTK_BF16 ? 64 : 32);
+	TTK_REQUIRE(dtype == TTK_F32 || dtype == TTK_BF16 || dtype == TTK_F16 || dtype == TTK_FP8, TTK_E_ARG, "ttk_gemm_nt: dtype must be TTK_F32, TTK_BF16, TTK_F16 or TTK_FP8 (fp8-e4m3 bytes), got %d", dtype);
+	const int kmul = dtype == TTK_FP8 ? 128 : (dtype == TTK_F32 ? 32 : 64);
 	TTK_REQUIRE(M >= 1 && N >= 128 && N % 128 == 0 && K >= kmul && K % kmul == 0, TTK_E_ARG,
 				"ttk_gemm_nt: need M >= 1, N %% 128 == 0, K %% %d == 0 (got M=%d N=%d K=%d)", kmul, M, N, K);
 	GemmParams g = {};

@@ -11,7 +11,9 @@ namespace ttk {
 // decode GEMVs stream the weights as fp8 bytes.  Kernels are launched with DT_BF16 plus a per-matrix flag.
 // DT_FP8 (diffusion handle only): as DT_FP8W, and the ResBlock / AttentionBlock GEMMs take their ACTIVATION operand in fp8-e4m3 as well
 // (written by the GroupNorm-apply and attention kernels) and run on v_mfma_f32_16x16x32_fp8_fp8; launch_gemm accepts DT_FP8 for those.
-enum DType { DT_F32 = 0, DT_BF16 = 1, DT_FP8W = 2, DT_FP8 = 3 };
+// DT_F16: the bf16 design with fp16 operands (v_mfma_f32_16x16x32_f16); autoregressive and diffusion handles only.
+enum DType { DT_F32 = 0, DT_BF16 = 1, DT_FP8W = 2, DT_FP8 = 3, DT_F16 = 4 };
+inline int elem_kind(int dt) { return dt == DT_F32 ? 1 : (dt == DT_F16 ? 2 : 0); }      // ttk::ElemKind of a "T-typed" buffer
 inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 inline int kernel_dtype(int dt) { return (dt == DT_FP8W || dt == DT_FP8) ? DT_BF16 : dt; }
 

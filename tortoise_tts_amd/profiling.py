@@ -13,7 +13,7 @@ KINDS = ["gemm", "skinny_gemm", "attn_fwd", "attn_decode", "groupnorm_stats", "g
 KERNEL_NAMES = {"gemm": "ttk::k_gemm", "skinny_gemm": "ttk::k_skinny", "attn_fwd": "ttk::k_attn_fwd", "attn_decode": "ttk::k_attn_decode",
 				"groupnorm_stats": "ttk::k_gn_stats", "groupnorm_apply": "ttk::k_gn_apply", "layernorm": "ttk::k_layernorm"}
 MFMA_BOUND = {"gemm", "attn_fwd"}
-PEAK_TFLOPS = {_lib.TTK_BF16: 2500.0, _lib.TTK_F32: 157.3, _lib.TTK_FP8W: 2500.0, _lib.TTK_FP8: 2500.0}   # fp8w: fp8 weight storage, bf16 MFMA
+PEAK_TFLOPS = {_lib.TTK_BF16: 2500.0, _lib.TTK_F16: 2500.0, _lib.TTK_F32: 157.3, _lib.TTK_FP8W: 2500.0, _lib.TTK_FP8: 2500.0}   # fp8w: fp8 weight storage, bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
