@@ -265,20 +265,26 @@ def main():
 		roof = profiling.dominant_kernel_roofline(lambda: step(exchange=False), ar, df)   # rank 0 alone: no collective in here
 		if not a.small:
 			roof["phases"] = phase_roofline(marks, a.dtype)
-	# informational, never `value`: a stream of utterances with line i's diffusion overlapped with line i+1's sampling
-	# (TTSHotPath.inference_lines; identical results).  `value` above stays the one-utterance-at-a-time figure of configs[1].
+	# informational, never `value`: a stream of utterances through TTSHotPath.inference_lines -- the sampling of 4 consecutive lines as ONE
+	# decode batch (weights streamed once per token for all of them), line i's diffusion overlapped with later lines' sampling; results
+	# identical to the per-line calls.  Built on its own handle (max_batch = 4 x candidates) AFTER the headline was measured; `value` above
+	# stays the one-utterance-at-a-time figure of configs[1].
 	piped = None
 	if rank == 0 and world == 1 and not a.no_roofline and not by_cand:
-		n_lines = 4
+		n_lines, per_batch = 8, 4
+		ar4 = UnifiedVoice(W.synth_state_dict(W.ar_shapes(ar_cfg), 0), ar_cfg, dtype=a.dtype, device=dev, max_batch=per_batch * n_cand,
+						   max_ctx=n_text + 4 + n_mel + 8)
+		tts4 = TTSHotPath(ar4, df)
 		lkw = {k: v for k, v in kw.items() if k != "return_all"}
-		tts.inference_lines([text] * 2, ar_lat, df_lat, **lkw)
+		tts4.inference_lines([text] * per_batch, ar_lat, df_lat, ar_batch_lines=per_batch, **lkw)
 		torch.cuda.synchronize()
 		t1 = time.perf_counter()
-		res = tts.inference_lines([text] * n_lines, ar_lat, df_lat, **lkw)
+		res = tts4.inference_lines([text] * n_lines, ar_lat, df_lat, ar_batch_lines=per_batch, **lkw)
 		torch.cuda.synchronize()
 		dl = time.perf_counter() - t1
-		piped = {"value": sum(r[1] for r in res) / dl, "unit": "audio-sec/wall-sec", "lines": n_lines, "ms_per_line": 1e3 * dl / n_lines,
-				 "note": "software-pipelined stream of utterances; not the headline metric"}
+		piped = {"value": sum(r[1] for r in res) / dl, "unit": "audio-sec/wall-sec", "lines": n_lines, "ar_batch_lines": per_batch, "ms_per_line": 1e3 * dl / n_lines,
+				 "note": "stream of utterances: 4 lines sampled as one decode batch, diffusion pipelined under the next batch; not the headline metric"}
+		del tts4, ar4
 	log("roofline pass done; cpu baseline")
 	cpu = None
 	if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small and not by_cand:

@@ -141,14 +141,24 @@ int ttk_ar_decode_next(ttk_ar* h, float* logits_out, float* hidden_out, void* st
 /* The Exp(1) noise of torch.multinomial without torch in the token step.  `q.exponential_(1)` on the GPU is a pure function of (generator seed,
  * generator offset, element index, launch geometry) -- ATen's distribution_nullary_kernel over a Philox4_32_10 state (csrc/ttk_rng.h restates
  * the indexing; the state and the uniform conversion are rocRAND's own header code, as in torch's build).  ttk_ar_set_noise makes the mel-head
- * launch of ttk_ar_prefill / ttk_ar_decode[_next] write q[m][n] for its logits: rng_args = device int64[5] {seed, offset before the first draw,
- * threads of torch's launch for the full [C, V] tensor, offset step per draw, first row of this handle's candidates in that tensor}, draws =
+ * launch of ttk_ar_prefill / ttk_ar_decode[_next] write q[m][n] for its logits: rng_args = device int64[6] {seed, offset before the first draw,
+ * threads of torch's launch for the full [C, V] tensor, offset step per draw, first row of this handle's candidates in that tensor, candidates per text line or 0 (ttk_ar_prefill_lines)}, draws =
  * device int64[B] draws made so far per row (the `col` of ttk_sample_args), q = f32 rows [B][V].  The caller advances the torch generator by
  * step x draws afterwards, so everything drawn later is the reference's stream too.  Pass NULLs to switch it off.
  * ttk_exponential_like_torch fills out[li] for li < numel with the same function (draw-th draw): the bitwise comparison against
  * torch.Tensor.exponential_ that a caller runs before relying on it (tortoise_tts_amd/autoregressive.py does).                          */
 int ttk_ar_set_noise(ttk_ar* h, const int64_t* rng_args, const int64_t* draws, float* q);
 int ttk_exponential_like_torch(float* out, int64_t numel, int64_t seed, int64_t offset0, int64_t threads, int64_t step, int64_t draw, void* stream);
+
+/* Several text lines prefilled as ONE decode batch (no reference counterpart: TTS.inference walks the lines of a text one by one,
+ * inference.py:244-246, streaming the weights again for each line's 16 candidates).  Line g: conditioning latent cond_latents[g] (f32 [n_lines][model_dim]),
+ * text ids text[sum(text_len[:g]) ...] (device int64, concatenated), text_len[g] of them (HOST int array); it occupies candidates
+ * [g * rows_per_line, (g + 1) * rows_per_line).  logits_out f32 [n_lines * rows_per_line][number_mel_codes].  The decode entries then step all
+ * candidates together, each with the cache length of its own line, and every row's logits are bit for bit those of ttk_ar_prefill / ttk_ar_decode
+ * on its line alone.  With ttk_ar_set_noise, rng_args[5] = rows_per_line makes every line draw the same [rows_per_line, V] noise, as the reference's
+ * reseeding to 0 per line does.                                                                                                   */
+int ttk_ar_prefill_lines(ttk_ar* h, const float* cond_latents, const int64_t* text, const int* text_len, int n_lines, int rows_per_line,
+						 float* logits_out, void* stream);
 
 /* hipGraphLaunch of an instantiated graph the caller captured around libttk launches (torch.cuda.CUDAGraph.raw_cuda_graph_exec()): the
  * token step replayed without torch.cuda.CUDAGraph.replay()'s prologue, which fills the generator's seed / offset tensors -- two launches per

@@ -8,11 +8,12 @@ from tortoise_tts_amd import weights as W
 from tortoise_tts_amd.autoregressive import UnifiedVoice
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtype=os.environ.get("TTK_AB_DTYPE", "bf16"), device=dev, max_batch=16, max_ctx=64 + 4 + 250 + 8)
+B = int(os.environ.get("TTK_AB_B", "16"))
+ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtype=os.environ.get("TTK_AB_DTYPE", "bf16"), device=dev, max_batch=B, max_ctx=64 + 4 + 250 + 8)
 g = torch.Generator().manual_seed(1234)
 text = torch.randint(1, 255, (1, 64), generator=g).to(dev)
 cond = torch.randn(1, 1024, generator=g).to(dev)
-run = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16, max_generate_length=250, suppress_tokens=[8193])
+run = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=B, max_generate_length=250, suppress_tokens=[8193])
 with torch.inference_mode():
 	run(); run(); torch.cuda.synchronize()
 	ts = []

@@ -95,6 +95,22 @@ class UnifiedVoice:
 										   logits.data_ptr(), _lib.stream_ptr()), "ttk_ar_prefill")
 		return logits
 
+	def _prefill_lines(self, cond: torch.Tensor, texts, rows_per_line: int) -> torch.Tensor:
+		"""several text lines as one decode batch (include/ttk.h: ttk_ar_prefill_lines): line g -> candidates [g * rows, (g + 1) * rows)"""
+		G = len(texts)
+		cond = cond.to(self.device, torch.float32)
+		cond = (cond.expand(G, -1) if cond.shape[0] == 1 else cond).contiguous()
+		if cond.shape[0] != G:
+			raise ValueError("one conditioning latent, or one per line")
+		flat = torch.cat([t.to(self.device, torch.int64).reshape(-1) for t in texts]).contiguous()
+		_lib.require_cuda(cond, flat)
+		self._check_ids(flat, self.cfg.number_text_tokens + 1, "text token")
+		lens = (_lib.C.c_int * G)(*[int(t.numel()) for t in texts])
+		logits = torch.empty((G * rows_per_line, self.cfg.number_mel_codes), device=self.device, dtype=torch.float32)
+		_lib.check(self.lib.ttk_ar_prefill_lines(self._h, cond.data_ptr(), flat.data_ptr(), lens, G, rows_per_line, logits.data_ptr(),
+												 _lib.stream_ptr()), "ttk_ar_prefill_lines")
+		return logits
+
 	def _decode(self, tok: torch.Tensor, logits: torch.Tensor, hidden: Optional[torch.Tensor] = None):
 		"""one KV-cached step fed with `tok` (callers pass ids this module sampled, or teacher-forced ones they validated)"""
 		_lib.check(self.lib.ttk_ar_decode(self._h, tok.data_ptr(), logits.data_ptr(), _lib.ptr(hidden), _lib.stream_ptr()),
@@ -163,6 +179,72 @@ class UnifiedVoice:
 								typical_mass if typical_sampling else None, hf_generate_kwargs, stream=False, shard=candidate_shard)
 		return gen
 
+	def inference_speech_lines(self, speech_conditioning_latent, texts, num_return_sequences=1, max_generate_length=None, **hf_generate_kwargs):
+		"""`inference_speech` for several text lines as ONE decode batch (no reference counterpart: TTS.inference walks its lines one by one,
+		inference.py:244-246, and every line streams the GPT-2 weights again for its 16 candidates; a token step over 2 / 4 lines costs 1.36x /
+		2.05x the step over one).  texts: list of [1, Tt_g] id tensors.  Returns a list of int64 [num_return_sequences, L_g]: element g is bit for
+		bit what `inference_speech(latent, texts[g], ...)` returns -- each row keeps the cache length of its own line, every line draws the same
+		[num_return_sequences, V] multinomial noise (the reference reseeds to 0 per line), and line g is cut where its own last row finished.
+		`self.last_generate_lines[g]` says where the generator stands after line g's sampling in the reference (steps, rng_start, rng_step):
+		a caller that draws per line afterwards (TTSHotPath.inference_lines) re-positions it with `position_rng_after_line(g)`."""
+		if hf_generate_kwargs.get("num_beams", 1) not in (None, 1) or not hf_generate_kwargs.get("do_sample", False):
+			raise NotImplementedError("only the sampling branch (do_sample=True, num_beams=1) is implemented; pass do_sample=True")
+		texts = list(texts)
+		if any(t.dim() != 2 or t.shape[0] != 1 for t in texts):
+			raise NotImplementedError("texts: a list of [1, Tt] id tensors, one per line")
+		if len(texts) == 1:
+			ids = self.inference_speech(speech_conditioning_latent, texts[0], num_return_sequences=num_return_sequences,
+										max_generate_length=max_generate_length, **hf_generate_kwargs)
+			self.last_generate_lines = [dict(self.last_generate, seed=hf_generate_kwargs.get("seed", 0))]
+			return [ids]
+		return self._generate_lines(speech_conditioning_latent, texts, num_return_sequences, max_generate_length, hf_generate_kwargs)
+
+	def position_rng_after_line(self, g: int):
+		"""leave the torch generators as the reference's `generate` on line g alone leaves them (reseeded, advanced by that line's draws)"""
+		info = self.last_generate_lines[g]
+		setup_seed(info["seed"])
+		torch.cuda.default_generators[self.device.index or 0].set_offset(info["rng_start"] + info["steps"] * info["rng_step"])
+
+	def _generate_lines(self, cond, texts, C, max_generate_length, kw):
+		c = self.cfg
+		G = len(texts)
+		B = G * C
+		if B > self.max_batch:
+			raise _lib.TTKError(f"{G} lines x {C} candidates exceed max_batch={self.max_batch}")
+		Tmax = max(int(t.shape[1]) for t in texts)
+		max_new = (c.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+		if Tmax + 4 + max_new > self.max_ctx or max_new + 2 > c.max_mel_seq_len:
+			raise _lib.TTKError(f"prefix {Tmax + 4} + {max_new} new tokens exceed max_ctx={self.max_ctx} or the mel position table ({c.max_mel_seq_len})")
+		suppress = tuple(kw.get("suppress_tokens") or ())
+		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 50), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0), suppress, None)
+		can_stop = c.stop_mel_token not in suppress
+		seed = kw.get("seed", 0)
+		with torch.cuda.device(self.device):
+			st = self._gen_state(B, max_new, pipe_key, C, 0, lines=G)
+			setup_seed(seed)
+			gen = torch.cuda.default_generators[self.device.index or 0]
+			off_start = gen.get_offset()
+			st.reset(c)
+			if st.own_rng:
+				st.arm_noise(gen, 0)
+			try:
+				n = self._token_loop(st, gen, off_start, lambda: self._prefill_lines(cond, texts, C), max_new, can_stop)
+			finally:
+				if st.own_rng:
+					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
+			step = st.noise_step if st.own_rng else (gen.get_offset() - off_start) // max(n, 1)
+			ids = st.ids[:, :n]
+			first_stop = torch.where((ids == c.stop_mel_token).any(dim=1), (ids == c.stop_mel_token).float().argmax(dim=1), torch.full((B,), n, device=ids.device)).view(G, C)
+			done = bool(can_stop) & (first_stop < n).all(dim=1)
+			n_line = torch.where(done, first_stop.max(dim=1).values + 1, torch.full((G,), n, device=ids.device)).tolist()
+			out, self.last_generate_lines = [], []
+			for g in range(G):
+				out.append(ids[g * C:(g + 1) * C, :int(n_line[g])].clone())
+				self.last_generate_lines.append(dict(steps=int(n_line[g]), rng_start=off_start, rng_step=step, seed=seed))
+			self.position_rng_after_line(G - 1)
+			self.last_generate = dict(self.last_generate_lines[-1])
+			return out
+
 	def compute_embeddings(self, cond_latents, text_inputs, kv_cache=True):
 		"""unified_voice.py:614-630: remembers the prefix, returns the fake id row [b, P+1]."""
 		self._prefix = (cond_latents, text_inputs)
@@ -216,7 +298,7 @@ class UnifiedVoice:
 			if st.own_rng:
 				st.arm_noise(gen, lo)
 			try:
-				n = self._token_loop(st, gen, off_start, cond, text, B, max_new, can_stop)
+				n = self._token_loop(st, gen, off_start, lambda: self._prefill(cond, text, B), max_new, can_stop)
 			finally:
 				if st.own_rng:
 					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
@@ -226,9 +308,9 @@ class UnifiedVoice:
 			self.last_generate = dict(steps=n, rng_start=off_start, rng_step=(gen.get_offset() - off_start) // max(n, 1))
 			return st.ids[:, :n].clone(), None
 
-	def _token_loop(self, st, gen, off_start, cond, text, B, max_new, can_stop):
+	def _token_loop(self, st, gen, off_start, prefill, max_new, can_stop):
 		c = self.cfg
-		st.logits.copy_(self._prefill(cond, text, B))
+		st.logits.copy_(prefill())
 		n = 0
 		if not (self.use_graph and st.graphable):
 			while True:
@@ -311,18 +393,18 @@ class UnifiedVoice:
 						n = n_true
 		return n
 
-	def _gen_state(self, B, max_new, pipe_key, C=None, lo=0):
+	def _gen_state(self, B, max_new, pipe_key, C=None, lo=0, lines=1):
 		"""generation states (device buffers + the captured token step) keyed by what is baked into them; a few are kept so that
 		alternating shapes (e.g. `TTS.inference` lines with different max lengths) do not re-capture every call"""
 		C = B if C is None else C
-		key = (B, max_new, pipe_key, C, lo)
+		key = (B, max_new, pipe_key, C, lo, lines)
 		states = self._states
 		if key in states:
 			states[key] = states.pop(key)             # most recently used last
 		else:
 			while len(states) >= 4:
 				states.pop(next(iter(states)))
-			states[key] = _GenState(self, B, max_new, pipe_key, C, lo)
+			states[key] = _GenState(self, B, max_new, pipe_key, C, lo, lines)
 		return states[key]
 
 	def _loop_stream(self, cond, text, B, max_new, pipe):
@@ -355,9 +437,10 @@ class _GenState:
 	"""Persistent device buffers of one generation shape, so a captured token step can be replayed across calls (and across text
 	lengths: nothing in it depends on the prefix length)."""
 
-	def __init__(self, model: UnifiedVoice, B, max_new, pipe_key, C=None, lo=0):
+	def __init__(self, model: UnifiedVoice, B, max_new, pipe_key, C=None, lo=0, lines=1):
 		c, dev = model.cfg, model.device
 		C = B if C is None else C
+		self.lines, self.noise_rows = lines, C                          # lines > 1: B = lines * C rows, every line draws the same [C, V] noise
 		self.model = model
 		self.B, self.max_new = B, max_new
 		self.pipe = LogitsPipeline(temperature=pipe_key[0], top_k=pipe_key[1], top_p=pipe_key[2], repetition_penalty=pipe_key[3],
@@ -370,13 +453,14 @@ class _GenState:
 		self.col = torch.zeros(B, dtype=torch.long, device=dev)         # per-row output column (all rows move together)
 		# Exp(1) noise of multinomial for ALL C candidates of the call (C == B unless this is one shard of a candidate-sharded run:
 		# every rank draws the same [C, V] block and reads its rows lo..lo+B-1, see inference_speech)
-		self.q = torch.empty((C, c.number_mel_codes), device=dev, dtype=torch.float32)
+		self.q = torch.empty((B if lines > 1 else C, c.number_mel_codes), device=dev, dtype=torch.float32)
+		self.qc = torch.empty((C, c.number_mel_codes), device=dev, dtype=torch.float32) if lines > 1 else None      # torch-drawn fallback of a line batch
 		self.live = torch.zeros(1, dtype=torch.int32, device=dev)        # unfinished rows, decremented on the device
 		self.done = torch.zeros(1, dtype=torch.int32).pin_memory()       # raised by the row that finishes last; polled by the host
 		self.rng_step = None                                             # generator offset consumed by one sample() call
 		# torch's `q.exponential_(1)` restated inside the mel-head launch (include/ttk.h: ttk_ar_set_noise) -- one launch per token less.
 		# Relied on only after a bitwise comparison with torch's own draw on this device, for this very shape (below).
-		self.rng = torch.zeros(5, dtype=torch.long, device=dev)          # RngArgs {seed, offset0, threads, step, row0}
+		self.rng = torch.zeros(6, dtype=torch.long, device=dev)          # RngArgs {seed, offset0, threads, step, row0, candidates per line or 0}
 		self.own_rng = os.environ.get("TTK_AR_OWN_RNG", "1") != "0" and self._noise_matches_torch(model, dev)
 		# input_ids as the repetition penalty sees them: the fake prefix ids are all 1 with start_mel last (unified_voice.py:647-649),
 		# i.e. the SET {1, start_mel} whatever the text length (the penalty acts once per distinct id), then the sampled tokens
@@ -413,7 +497,7 @@ class _GenState:
 		"""(threads, offset step per draw) of ATen's launch for `self.q.exponential_()` (ATen/native/cuda/DistributionTemplates.h:
 		distribution_nullary_kernel -- 256-thread blocks, a grid capped at the resident blocks of the device, four values per Philox call)"""
 		props = torch.cuda.get_device_properties(dev)
-		numel = self.q.numel()
+		numel = self.noise_rows * self.q.shape[1]
 		grid = min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (numel + 255) // 256)
 		threads = 256 * grid
 		return threads, ((numel - 1) // (threads * 4) + 1) * 4
@@ -425,10 +509,11 @@ class _GenState:
 			threads, step = self._noise_geometry(dev)
 			seed, off = gen.initial_seed(), gen.get_offset()
 			seed = seed - (1 << 64) if seed >= (1 << 63) else seed
-			want = [torch.empty_like(self.q).exponential_(1) for _ in range(2)]
+			shape = (self.noise_rows, self.q.shape[1])
+			want = [torch.empty(shape, device=dev).exponential_(1) for _ in range(2)]
 			if gen.get_offset() - off != 2 * step:
 				return False
-			got = torch.empty_like(self.q)
+			got = torch.empty(shape, device=dev)
 			for draw in range(2):
 				_lib.check(model.lib.ttk_exponential_like_torch(got.data_ptr(), got.numel(), seed, off, threads, step, draw, _lib.stream_ptr()),
 						   "ttk_exponential_like_torch")
@@ -443,7 +528,7 @@ class _GenState:
 		"""point the mel-head launches of this call at q, starting from the generator's current state"""
 		seed = gen.initial_seed()
 		seed = seed - (1 << 64) if seed >= (1 << 63) else seed
-		self.rng.copy_(torch.tensor([seed, gen.get_offset(), self.noise_threads, self.noise_step, lo], dtype=torch.long))
+		self.rng.copy_(torch.tensor([seed, gen.get_offset(), self.noise_threads, self.noise_step, lo, self.noise_rows if self.lines > 1 else 0], dtype=torch.long))
 		m = self.model
 		_lib.check(m.lib.ttk_ar_set_noise(m._h, self.rng.data_ptr(), self.col.data_ptr(), self.q[lo].data_ptr()), "ttk_ar_set_noise")
 
@@ -469,5 +554,9 @@ class _GenState:
 		# multinomial(softmax(scores), 1) == argmax(softmax(scores) / q), q ~ Exp(1) from the torch generator (see sampling.multinomial1)
 		# (own_rng: the mel-head launch that produced self.logits has written q already)
 		if not self.own_rng:
-			self.q.exponential_(1)
+			if self.lines > 1:
+				self.qc.exponential_(1)
+				self.q.view(self.lines, *self.qc.shape).copy_(self.qc)
+			else:
+				self.q.exponential_(1)
 		_lib.check(self.model.lib.ttk_ar_sample_next(self.model._h, _lib.C.byref(a), _lib.stream_ptr()), "ttk_ar_sample_next")

@@ -84,7 +84,8 @@ struct ttk_ar {
 	float *text_emb, *mel_emb, *mel_pos, *text_pos;
 	void *kc, *vc;          // [layers][max_batch][H][max_ctx][64]
 	size_t kv_layer_stride; // elements
-	int* d_pos;             // device scalar: number of valid cache rows
+	int* d_pos;             // device: [0] valid cache rows (first line), [1] rows of the shared prefix, then row_off[max_batch], row_grp[max_batch]
+	int* d_rowoff; int* d_rowgrp;    // per candidate: extra cache rows relative to [0] / first candidate of its line (ttk_ar_prefill_lines)
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
 	void* x_frag = nullptr; // T copy of x in A-fragment order [m_tile][d/32][64][8]: operand of the folded-LayerNorm launches
@@ -111,9 +112,10 @@ struct ttk_ar {
 	hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 	WsBuf ws_x, ws_a, ws_qkv, ws_ao, ws_h;
 	int B = 0, P = 0, k = 0, ready = 0;
+	int Pmax = 0;           // longest prefix of the batch (capacity checks); == P for one line
 };
 
-static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipStream_t s) {
+static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipStream_t s, int kv_row0 = 0) {
 	const int d = h->cfg.model_dim, H = h->cfg.heads, dt = h->dt;
 	const int rows = B * S;
 	TTK_TRY(h->ws_a.reserve((size_t)rows * d * h->es));
@@ -129,8 +131,9 @@ static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipSt
 		g.C = h->ws_qkv.p; g.ldc = 3 * d;
 		launch_gemm(dt, g, s);
 		if (write_kv) {
-			char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * h->es;
-			char* vc = (char*)h->vc + (size_t)l * h->kv_layer_stride * h->es;
+			const size_t row0 = (size_t)kv_row0 * H * h->cfg.max_ctx * 64;      // first candidate slice written
+			char* kc = (char*)h->kc + ((size_t)l * h->kv_layer_stride + row0) * h->es;
+			char* vc = (char*)h->vc + ((size_t)l * h->kv_layer_stride + row0) * h->es;
 			launch_kv_scatter(dt, h->ws_qkv.p, B, S, H, kc, vc, h->cfg.max_ctx, s);
 		}
 		AttnParams a = {};
@@ -193,9 +196,11 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		if (fold_qkv) { p.Wp = L.attn.wfrag_fold; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b; }
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
+		p.row_off = h->d_rowoff + r0;
 		launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
 		AttnDecodeParams a = {};
 		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 && h->share_prefix && h->nsplit == 1;
+		a.row_off = h->d_rowoff + r0; a.row_grp = r0 == 0 ? h->d_rowgrp : nullptr;
 		launch_attn_decode(dt, a, s);
 		p = {};
 		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
@@ -288,7 +293,9 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	h->kv_layer_stride = (size_t)cfg->max_batch * cfg->heads * cfg->max_ctx * 64;
 	AR_TRY(h->arena.alloc(&h->kc, h->kv_layer_stride * cfg->layers * h->es));
 	AR_TRY(h->arena.alloc(&h->vc, h->kv_layer_stride * cfg->layers * h->es));
-	AR_TRY(h->arena.alloc((void**)&h->d_pos, 16));
+	AR_TRY(h->arena.alloc((void**)&h->d_pos, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)));
+	h->d_rowoff = h->d_pos + 4; h->d_rowgrp = h->d_rowoff + cfg->max_batch;
+	if (hipMemset(h->d_pos, 0, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc(&h->attn_out, (size_t)round_up(cfg->max_batch, 16) * d * h->es));
@@ -374,8 +381,53 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, S, s);
 	launch_set_int(h->d_pos + 1, shared ? S : 0, s);      // rows of the shared prefix (AttnDecodeParams.shared_rows): device-resident, like the cache length
-	h->B = B; h->P = Tt + 3; h->k = 0; h->ready = 1;
+	launch_fill_int(h->d_rowoff, 0, 2 * c.max_batch, s);  // one line: no per-row offsets, every candidate's prefix owner is candidate 0
+	h->B = B; h->P = h->Pmax = Tt + 3; h->k = 0; h->ready = 1;
 	h->shared_rows = shared ? S : 0;
+	TTK_HIP(hipGetLastError());
+	return TTK_OK;
+}
+
+// Several text lines as ONE decode batch (no reference counterpart: TTS.inference walks its lines one by one, inference.py:244-246, each with
+// the weights streamed again for 16 rows): line g occupies candidates [g * rows_per_line, (g + 1) * rows_per_line), its prefix is run once into
+// the slice of its first candidate, and the decode step gives every candidate its own cache length -- d_pos + row_off[b] -- so each row's keys
+// are dealt to the waves exactly as in a batch of its own and its logits are bit for bit those of ttk_ar_prefill / ttk_ar_decode on that line alone.
+int ttk_ar_prefill_lines(ttk_ar* h, const float* cond_latents, const int64_t* text, const int* text_len, int n_lines, int rows_per_line,
+						 float* logits_out, void* stream) {
+	TTK_REQUIRE(h && cond_latents && text && text_len && logits_out, TTK_E_ARG, "ttk_ar_prefill_lines: null argument");
+	const ttk_ar_config& c = h->cfg;
+	const int B = n_lines * rows_per_line, d = c.model_dim;
+	TTK_REQUIRE(n_lines >= 1 && rows_per_line >= 1 && B <= c.max_batch, TTK_E_ARG, "ttk_ar_prefill_lines: %d lines x %d candidates exceed max_batch=%d", n_lines, rows_per_line, c.max_batch);
+	TTK_REQUIRE(h->share_prefix && h->nsplit == 1, TTK_E_STATE, "ttk_ar_prefill_lines: needs the shared-prefix decode (TTK_AR_SHARE_PREFIX=1, TTK_AR_SPLIT=1)");
+	int Smax = 0;
+	for (int g = 0; g < n_lines; ++g) {
+		const int Tt = text_len[g];
+		TTK_REQUIRE(Tt >= 1 && Tt + 2 <= c.max_text_seq_len, TTK_E_ARG, "ttk_ar_prefill_lines: line %d: %d text tokens exceed the position table (%d)", g, Tt, c.max_text_seq_len - 2);
+		TTK_REQUIRE(Tt + 5 <= c.max_ctx, TTK_E_ARG, "ttk_ar_prefill_lines: line %d: prefix of %d rows does not fit max_ctx=%d", g, Tt + 4, c.max_ctx);
+		Smax = Tt + 4 > Smax ? Tt + 4 : Smax;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	TTK_TRY(h->ws_x.reserve((size_t)Smax * d * sizeof(float)));
+	float* x = (float*)h->ws_x.p;
+	const int S0 = text_len[0] + 4;
+	int64_t toff = 0;
+	for (int g = 0; g < n_lines; ++g) {
+		const int Tt = text_len[g], S = Tt + 4, r0 = g * rows_per_line;
+		const int64_t total = (int64_t)S * (d / 4);
+		hipLaunchKernelGGL(k_build_prefill_emb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cond_latents + (size_t)g * d, 1, text + toff, Tt, 1, d,
+						   h->text_emb, h->text_pos, h->mel_emb, h->mel_pos, c.start_text_token, c.stop_text_token, c.start_mel_token, x);
+		TTK_TRY(dense_forward(h, x, 1, S, true, s, r0));
+		launch_copy_rows(x + (size_t)(S - 1) * d, 0, h->x + (size_t)r0 * d, d, rows_per_line, d, s);      // the line's last prefix row to all its candidates
+		launch_fill_int(h->d_rowoff + r0, S - S0, rows_per_line, s);
+		launch_fill_int(h->d_rowgrp + r0, r0, rows_per_line, s);
+		toff += Tt;
+	}
+	if (B < c.max_batch) { launch_fill_int(h->d_rowoff + B, 0, c.max_batch - B, s); launch_fill_int(h->d_rowgrp + B, 0, c.max_batch - B, s); }
+	head_launch(h, B, logits_out, nullptr, s);
+	launch_set_int(h->d_pos, S0, s);
+	launch_set_int(h->d_pos + 1, S0, s);
+	h->B = B; h->P = text_len[0] + 3; h->Pmax = Smax - 1; h->k = 0; h->ready = 1;
+	h->shared_rows = S0;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }
@@ -385,7 +437,7 @@ static int decode_impl(ttk_ar* h, const int64_t* tok, float* logits_out, float* 
 	TTK_REQUIRE(h->ready, TTK_E_STATE, "%s: call ttk_ar_prefill first", who);
 	const ttk_ar_config& c = h->cfg;
 	const int B = h->B, d = c.model_dim;
-	TTK_REQUIRE(h->P + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "%s: KV cache full (max_ctx=%d)", who, c.max_ctx);
+	TTK_REQUIRE(h->Pmax + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "%s: KV cache full (max_ctx=%d)", who, c.max_ctx);
 	TTK_REQUIRE(h->k + 2 < c.max_mel_seq_len, TTK_E_STATE, "%s: mel position table exhausted (%d rows)", who, c.max_mel_seq_len);
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)

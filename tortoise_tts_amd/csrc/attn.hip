@@ -360,13 +360,17 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 #ifdef TTK_ABL      // diagnostic builds only (tests/diag/ar_ablate.sh): 256 = the whole kernel, 128 = the K / V loads
 	if (TTK_ABL & 256) return;
 #endif
-	const int n = min(p.d_pos[0] + 1, p.max_ctx);
-	// rows [0, shared) are read from candidate 0's slice.  The count sits next to the cache length in device memory, not in the kernel
+	// several text lines in one batch: candidate b's prefix is row_off[b] rows longer than the first line's, and its shared prefix rows live
+	// in the slice of the first candidate of ITS line
+	const int off = p.row_off ? p.row_off[b] : 0, grp = p.row_grp ? p.row_grp[b] : 0;
+	const int n = min(p.d_pos[0] + 1 + off, p.max_ctx);
+	// rows [0, shared) are read from the line's first candidate.  The count sits next to the cache length in device memory, not in the kernel
 	// arguments: a captured token step is replayed for later calls with other prefix lengths
-	const int shared = p.shared_rows ? p.d_pos[1] : 0;
+	const int sh0 = p.shared_rows ? p.d_pos[1] : 0;
+	const int shared = sh0 > 0 ? sh0 + off : 0;
 	const T* Kc = (const T*)p.kcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
 	const T* Vc = (const T*)p.vcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
-	const int64_t to_shared = -(int64_t)b * p.H * p.max_ctx * HD;      // element offset from this candidate's slice to candidate 0's
+	const int64_t to_shared = -(int64_t)(b - grp) * p.H * p.max_ctx * HD;      // element offset from this candidate's slice to its line's first
 	float q[8];
 	{
 		const float* qp = p.qbuf + ((int64_t)b * p.H + h) * HD + 8 * dg;

@@ -9,6 +9,8 @@ __global__ void k_set_int(int* p, int v) { *p = v; }
 __global__ void k_add_int(int* p, int v) { *p += v; }
 void launch_set_int(int* p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, p, v); }
 void launch_add_int(int* p, int v, hipStream_t s) { hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s, p, v); }
+__global__ void k_fill_int(int* p, int v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+void launch_fill_int(int* p, int v, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_fill_int, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
 
 // out[r] = A[ia[r]] + Bt[ib[r]]      (unified_voice.py:582,590,641: embedding + learned position embedding)
 __global__ void k_gather_add(const float* A, const int* ia, const float* Bt, const int* ib, float* out, int rows, int d) {

@@ -361,7 +361,7 @@ __global__ void k_exponential_like_torch(float* out, int64_t numel, RngArgs a, i
 extern "C" int ttk_exponential_like_torch(float* out, int64_t numel, int64_t seed, int64_t offset0, int64_t threads, int64_t step, int64_t draw, void* stream) {
 	using namespace ttk;
 	TTK_REQUIRE(out && numel >= 1 && threads >= 1, TTK_E_ARG, "ttk_exponential_like_torch: bad argument");
-	RngArgs a = {seed, offset0, threads, step, 0};
+	RngArgs a = {seed, offset0, threads, step, 0, 0};
 	hipLaunchKernelGGL(k_exponential_like_torch, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, numel, a, draw);
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;

@@ -23,6 +23,8 @@ struct RngArgs {            // device-resident, written by the host at the start
 	int64_t threads;        // 256 * grid of torch's launch for this numel
 	int64_t step;           // offset advance per draw: 4 * rounds
 	int64_t row0;           // first row of this rank's candidates inside the [C, V] tensor torch would fill (candidate shards)
+	int64_t group;          // > 0: the batch holds several text lines of `group` candidates each, every line drawing the SAME [group, V] noise
+	                        // (the reference reseeds to 0 for every line): row m uses noise row m mod group
 };
 
 // at::log of the torch wheel on this image (ATen/NumericUtils.h; __HIP_ARCH__ is not a HIP macro, so its `::log(x)` branch is the one

@@ -177,8 +177,11 @@ class TTSHotPath:
 	@torch.inference_mode()
 	def inference_lines(self, lines, autoregressive_latents, diffusion_latents, *, max_ar_steps=500, max_diffusion_steps=80, ar_temp=0.8,
 						diffusion_temp=1.0, top_p=1.0, top_k=0, repetition_penalty=1.0, length_penalty=1.0, cond_free=True,
-						candidates=1, suppress_tokens=None):
-		"""The reference's `for line in lines` loop (inference.py:237-422) software-pipelined: the diffusion of line i runs while the
+						candidates=1, suppress_tokens=None, ar_batch_lines=None):
+		"""The reference's `for line in lines` loop (inference.py:237-422) software-pipelined and batched:
+		(1) the autoregressive sampling of up to `ar_batch_lines` consecutive lines runs as ONE decode batch (UnifiedVoice.inference_speech_lines:
+		the GPT-2 weights are streamed once per token for all of them; default: as many as fit max_batch, at most 4; 1 = one line per batch);
+		(2) the diffusion of line i runs while the sampling of later lines does: the diffusion of line i runs while the
 		autoregressive sampling of line i+1 does.  The two phases of different lines are independent and both are latency-bound chains of
 		small kernels, so they interleave on the CUs -- provided BOTH keep being fed: the sampling loop needs the host once per token
 		(graph replay), and enqueuing a diffusion is ~10k launches from one C call, so the diffusion is issued from a worker thread on its
@@ -189,6 +192,8 @@ class TTSHotPath:
 		(stream_generator.py:296), and the draws that follow a line's AR phase in the reference (the diffusion start noise,
 		inference.py:404, and DDIM's per-step dummy draws, diffusion.py:685) are made by the main thread in that same order before the next
 		line's AR phase starts; the worker draws nothing.
+		Batched lines keep that property: each row decodes with its own line's cache length, every line draws the same noise, and before a line's
+		own draws the generators are put where its `generate` alone would have left them (UnifiedVoice.position_rng_after_line).
 		`lines`: list of [1, Tt] int64 token tensors.  Returns a list of (mels [1, 100, T], seconds, codes)."""
 		from concurrent.futures import ThreadPoolExecutor
 		ar, diff = self.autoregressive, self.diffusion
@@ -212,14 +217,18 @@ class TTSHotPath:
 				return mels
 
 		out, pending = [], []
+		lines = [t.to(dev) for t in lines]
+		G = ar_batch_lines or max(1, min(4, ar.max_batch // max(candidates, 1)))
+		G = max(1, min(G, ar.max_batch // max(candidates, 1)))
 		with ThreadPoolExecutor(max_workers=1) as pool:          # one worker: diffusions stay in line order on s_df
-			for text_tokens in lines:
-				text_tokens = text_tokens.to(dev)
+			for i, text_tokens in enumerate(lines):
 				with torch.cuda.stream(s_ar):
-					codes = ar.inference_speech(autoregressive_latents, text_tokens, do_sample=True, top_k=top_k, top_p=top_p, temperature=ar_temp,
-												num_return_sequences=candidates, num_beams=1, length_penalty=length_penalty,
-												repetition_penalty=repetition_penalty, max_generate_length=max_ar_steps, **extra)
-					codes = fix_stop_tokens(codes, ar.stop_mel_token)
+					if i % G == 0:      # sample this line and the next G - 1 as one batch
+						batch_codes = ar.inference_speech_lines(autoregressive_latents, lines[i:i + G], do_sample=True, top_k=top_k, top_p=top_p,
+																temperature=ar_temp, num_return_sequences=candidates, num_beams=1, length_penalty=length_penalty,
+																repetition_penalty=repetition_penalty, max_generate_length=max_ar_steps, **extra)
+					ar.position_rng_after_line(i % G)       # the generators as this line's own `generate` leaves them
+					codes = fix_stop_tokens(batch_codes[i % G], ar.stop_mel_token)
 					B, M = codes.shape
 					latents = ar.forward(autoregressive_latents.expand(B, -1) if autoregressive_latents.shape[0] != B else autoregressive_latents,
 										 text_tokens.expand(B, -1), torch.tensor([text_tokens.shape[1]], dtype=torch.int32).expand(B), codes,
