@@ -265,6 +265,18 @@ def main():
 		roof = profiling.dominant_kernel_roofline(lambda: step(exchange=False), ar, df)   # rank 0 alone: no collective in here
 		if not a.small:
 			roof["phases"] = phase_roofline(marks, a.dtype)
+	# informational, never `value`: the k = 1 variant SURVEY.md 8d row 2 asks to be reported beside the headline -- the candidate is chosen first and
+	# only its row goes through the dense latent pass (same bits out; the reference runs all 16, inference.py:370-379, and so does `value`)
+	k1 = None
+	if rank == 0 and world == 1 and not a.no_roofline and not by_cand:
+		kw1 = dict(kw, latents_for="winner")
+		tts.inference(text, ar_lat, df_lat, **kw1)
+		torch.cuda.synchronize()
+		t1 = time.perf_counter()
+		sec = sum(tts.inference(text, ar_lat, df_lat, **kw1)[1] for _ in range(2))
+		torch.cuda.synchronize()
+		d1 = time.perf_counter() - t1
+		k1 = {"value": sec / d1, "unit": "audio-sec/wall-sec", "ms_per_step": 1e3 * d1 / 2, "note": "latent pass on the diffused candidate only; not the headline metric"}
 	# informational, never `value`: a stream of utterances through TTSHotPath.inference_lines -- the sampling of 4 consecutive lines as ONE
 	# decode batch (weights streamed once per token for all of them), line i's diffusion overlapped with later lines' sampling; results
 	# identical to the per-line calls.  Built on its own handle (max_batch = 4 x candidates) AFTER the headline was measured; `value` above
@@ -309,7 +321,7 @@ def main():
 			"ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": a.dtype, "data": "synthetic",
 			"config": cfg_line,
-			"roofline": roof, "cpu_baseline": cpu, "pipelined_lines": piped,
+			"roofline": roof, "cpu_baseline": cpu, "latent_k1_variant": k1, "pipelined_lines": piped,
 		}
 		print(json.dumps(line), flush=True)
 	if dist.is_initialized():

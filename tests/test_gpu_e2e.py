@@ -222,3 +222,28 @@ def test_clvp_picks_the_candidate_that_is_diffused(small):
 	assert torch.equal(aux["latents"], trim_calm_tokens(aux["codes"][b:b + 1], lat_all[b:b + 1]))
 	if b != 0:
 		assert not torch.equal(mels, base_mels)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_latents_for_the_winner_only_gives_the_same_bits(dtype):
+	"""the k = 1 variant of SURVEY.md 8d row 2: choosing the candidate first and running the dense latent pass on its row alone returns the
+	mel of the all-candidates pass bit for bit (rows of the pass are independent), with and without a scorer"""
+	import clvp_oracle  # noqa: F401  (oracle/ on the path: fixtures of this module)
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	from tortoise_tts_amd.clvp import CLVP
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	from tortoise_tts_amd.inference import TTSHotPath
+	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 31), W.AR_SMALL, dtype=dtype, device=DEV, max_batch=8, max_ctx=128)
+	df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(W.DIFF_SMALL), 32), W.DIFF_SMALL, dtype=dtype, device=DEV)
+	ccfg = W.CLVPConfig(dim=128, depth=2, heads=2, num_speech_tokens=8194)
+	clvp = CLVP(W.synth_state_dict(W.clvp_shapes(ccfg), 34), ccfg, dtype="f32", device=DEV)
+	text, al, dl = _inputs(900, 8)
+	kw = dict(max_ar_steps=18, max_diffusion_steps=3, candidates=7, suppress_tokens=[W.AR_SMALL.stop_mel_token], return_all=True)
+	for tts in (TTSHotPath(ar, df), TTSHotPath(ar, df, clvp=clvp)):
+		with torch.inference_mode():
+			m_all, s_all, a_all = tts.inference(text, al.to(DEV), dl.to(DEV), **kw)
+			m_one, s_one, a_one = tts.inference(text, al.to(DEV), dl.to(DEV), latents_for="winner", **kw)
+		assert s_all == s_one and a_all["best"] == a_one["best"] and torch.equal(a_all["codes"], a_one["codes"])
+		assert torch.equal(a_all["latents"], a_one["latents"]) and torch.equal(m_all, m_one)
+	with pytest.raises(ValueError):
+		TTSHotPath(ar, df).inference(text, al.to(DEV), dl.to(DEV), latents_for="some", **kw)

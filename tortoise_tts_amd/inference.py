@@ -123,8 +123,11 @@ class TTSHotPath:
 	def inference(self, text_tokens: torch.Tensor, autoregressive_latents: torch.Tensor, diffusion_latents: torch.Tensor, *,
 				  max_ar_steps=500, max_diffusion_steps=80, ar_temp=0.8, diffusion_temp=1.0, top_p=1.0, top_k=0,
 				  repetition_penalty=1.0, length_penalty=1.0, diffusion_sampler="ddim", cond_free=True, candidates=1,
-				  suppress_tokens=None, return_all=False, phase_marks=None):
+				  suppress_tokens=None, return_all=False, phase_marks=None, latents_for="all"):
 		"""text_tokens [1, Tt] int64; latents from the reference's conditioning encoders ([1,1024], [1,2048]).
+		latents_for: "all" = the latent pass over every candidate, as the reference runs it before scoring (inference.py:370-379; the benchmarked
+		workload); "winner" = the k = 1 variant: the candidate is chosen first and only its row goes through the dense
+		pass (the reference's own to-do at :370) -- rows of the pass are independent, so the result is the same bits.
 		Returns the denormalised mel [1, 100, T] (input of the vocoder) and the audio seconds it represents.
 		phase_marks (measurement only): a list that receives (name, torch.cuda.Event) at the phase boundaries -- start, after the AR
 		sampling, after the latent pass, after the diffusion -- for bench.py's per-phase roofline."""
@@ -149,19 +152,29 @@ class TTSHotPath:
 		B, M = codes.shape
 		wav_lengths = torch.tensor([M * ar.mel_length_compression])
 		text_lengths = torch.tensor([text_tokens.shape[1]], dtype=torch.int32)
-		latents = ar.forward(autoregressive_latents.expand(B, -1) if autoregressive_latents.shape[0] != B else autoregressive_latents,
-							 text_tokens.expand(B, -1), text_lengths.expand(B), codes, wav_lengths.expand(B),
-							 return_latent=True, clip_inputs=False)
+		if latents_for not in ("all", "winner"):
+			raise ValueError("latents_for: 'all' or 'winner'")
+		pre_best, pre_scores = 0, None
+		if latents_for == "winner":
+			if self.clvp is not None and B > 1:
+				pre_scores = self.clvp(text_tokens, codes, return_loss=False)
+				pre_best = int(torch.argmax(pre_scores))
+			al_row = autoregressive_latents if autoregressive_latents.shape[0] == 1 else autoregressive_latents[pre_best:pre_best + 1]
+			latents = ar.forward(al_row, text_tokens, text_lengths, codes[pre_best:pre_best + 1], wav_lengths, return_latent=True, clip_inputs=False)
+		else:
+			latents = ar.forward(autoregressive_latents.expand(B, -1) if autoregressive_latents.shape[0] != B else autoregressive_latents,
+								 text_tokens.expand(B, -1), text_lengths.expand(B), codes, wav_lengths.expand(B),
+								 return_latent=True, clip_inputs=False)
 		# Candidate choice.  The reference scores the candidates with CLVP and reorders `codes` (inference.py:392-396) but diffuses the
 		# latents computed BEFORE that, in generation order (its own to-do at :370), trimmed where row 0 goes calm (:381-389).  Without
 		# a CLVP model this path keeps that observable behaviour for the first candidate: row 0, trimmed by row 0.  With one
 		# (`TTSHotPath(..., clvp=)`) it does what the to-do asks for: the best-scoring candidate's latents, trimmed by its own codes.
 		mark("latent_pass")
-		best, scores = 0, None
-		if self.clvp is not None and B > 1:
+		best, scores = pre_best, pre_scores
+		if latents_for == "all" and self.clvp is not None and B > 1:
 			scores = self.clvp(text_tokens, codes, return_loss=False)
 			best = int(torch.argmax(scores))
-		latents = trim_calm_tokens(codes[best:best + 1], latents[best:best + 1])
+		latents = trim_calm_tokens(codes[best:best + 1], latents[best:best + 1] if latents_for == "all" else latents)
 		T = latents.shape[1] * 4 * 24000 // 22050
 		E = diff.timestep_independent(latents, diffusion_latents, T, False)
 		noise = torch.randn((1, 100, T), device=dev) * diffusion_temp
