@@ -153,8 +153,8 @@ int ttk_exponential_like_torch(float* out, int64_t numel, int64_t seed, int64_t 
 /* Several text lines prefilled as ONE decode batch (no reference counterpart: TTS.inference walks the lines of a text one by one,
  * inference.py:244-246, streaming the weights again for each line's 16 candidates).  Line g: conditioning latent cond_latents[g] (f32 [n_lines][model_dim]),
  * text ids text[sum(text_len[:g]) ...] (device int64, concatenated), text_len[g] of them (HOST int array); it occupies candidates
- * [g * rows_per_line, (g + 1) * rows_per_line).  logits_out f32 [n_lines * rows_per_line][number_mel_codes].  The decode entries then step all
- * candidates together, each with the cache length of its own line, and every row's logits are bit for bit those of ttk_ar_prefill / ttk_ar_decode
+ * [g * rows_per_line, (g + 1) * rows_per_line).  logits_out f32 [n_lines * rows_per_line][number_mel_codes].  The prefixes are right-aligned in the cache (one cache length for the batch); the decode entries
+ * then step all candidates together, the attention reading every candidate's keys from where its line begins, and every row's logits are bit for bit those of ttk_ar_prefill / ttk_ar_decode
  * on its line alone.  With ttk_ar_set_noise, rng_args[5] = rows_per_line makes every line draw the same [rows_per_line, V] noise, as the reference's
  * reseeding to 0 per line does.                                                                                                   */
 int ttk_ar_prefill_lines(ttk_ar* h, const float* cond_latents, const int64_t* text, const int* text_len, int n_lines, int rows_per_line,

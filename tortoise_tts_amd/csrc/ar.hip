@@ -84,8 +84,9 @@ struct ttk_ar {
 	float *text_emb, *mel_emb, *mel_pos, *text_pos;
 	void *kc, *vc;          // [layers][max_batch][H][max_ctx][64]
 	size_t kv_layer_stride; // elements
-	int* d_pos;             // device: [0] valid cache rows (first line), [1] rows of the shared prefix, then row_off[max_batch], row_grp[max_batch]
-	int* d_rowoff; int* d_rowgrp;    // per candidate: extra cache rows relative to [0] / first candidate of its line (ttk_ar_prefill_lines)
+	int* d_pos;             // device: [0] valid cache rows, [1] rows of the shared prefix; then, 8-byte aligned, row_info[max_batch]
+	int2* d_rowinfo;        // per candidate {first cache row, first candidate of its line}: line batches (ttk_ar_prefill_lines), prefixes right-aligned
+	int lines_mode = 0;     // the current generation was started by ttk_ar_prefill_lines: the attention launches read d_rowinfo
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
 	void* x_frag = nullptr; // T copy of x in A-fragment order [m_tile][d/32][64][8]: operand of the folded-LayerNorm launches
@@ -115,7 +116,7 @@ struct ttk_ar {
 	int Pmax = 0;           // longest prefix of the batch (capacity checks); == P for one line
 };
 
-static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipStream_t s, int kv_row0 = 0) {
+static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipStream_t s, int kv_row0 = 0, int kv_t0 = 0) {
 	const int d = h->cfg.model_dim, H = h->cfg.heads, dt = h->dt;
 	const int rows = B * S;
 	TTK_TRY(h->ws_a.reserve((size_t)rows * d * h->es));
@@ -134,7 +135,7 @@ static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipSt
 			const size_t row0 = (size_t)kv_row0 * H * h->cfg.max_ctx * 64;      // first candidate slice written
 			char* kc = (char*)h->kc + ((size_t)l * h->kv_layer_stride + row0) * h->es;
 			char* vc = (char*)h->vc + ((size_t)l * h->kv_layer_stride + row0) * h->es;
-			launch_kv_scatter(dt, h->ws_qkv.p, B, S, H, kc, vc, h->cfg.max_ctx, s);
+			launch_kv_scatter(dt, h->ws_qkv.p, B, S, H, kc, vc, h->cfg.max_ctx, s, kv_t0);
 		}
 		AttnParams a = {};
 		a.qkv = h->ws_qkv.p; a.ld = 3 * d; a.q_off = 0; a.k_off = d; a.v_off = 2 * d; a.head_stride = 64;
@@ -196,11 +197,10 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		if (fold_qkv) { p.Wp = L.attn.wfrag_fold; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b; }
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
-		p.row_off = h->d_rowoff + r0;
 		launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
 		AttnDecodeParams a = {};
 		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 && h->share_prefix && h->nsplit == 1;
-		a.row_off = h->d_rowoff + r0; a.row_grp = r0 == 0 ? h->d_rowgrp : nullptr;
+		a.row_info = h->lines_mode && r0 == 0 ? h->d_rowinfo : nullptr;
 		launch_attn_decode(dt, a, s);
 		p = {};
 		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
@@ -294,7 +294,7 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	AR_TRY(h->arena.alloc(&h->kc, h->kv_layer_stride * cfg->layers * h->es));
 	AR_TRY(h->arena.alloc(&h->vc, h->kv_layer_stride * cfg->layers * h->es));
 	AR_TRY(h->arena.alloc((void**)&h->d_pos, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)));
-	h->d_rowoff = h->d_pos + 4; h->d_rowgrp = h->d_rowoff + cfg->max_batch;
+	h->d_rowinfo = (int2*)(h->d_pos + 4);
 	if (hipMemset(h->d_pos, 0, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
@@ -381,8 +381,7 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, S, s);
 	launch_set_int(h->d_pos + 1, shared ? S : 0, s);      // rows of the shared prefix (AttnDecodeParams.shared_rows): device-resident, like the cache length
-	launch_fill_int(h->d_rowoff, 0, 2 * c.max_batch, s);  // one line: no per-row offsets, every candidate's prefix owner is candidate 0
-	h->B = B; h->P = h->Pmax = Tt + 3; h->k = 0; h->ready = 1;
+	h->B = B; h->P = h->Pmax = Tt + 3; h->k = 0; h->ready = 1; h->lines_mode = 0;
 	h->shared_rows = shared ? S : 0;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
@@ -409,25 +408,24 @@ int ttk_ar_prefill_lines(ttk_ar* h, const float* cond_latents, const int64_t* te
 	hipStream_t s = (hipStream_t)stream;
 	TTK_TRY(h->ws_x.reserve((size_t)Smax * d * sizeof(float)));
 	float* x = (float*)h->ws_x.p;
-	const int S0 = text_len[0] + 4;
 	int64_t toff = 0;
 	for (int g = 0; g < n_lines; ++g) {
-		const int Tt = text_len[g], S = Tt + 4, r0 = g * rows_per_line;
+		// prefixes right-aligned at Smax: the cache length is then ONE number for all candidates (the c_attn epilogue appends every row at
+		// *d_pos, as for one line) and only the attention needs to know where a candidate's rows begin
+		const int Tt = text_len[g], S = Tt + 4, r0 = g * rows_per_line, start = Smax - S;
 		const int64_t total = (int64_t)S * (d / 4);
 		hipLaunchKernelGGL(k_build_prefill_emb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cond_latents + (size_t)g * d, 1, text + toff, Tt, 1, d,
 						   h->text_emb, h->text_pos, h->mel_emb, h->mel_pos, c.start_text_token, c.stop_text_token, c.start_mel_token, x);
-		TTK_TRY(dense_forward(h, x, 1, S, true, s, r0));
+		TTK_TRY(dense_forward(h, x, 1, S, true, s, r0, start));
 		launch_copy_rows(x + (size_t)(S - 1) * d, 0, h->x + (size_t)r0 * d, d, rows_per_line, d, s);      // the line's last prefix row to all its candidates
-		launch_fill_int(h->d_rowoff + r0, S - S0, rows_per_line, s);
-		launch_fill_int(h->d_rowgrp + r0, r0, rows_per_line, s);
+		launch_fill_int2((int*)(h->d_rowinfo + r0), start, r0, rows_per_line, s);
 		toff += Tt;
 	}
-	if (B < c.max_batch) { launch_fill_int(h->d_rowoff + B, 0, c.max_batch - B, s); launch_fill_int(h->d_rowgrp + B, 0, c.max_batch - B, s); }
 	head_launch(h, B, logits_out, nullptr, s);
-	launch_set_int(h->d_pos, S0, s);
-	launch_set_int(h->d_pos + 1, S0, s);
-	h->B = B; h->P = text_len[0] + 3; h->Pmax = Smax - 1; h->k = 0; h->ready = 1;
-	h->shared_rows = S0;
+	launch_set_int(h->d_pos, Smax, s);
+	launch_set_int(h->d_pos + 1, Smax, s);
+	h->B = B; h->P = h->Pmax = Smax - 1; h->k = 0; h->ready = 1; h->lines_mode = 1;
+	h->shared_rows = Smax;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }

@@ -349,7 +349,7 @@ __device__ __forceinline__ int64_t decode_out_index(const AttnDecodeParams& p, i
 	return ((((int64_t)(b >> 4) * (p.H * HD / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (b & 15)) * 8 + (n & 7));
 }
 
-template <typename T, int NW, int UN>
+template <typename T, int NW, int UN, bool ROWS = false>
 __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	typedef typename Frag<T>::type FragT;
 	constexpr int NP = NW * 8;           // (wave, slot) partial softmaxes
@@ -360,16 +360,17 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 #ifdef TTK_ABL      // diagnostic builds only (tests/diag/ar_ablate.sh): 256 = the whole kernel, 128 = the K / V loads
 	if (TTK_ABL & 256) return;
 #endif
-	// several text lines in one batch: candidate b's prefix is row_off[b] rows longer than the first line's, and its shared prefix rows live
-	// in the slice of the first candidate of ITS line
-	const int off = p.row_off ? p.row_off[b] : 0, grp = p.row_grp ? p.row_grp[b] : 0;
-	const int n = min(p.d_pos[0] + 1 + off, p.max_ctx);
+	// ROWS: several text lines in one batch, prefixes right-aligned.  Candidate b's keys are cache rows [start, d_pos + 1) -- numbered from 0 here,
+	// so they are dealt to the waves exactly as in a batch of its own -- and its shared prefix rows live in the slice of its line's first candidate
+	int start = 0, grp = 0;
+	if (ROWS) { const int2 ri = p.row_info[b]; start = ri.x; grp = ri.y; }
+	const int n = min(p.d_pos[0] + 1, p.max_ctx) - start;
 	// rows [0, shared) are read from the line's first candidate.  The count sits next to the cache length in device memory, not in the kernel
 	// arguments: a captured token step is replayed for later calls with other prefix lengths
 	const int sh0 = p.shared_rows ? p.d_pos[1] : 0;
-	const int shared = sh0 > 0 ? sh0 + off : 0;
-	const T* Kc = (const T*)p.kcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
-	const T* Vc = (const T*)p.vcache + ((int64_t)b * p.H + h) * p.max_ctx * HD;
+	const int shared = sh0 > 0 ? sh0 - start : 0;
+	const T* Kc = (const T*)p.kcache + (((int64_t)b * p.H + h) * p.max_ctx + start) * HD;
+	const T* Vc = (const T*)p.vcache + (((int64_t)b * p.H + h) * p.max_ctx + start) * HD;
 	const int64_t to_shared = -(int64_t)(b - grp) * p.H * p.max_ctx * HD;      // element offset from this candidate's slice to its line's first
 	float q[8];
 	{
@@ -452,7 +453,8 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 
 template <typename T, int NW, int UN>
 static void launch_attn_decode_t(const AttnDecodeParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-	hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
+	if (p.row_info) hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN, true>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
+	else hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
 }
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {
 	hipEvent_t ea = nullptr, eb = nullptr;      // kernel start / stop timestamps when profiling (prof_pair)
@@ -473,7 +475,7 @@ void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ prefill KV -> cache
 template <typename T>
-__global__ void k_kv_scatter(const T* qkv, int B, int S, int H, T* kc, T* vc, int max_ctx) {
+__global__ void k_kv_scatter(const T* qkv, int B, int S, int H, T* kc, T* vc, int max_ctx, int t0) {
 	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 8 elements
 	const int d = H * HD;
 	const int64_t total = (int64_t)B * S * (d / 8);
@@ -484,16 +486,16 @@ __global__ void k_kv_scatter(const T* qkv, int B, int S, int H, T* kc, T* vc, in
 	const int c = c8 * 8, h = c >> 6, dd = c & 63;
 	typedef typename Frag<T>::type FragT;
 	const T* src = qkv + row * (3 * d);
-	const int64_t dst = (((int64_t)b * H + h) * max_ctx + t) * HD + dd;
+	const int64_t dst = (((int64_t)b * H + h) * max_ctx + t0 + t) * HD + dd;      // t0: first cache row (right-aligned prefixes of a line batch)
 	*(FragT*)(kc + dst) = *(const FragT*)(src + d + c);
 	*(FragT*)(vc + dst) = *(const FragT*)(src + 2 * d + c);
 }
-void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcache, void* vcache, int max_ctx, hipStream_t s) {
+void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcache, void* vcache, int max_ctx, hipStream_t s, int t0) {
 	const int64_t total = (int64_t)B * S * (H * HD / 8);
 	const int grid = (int)((total + 255) / 256);
-	if (dt == DT_BF16) hipLaunchKernelGGL((k_kv_scatter<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)qkv, B, S, H, (bf16*)kcache, (bf16*)vcache, max_ctx);
-	else if (dt == DT_F16) hipLaunchKernelGGL((k_kv_scatter<f16>), dim3(grid), dim3(256), 0, s, (const f16*)qkv, B, S, H, (f16*)kcache, (f16*)vcache, max_ctx);
-	else hipLaunchKernelGGL((k_kv_scatter<float>), dim3(grid), dim3(256), 0, s, (const float*)qkv, B, S, H, (float*)kcache, (float*)vcache, max_ctx);
+	if (dt == DT_BF16) hipLaunchKernelGGL((k_kv_scatter<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)qkv, B, S, H, (bf16*)kcache, (bf16*)vcache, max_ctx, t0);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_kv_scatter<f16>), dim3(grid), dim3(256), 0, s, (const f16*)qkv, B, S, H, (f16*)kcache, (f16*)vcache, max_ctx, t0);
+	else hipLaunchKernelGGL((k_kv_scatter<float>), dim3(grid), dim3(256), 0, s, (const float*)qkv, B, S, H, (float*)kcache, (float*)vcache, max_ctx, t0);
 }
 
 }  // namespace ttk

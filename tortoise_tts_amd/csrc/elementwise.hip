@@ -11,6 +11,8 @@ void launch_set_int(int* p, int v, hipStream_t s) { hipLaunchKernelGGL(k_set_int
 void launch_add_int(int* p, int v, hipStream_t s) { hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s, p, v); }
 __global__ void k_fill_int(int* p, int v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 void launch_fill_int(int* p, int v, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_fill_int, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
+__global__ void k_fill_int2(int* p, int a, int b, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { p[2 * i] = a; p[2 * i + 1] = b; } }
+void launch_fill_int2(int* p, int a, int b, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_fill_int2, dim3((n + 255) / 256), dim3(256), 0, s, p, a, b, n); }
 
 // out[r] = A[ia[r]] + Bt[ib[r]]      (unified_voice.py:582,590,641: embedding + learned position embedding)
 __global__ void k_gather_add(const float* A, const int* ia, const float* Bt, const int* ib, float* out, int rows, int d) {

@@ -198,7 +198,6 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	// the cache row the c_attn epilogue appends at: requested now (first in the vmcnt order), not as one more dependent round trip at the end
 	int kv_pos = 0;
 	if (p.mode == SK_QKV) kv_pos = *p.d_pos;
-	int kv_off[MT];                // per-row extra (lines of different length decoded as one batch)
 	// mel_head launch of a decode step: one thread advances the cache length for the next step (nothing in this launch reads it)
 	if (p.mode == SK_STORE_F32 && p.d_pos && blockIdx.x == 0 && threadIdx.x == 0) *(int*)p.d_pos += 1;
 	// Epilogue role of the first 256 threads: element (row 4*(l2>>4)+r of each m-tile, column l2&15) of the 16-wide output tile.  Its
@@ -215,16 +214,14 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		if (p.bias) bias = p.bias[nn];
 		if (FOLD) fcs = p.g1[nn];            // column sum of the folded matrix (cold, like the bias: left to the epilogue it is a dependent trip to HBM)
 		const bool noise = p.mode == SK_STORE_F32 && p.qbuf;
-		const bool rowpos = p.mode == SK_QKV && p.row_off;
 		if (noise) rng = *(const RngArgs*)p.slab;
 #pragma unroll
 		for (int mt = 0; mt < MT; ++mt) {
-			res[mt] = 0.f; draw[mt] = 0; kv_off[mt] = 0;
+			res[mt] = 0.f; draw[mt] = 0;
 			int m = mt * 16 + 4 * (l2 >> 4) + (r & 3);
 			m = m < p.M ? m : p.M - 1;
 			if (p.mode == SK_RESIDUAL) res[mt] = p.out_f32[(int64_t)m * p.ldc + nn];
 			if (noise) draw[mt] = ((const int64_t*)p.tickets)[m];
-			if (rowpos) kv_off[mt] = p.row_off[m];
 		}
 	}
 	if (LN) { ln_load(wave); ln_load_affine(); }
@@ -399,7 +396,12 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		if (p.mode == SK_STORE_F32) {
 			p.out_f32[(int64_t)m * p.ldc + n] = v;
 			// mel head: the multinomial noise of the sampling launch that follows, one value per logit (SkinnyParams.qbuf in this mode)
-			if (p.qbuf) p.qbuf[(int64_t)m * p.ldc + n] = torch_exponential_at(rng, draw[mt], (rng.row0 + (rng.group > 0 ? (p.max_ctx + m) % rng.group : p.max_ctx + m)) * (int64_t)p.N + n);   // max_ctx: first row of this launch's row group
+			if (p.qbuf) {
+				int mrow = p.max_ctx + m;                  // max_ctx: first row of this launch's row group
+				const int grp = (int)rng.group;            // line batch: every line draws the same rows (a handful of subtractions, not a division routine in every instantiation)
+				if (grp > 0) while (mrow >= grp) mrow -= grp;
+				p.qbuf[(int64_t)m * p.ldc + n] = torch_exponential_at(rng, draw[mt], (rng.row0 + mrow) * (int64_t)p.N + n);
+			}
 		} else if (p.mode == SK_RESIDUAL) {
 			p.out_f32[(int64_t)m * p.ldc + n] = res[mt] + v;
 			if (p.out_T) ((T*)p.out_T)[((((int64_t)mt * (p.N / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (m & 15)) * 8 + (n & 7))] = cvt<T>(res[mt] + v);
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 			} else {
 				const int h = c >> 6, dd = c & 63;
 				T* cache = (T*)(which == 1 ? p.kcache : p.vcache);
-				const int pos = kv_pos + kv_off[mt];
+				const int pos = kv_pos;
 				if (pos < p.max_ctx) cache[(((int64_t)m * p.H + h) * p.max_ctx + pos) * 64 + dd] = cvt<T>(v);   // guard: never write past the cache
 			}
 		}

@@ -96,7 +96,6 @@ struct SkinnyParams {
 	// SK_STORE_F32 with qbuf != null (mel head): qbuf[m][n] (row stride ldc) receives the Exp(1) noise torch.multinomial would draw for logit
 	// (m, n) -- `slab` then points to a device RngArgs and `tickets` to the per-row int64 draw counters (ttk_rng.h)
 	float* qbuf; void* kcache; void* vcache; const int* d_pos; int max_ctx, H; float q_scale;
-	const int* row_off;         // SK_QKV, optional [M]: row m appends at *d_pos + row_off[m] (lines of different length in one batch)
 	// optional split-K over workgroups: slab f32 [n_tiles][ksplit][MT][256], tickets int [n_tiles] (zero between launches)
 	int ksplit; float* slab; int* tickets;
 	// narrow mode (plain A only, excludes ksplit): N/4 workgroups of 4 columns each instead of N/16 of 16 -- for the N = d projections
@@ -154,8 +153,9 @@ struct AttnDecodeParams {
 	int ctx_hint;             // host-side copy of the key count (profiling only; stale under graph replay)
 	void* out;                // T [B][H*64], or (out_frag) MFMA-fragment order [m_tile][H*2][lane][8] for the projection that follows
 	int out_frag;
-	const int* row_off;       // optional [B]: candidate b's cache holds row_off[b] more rows than d_pos says (several text lines decoded as one
-	const int* row_grp;       // batch, ttk_ar_prefill_lines); optional [B]: first candidate of b's line = the owner of its shared prefix rows
+	const int2* row_info;     // null, or [B] {start, first}: several text lines decoded as one batch (ttk_ar_prefill_lines).  The lines' prefixes are
+	                          // right-aligned: candidate b's cache begins at row `start` (its line is that much shorter than the longest), and `first`
+	                          // = first candidate of its line, the owner of its shared prefix rows.  Selects the kernel variant that reads it.
 	int shared_rows;          // != 0: cache rows [0, d_pos[1]) are identical for every candidate (one conditioning latent + one text line: the
 	                          // prefill computed the same prefix B times): read them from candidate 0's slice, which the 16 workgroups of a head
 	                          // -- equal blockIdx.x, so one XCD -- then share in L2 instead of fetching B copies from HBM
@@ -163,11 +163,12 @@ struct AttnDecodeParams {
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s);
 
 // copy k/v of a dense qkv buffer [B*S][3d] (GPT-2 order q|k|v, head h at h*64) into the cache rows [0,S)
-void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcache, void* vcache, int max_ctx, hipStream_t s);
+void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcache, void* vcache, int max_ctx, hipStream_t s, int t0 = 0);
 
 // ---------------------------------------------------------------- elementwise (elementwise.hip)
 void launch_set_int(int* p, int v, hipStream_t s);
 void launch_fill_int(int* p, int v, int n, hipStream_t s);
+void launch_fill_int2(int* p, int a, int b, int n, hipStream_t s);      // n pairs {a, b}
 void launch_add_int(int* p, int v, hipStream_t s);
 // out[r][:] = A[ia[r]][:] + Bt[ib[r]][:]   (f32 tables, f32 out); ia/ib int32 device arrays; Bt may be null
 void launch_gather_add(const float* A, const int* ia, const float* Bt, const int* ib, float* out, int rows, int d, hipStream_t s);
