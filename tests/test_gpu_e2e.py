@@ -247,3 +247,21 @@ def test_latents_for_the_winner_only_gives_the_same_bits(dtype):
 		assert torch.equal(a_all["latents"], a_one["latents"]) and torch.equal(m_all, m_one)
 	with pytest.raises(ValueError):
 		TTSHotPath(ar, df).inference(text, al.to(DEV), dl.to(DEV), latents_for="some", **kw)
+
+
+def test_pipelined_lines_with_a_scorer_equal_sequential_calls(small):
+	"""`inference_lines` (lines sampled as one decode batch, diffusion pipelined) picks each line's candidate with CLVP as `inference` does"""
+	from tortoise_tts_amd.clvp import CLVP
+	from tortoise_tts_amd.inference import TTSHotPath
+	tts0, _, _ = small
+	ccfg = W.CLVPConfig(dim=128, depth=2, heads=2, num_speech_tokens=8194)
+	tts = TTSHotPath(tts0.autoregressive, tts0.diffusion, clvp=CLVP(W.synth_state_dict(W.clvp_shapes(ccfg), 34), ccfg, dtype="f32", device=DEV))
+	lines = [_inputs(400 + i, Tt)[0] for i, Tt in enumerate((6, 13, 4))]
+	_, al, dl = _inputs(450, 4)
+	kw = dict(max_ar_steps=14, max_diffusion_steps=3, candidates=2, suppress_tokens=[W.AR_SMALL.stop_mel_token])
+	with torch.inference_mode():
+		seq = [tts.inference(t, al.to(DEV), dl.to(DEV), return_all=True, **kw) for t in lines]
+		pipe = tts.inference_lines(lines, al.to(DEV), dl.to(DEV), **kw)
+	torch.cuda.synchronize()
+	for (m0, s0, _a), (m1, s1, _c) in zip(seq, pipe):
+		assert s0 == s1 and torch.equal(m0, m1)

@@ -246,7 +246,10 @@ class TTSHotPath:
 					latents = ar.forward(autoregressive_latents.expand(B, -1) if autoregressive_latents.shape[0] != B else autoregressive_latents,
 										 text_tokens.expand(B, -1), torch.tensor([text_tokens.shape[1]], dtype=torch.int32).expand(B), codes,
 										 torch.tensor([M * ar.mel_length_compression]).expand(B), return_latent=True, clip_inputs=False)
-					latents = trim_calm_tokens(codes, latents)[:1]          # host copy of codes[0]: the AR phase of this line is complete
+					best = 0                                                # candidate choice as in `inference`
+					if self.clvp is not None and B > 1:
+						best = int(torch.argmax(self.clvp(text_tokens, codes, return_loss=False)))
+					latents = trim_calm_tokens(codes[best:best + 1], latents[best:best + 1])     # host copy of the codes: the AR phase of this line is complete
 					T = latents.shape[1] * 4 * 24000 // 22050
 					noise = torch.randn((1, 100, T), device=dev) * diffusion_temp
 					for _ in range(max_diffusion_steps):                    # DDIM's ignored per-step draws, in reference order

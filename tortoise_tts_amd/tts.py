@@ -68,13 +68,18 @@ class TTS:
 			raise ValueError("TTS was built without a vocoder")
 		ar_latent, diff_latent = self.encode_audio(references, references_sr)["latent"]
 		set_seed(seed)
-		wavs = []
+		lines = []
 		for line in text.split("\n"):
 			tokens = self.encode_text(line).to(self.device)[None]
 			if tokens.shape[1] == 0:
 				raise ValueError("empty line (the reference fails inside the embedding here)")
-			wav, sr = self.hot.inference_to_wav(tokens, ar_latent, diff_latent, max_ar_steps=max_ar_steps, max_diffusion_steps=max_diffusion_steps,
-												ar_temp=ar_temp, diffusion_temp=diffusion_temp, top_p=top_p, top_k=top_k, repetition_penalty=repetition_penalty,
-												length_penalty=length_penalty, diffusion_sampler=diffusion_sampler, cond_free=cond_free, candidates=candidates)
-			wavs.append(wav)
+			lines.append(tokens)
+		kw = dict(max_ar_steps=max_ar_steps, max_diffusion_steps=max_diffusion_steps, ar_temp=ar_temp, diffusion_temp=diffusion_temp, top_p=top_p, top_k=top_k,
+				  repetition_penalty=repetition_penalty, length_penalty=length_penalty, cond_free=cond_free, candidates=candidates)
+		if len(lines) > 1 and diffusion_sampler == "ddim":
+			# several lines: their sampling as one decode batch, the diffusion of a line under the sampling of later ones (TTSHotPath.inference_lines:
+			# the same waveforms as the line-by-line loop of inference.py:237-422, which is what the else branch runs)
+			wavs = [self.hot.vocoder.inference(mels) for mels, _, _ in self.hot.inference_lines(lines, ar_latent, diff_latent, **kw)]
+		else:
+			wavs = [self.hot.inference_to_wav(tokens, ar_latent, diff_latent, diffusion_sampler=diffusion_sampler, **kw)[0] for tokens in lines]
 		return torch.concat(wavs, dim=-1), SAMPLE_RATE
