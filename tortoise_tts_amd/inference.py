@@ -243,13 +243,14 @@ class TTSHotPath:
 					ar.position_rng_after_line(i % G)       # the generators as this line's own `generate` leaves them
 					codes = fix_stop_tokens(batch_codes[i % G], ar.stop_mel_token)
 					B, M = codes.shape
-					latents = ar.forward(autoregressive_latents.expand(B, -1) if autoregressive_latents.shape[0] != B else autoregressive_latents,
-										 text_tokens.expand(B, -1), torch.tensor([text_tokens.shape[1]], dtype=torch.int32).expand(B), codes,
-										 torch.tensor([M * ar.mel_length_compression]).expand(B), return_latent=True, clip_inputs=False)
 					best = 0                                                # candidate choice as in `inference`
 					if self.clvp is not None and B > 1:
 						best = int(torch.argmax(self.clvp(text_tokens, codes, return_loss=False)))
-					latents = trim_calm_tokens(codes[best:best + 1], latents[best:best + 1])     # host copy of the codes: the AR phase of this line is complete
+					# the dense latent pass on the chosen row only (rows are independent: the bits `inference` gets from the all-candidates pass)
+					al_row = autoregressive_latents if autoregressive_latents.shape[0] == 1 else autoregressive_latents[best:best + 1]
+					latents = ar.forward(al_row, text_tokens, torch.tensor([text_tokens.shape[1]], dtype=torch.int32), codes[best:best + 1],
+										 torch.tensor([M * ar.mel_length_compression]), return_latent=True, clip_inputs=False)
+					latents = trim_calm_tokens(codes[best:best + 1], latents)     # host copy of the codes: the AR phase of this line is complete
 					T = latents.shape[1] * 4 * 24000 // 22050
 					noise = torch.randn((1, 100, T), device=dev) * diffusion_temp
 					for _ in range(max_diffusion_steps):                    # DDIM's ignored per-step draws, in reference order
