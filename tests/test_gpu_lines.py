@@ -85,3 +85,13 @@ def test_argument_errors():
 		ar.inference_speech_lines(al, _texts([3, 55]), num_return_sequences=2, **kw)
 	with pytest.raises(IndexError):
 		ar.inference_speech_lines(al, [torch.full((1, 4), 300, device=DEV), _texts([3])[0]], num_return_sequences=2, **kw)
+
+
+def test_typical_sampling_falls_back_to_the_per_line_calls():
+	cfg = W.AR_SMALL
+	ar = _model(cfg, "f32", max_batch=8, max_ctx=96)
+	al = torch.randn(1, cfg.model_dim, generator=torch.Generator().manual_seed(3)).to(DEV)
+	kw = dict(do_sample=True, temperature=0.9, top_k=0, max_generate_length=12, typical_sampling=True, typical_mass=0.8)
+	_check(ar, al, _texts([5, 8], seed=2), 3, kw)
+	with pytest.raises(NotImplementedError):
+		ar.inference_speech_lines(al, _texts([5, 8]), num_return_sequences=2, do_sample=True, input_tokens=torch.zeros(1, 2))

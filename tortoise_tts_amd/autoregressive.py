@@ -192,11 +192,20 @@ class UnifiedVoice:
 		texts = list(texts)
 		if any(t.dim() != 2 or t.shape[0] != 1 for t in texts):
 			raise NotImplementedError("texts: a list of [1, Tt] id tensors, one per line")
-		if len(texts) == 1:
-			ids = self.inference_speech(speech_conditioning_latent, texts[0], num_return_sequences=num_return_sequences,
-										max_generate_length=max_generate_length, **hf_generate_kwargs)
-			self.last_generate_lines = [dict(self.last_generate, seed=hf_generate_kwargs.get("seed", 0))]
-			return [ids]
+		if hf_generate_kwargs.get("input_tokens") is not None:
+			raise NotImplementedError("input_tokens (prompted continuation) is not on the inference hot path")
+		hf_generate_kwargs.pop("input_tokens", None)
+		hf_generate_kwargs.pop("kv_cache", None)
+		typical = bool(hf_generate_kwargs.get("typical_sampling", False))
+		if len(texts) == 1 or typical:      # one line, or typical sampling (torch ops in front of the kernel, built per call): the per-line calls
+			out, self.last_generate_lines = [], []
+			for t in texts:
+				out.append(self.inference_speech(speech_conditioning_latent, t, num_return_sequences=num_return_sequences,
+												 max_generate_length=max_generate_length, **hf_generate_kwargs))
+				self.last_generate_lines.append(dict(self.last_generate, seed=hf_generate_kwargs.get("seed", 0)))
+			return out
+		hf_generate_kwargs.pop("typical_sampling", None)
+		hf_generate_kwargs.pop("typical_mass", None)
 		return self._generate_lines(speech_conditioning_latent, texts, num_return_sequences, max_generate_length, hf_generate_kwargs)
 
 	def position_rng_after_line(self, g: int):
