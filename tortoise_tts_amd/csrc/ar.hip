@@ -194,7 +194,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		SkinnyParams p = {};
 		p.Wp = L.attn.wfrag; p.w8 = L.attn.w8; p.wscale = L.attn.wscale; p.N = 3 * d; p.K = d; p.M = nrows; p.bias = L.attn.bias;
 		const bool fold_qkv = h->lnfold && whole && L.attn.wfrag_fold;
-		if (fold_qkv) { p.Wp = L.attn.wfrag_fold; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
+		if (fold_qkv) { p.Wp = L.attn.wfrag_fold; p.w8 = 0; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b; }
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
 		launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
@@ -209,7 +209,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		p = {};
 		p.Wp = L.fc.wfrag; p.w8 = L.fc.w8; p.wscale = L.fc.wscale; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
 		const bool fold_fc = h->lnfold && whole && L.fc.wfrag_fold;
-		if (fold_fc) { p.Wp = L.fc.wfrag_fold; p.bias = L.fc.bias_fold; p.g1 = L.fc.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
+		if (fold_fc) { p.Wp = L.fc.wfrag_fold; p.w8 = 0; p.bias = L.fc.bias_fold; p.g1 = L.fc.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b; }
 		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf; p.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		launch_skinny(dt, p, fold_fc ? wv_small : wv_prologue, s);
@@ -276,7 +276,7 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "attn.c_proj.weight", p + "attn.c_proj.bias", PK_KN, d, d, true, &L.proj));
 		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", PK_KN, 4 * d, d, true, &L.fc));
 		AR_TRY(upload_mat(h->arena, wm, h->wdt, p + "mlp.c_proj.weight", p + "mlp.c_proj.bias", PK_KN, d, 4 * d, true, &L.proj2));
-		if (h->wdt == h->dt) {   // not for fp8 weights: folding gamma in would change what gets rounded (TTK_FP8W is defined on the reference's matrices)
+		{   // (fp8 weights: the fold is taken of the rounded matrices and kept in bf16 -- TTK_FP8W stays "bf16 on the rounded weights")
 			AR_TRY(fold_layernorm(h->arena, wm, h->dt, p + "attn.c_attn.weight", p + "attn.c_attn.bias", p + "ln_1.weight", p + "ln_1.bias", &L.attn));
 			AR_TRY(fold_layernorm(h->arena, wm, h->dt, p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", p + "ln_2.weight", p + "ln_2.bias", &L.fc));
 		}
@@ -436,6 +436,7 @@ static int decode_impl(ttk_ar* h, const int64_t* tok, float* logits_out, float* 
 	const ttk_ar_config& c = h->cfg;
 	const int B = h->B, d = c.model_dim;
 	TTK_REQUIRE(h->Pmax + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "%s: KV cache full (max_ctx=%d)", who, c.max_ctx);
+	TTK_REQUIRE((h->lnfold && h->nsplit == 1) || B <= 32, TTK_E_STATE, "%s: the LayerNorm-prologue decode kernels (TTK_AR_LNFOLD=0 / TTK_AR_SPLIT) hold at most 32 candidates' rows in LDS; B=%d", who, B);
 	TTK_REQUIRE(h->k + 2 < c.max_mel_seq_len, TTK_E_STATE, "%s: mel position table exhausted (%d rows)", who, c.max_mel_seq_len);
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)

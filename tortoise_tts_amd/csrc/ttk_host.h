@@ -98,7 +98,7 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 			   int N, int K, bool frag, Mat* out, int ntap = 0);   // ntap: kernel size for PK_CONVK / PK_CONVT
 
 // For a PK_KN matrix uploaded with a fragment copy: build the folded-LayerNorm operands of the decode launch (see SkinnyParams.g1) from the
-// LayerNorm's gamma / beta.  Not available for fp8 weights (the fold would change what gets rounded).
+// LayerNorm's gamma / beta.  fp8 weights: folded AFTER the rounding, the folded operand held in the kernel type (see the definition).
 int fold_layernorm(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, const std::string& gname,
 				   const std::string& betaname, Mat* m);
 

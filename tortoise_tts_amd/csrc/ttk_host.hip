@@ -71,7 +71,7 @@ int upload_mat(Arena& ar, const WeightMap& wm, int dt, const std::string& wname,
 
 int fold_layernorm(Arena& ar, const WeightMap& wm, int dt, const std::string& wname, const std::string& bname, const std::string& gname,
 				   const std::string& betaname, Mat* m) {
-	TTK_REQUIRE(!m->w8 && m->wfrag && m->ntap == 1, TTK_E_ARG, "fold_layernorm('%s'): needs a plain fragment-order matrix", wname.c_str());
+	TTK_REQUIRE(m->wfrag && m->ntap == 1, TTK_E_ARG, "fold_layernorm('%s'): needs a fragment-order matrix", wname.c_str());
 	const ttk_weight_view *vw = wm.find(wname), *vb = wm.find(bname), *vg = wm.find(gname), *vbe = wm.find(betaname);
 	TTK_REQUIRE(vw && vb && vg && vbe, TTK_E_WEIGHT, "fold_layernorm: missing one of '%s', '%s', '%s', '%s'", wname.c_str(), bname.c_str(), gname.c_str(), betaname.c_str());
 	const int N = m->N, K = m->K;
@@ -94,6 +94,11 @@ int fold_layernorm(Arena& ar, const WeightMap& wm, int dt, const std::string& wn
 	if (rc == TTK_OK) rc = ar.alloc((void**)&m->csum, (size_t)N * 4);
 	if (rc == TTK_OK) rc = ar.alloc((void**)&m->bias_fold, (size_t)N * 4);
 	if (rc != TTK_OK) { cleanup(); return rc; }
+	// fp8 weights: the mode is defined on the reference's matrices, so those are rounded first (same scale as upload_mat) and the fold is taken
+	// of the ROUNDED matrix, in the kernel arithmetic -- what a bf16 handle built from the rounded weights computes, bit for bit.  The folded
+	// operand is a bf16 matrix (gamma o W^ is not on the fp8 grid): these two launches stream 2 bytes per weight, the decode step being bound by
+	// its launch chain, not by weight bytes
+	if (m->w8) launch_fp8_roundtrip(w, (int64_t)N * K, m->wscale, 0);
 	launch_bias_fold(w, be, b, K, N, m->bias_fold, 0);               // from the unscaled weights
 	launch_scale_kn(w, g, K, N, 0);
 	launch_pack_nk(dt, w, PK_KN, N, K, m->Npad, m->Kpad, wt, 0, 1);
