@@ -102,7 +102,7 @@ struct ttk_ar {
 	// owned 4 k-steps and half of its 16 load instructions re-read the last fragment -- on a path that is bound by what a CU can take in.
 	// More than 8 waves lose again (16 partial tiles to merge through LDS): 4 / 4 / 8 measured best in the 250-token loop (bf16, B = 16).
 	int wv_proj = 4, wv_proj2 = 8;
-	int wv_ln = 4;                    // ln_1 + c_attn and ln_2 + c_fc with the LayerNorm folded in; the LN-prologue form (fp8 weights) keeps 8
+	int wv_ln = 4;                    // ln_1 + c_attn and ln_2 + c_fc with the LayerNorm folded in; the LN-prologue form (TTK_AR_LNFOLD=0) keeps 8
 	int wv_head = 4;                  // waves per workgroup of the ln_f + final_norm + mel_head launch (TTK_AR_WV_HEAD): 513 n-tiles; with 8-wave
 	                                  // workgroups two fit a CU (512 slots), so tile 513 ran as a second round on an empty chip; 4-wave ones fit four
 	int hfrag = 1;                // MLP activations of the decode step in MFMA-fragment order (TTK_AR_HFRAG=0: row-major)
