@@ -24,10 +24,10 @@ same workload, rank 0, N = 1 only).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -52,12 +52,13 @@ def parse():
 	return ap.parse_args()
 
 
-def cpu_baseline(seed):
+def cpu_baseline(seed, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL_TOKENS, n_ddim=DDIM_STEPS, n_lines=1, light=False):
 	"""The CPU oracle (oracle/tortoise_oracle.py, kind 'port') on a bounded sample of the same workload, on this box's host cores, as
 	BASELINE.md section 3 lays out: phases timed separately with time.perf_counter after a warm-up, medians of repeated samples --
-	prefill at B=16 (second run timed), KV-cached decode steps at B=16 (median of 3 groups of 8 steps, scaled to 250), the latent
-	pass on the 16 candidates at its full length (one run), DDIM steps at the FULL T = 1088 (1 warm-up + median of 8 steps, each a
-	conditioned + a conditioning-free evaluation, scaled to 80)."""
+	prefill at B = n_cand (second run timed), KV-cached decode steps (median of 3 groups of 8 steps, scaled to n_mel), the latent
+	pass on the candidates at its full length (one run), DDIM steps at the FULL T (1 warm-up + median of 8 steps, each a
+	conditioned + a conditioning-free evaluation, scaled to n_ddim).  light (configs[3], where one DDIM step at T = 2176 is tens of seconds
+	of CPU time): groups of 4 decode steps, the latent pass on 4 candidates scaled to n_cand, 1 warm-up + 2 DDIM steps."""
 	sys.path.insert(0, os.path.join(ROOT, "oracle"))
 	import statistics
 	import tortoise_oracle as O
@@ -70,17 +71,18 @@ def cpu_baseline(seed):
 	cores = max(1, min(cores, 16))
 	torch.set_num_threads(cores)
 	g = torch.Generator().manual_seed(seed)
-	T = MEL_TOKENS * 4 * 24000 // 22050
+	T = n_mel * 4 * 24000 // 22050
+	grp, n_lat, n_steps = (4, min(4, n_cand), 2) if light else (8, n_cand, 8)
 	with torch.inference_mode():
 		ar = O.AROracle(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL)
-		text = torch.randint(1, 255, (1, TEXT_TOKENS), generator=g)
+		text = torch.randint(1, 255, (1, n_text), generator=g)
 		cond = torch.randn(1, 1024, generator=g)
 		prefix = ar.prefix_embeddings(cond, text)
-		ar.prefill(prefix, CANDIDATES)                                   # warm-up
+		ar.prefill(prefix, n_cand)                                       # warm-up
 		t0 = time.perf_counter()
-		logits, past, _ = ar.prefill(prefix, CANDIDATES)
+		logits, past, _ = ar.prefill(prefix, n_cand)
 		t_prefill = time.perf_counter() - t0
-		tok = torch.randint(0, 8192, (CANDIDATES,), generator=g)
+		tok = torch.randint(0, 8192, (n_cand,), generator=g)
 		k = 0
 		for _ in range(2):                                               # warm-up steps
 			k += 1
@@ -88,69 +90,81 @@ def cpu_baseline(seed):
 		groups = []
 		for _ in range(3):
 			t0 = time.perf_counter()
-			for _ in range(8):
+			for _ in range(grp):
 				k += 1
 				_, past, _ = ar.decode(tok, k, past)
-			groups.append((time.perf_counter() - t0) / 8)
+			groups.append((time.perf_counter() - t0) / grp)
 		t_dec = statistics.median(groups)
 		del past
-		codes = torch.randint(0, 8192, (CANDIDATES, MEL_TOKENS), generator=g)
+		codes = torch.randint(0, 8192, (n_lat, n_mel), generator=g)
 		t0 = time.perf_counter()
-		ar.forward_latents(cond.repeat(CANDIDATES, 1), text.repeat(CANDIDATES, 1), codes)
-		t_lat = time.perf_counter() - t0
+		ar.forward_latents(cond.repeat(n_lat, 1), text.repeat(n_lat, 1), codes)
+		t_lat = (time.perf_counter() - t0) * n_cand / n_lat
 		del ar
 		d = O.DiffusionOracle(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL)
 		x = torch.randn(1, 100, T, generator=g)
 		E = torch.randn(1, 1024, T, generator=g)
-		sched = O.SpacedSchedule(steps=DDIM_STEPS)
-		x = sched.ddim_step(d, x, DDIM_STEPS - 1, E)                      # warm-up
+		sched = O.SpacedSchedule(steps=n_ddim)
+		x = sched.ddim_step(d, x, n_ddim - 1, E)                          # warm-up
 		steps = []
-		for i in range(8):
+		for i in range(n_steps):
 			t0 = time.perf_counter()
-			x = sched.ddim_step(d, x, DDIM_STEPS - 2 - i, E)
+			x = sched.ddim_step(d, x, n_ddim - 2 - i, E)
 			steps.append(time.perf_counter() - t0)
 		t_step = statistics.median(steps)
-	est = t_prefill + MEL_TOKENS * t_dec + t_lat + DDIM_STEPS * t_step
-	audio = T * 256 / 24000
+	est = n_lines * (t_prefill + n_mel * t_dec + t_lat + n_ddim * t_step)
+	audio = n_lines * T * 256 / 24000
 	return {"value": audio / est, "unit": "audio-sec/wall-sec", "cores": cores, "kind": "port",
 			"torch": torch.__version__, "seconds_per_utterance": est,
-			"sample": f"B=16: prefill (2nd run) {t_prefill:.2f} s + decode {t_dec * 1e3:.0f} ms/step (median of 3 groups of 8, scaled to {MEL_TOKENS}) + "
-					  f"latent pass on 16 candidates x {MEL_TOKENS} tokens {t_lat:.2f} s (one run) + DDIM {t_step:.2f} s/step at T={T} "
-					  f"(cond + cond-free evaluation; 1 warm-up, median of 8 steps, scaled to {DDIM_STEPS}); fp32, {cores} threads"}
+			"sample": f"B={n_cand}: prefill (2nd run) {t_prefill:.2f} s + decode {t_dec * 1e3:.0f} ms/step (median of 3 groups of {grp}, scaled to {n_mel}) + "
+					  f"latent pass on {n_lat} candidates x {n_mel} tokens" + (f" scaled to {n_cand}" if n_lat != n_cand else "") + f" {t_lat:.2f} s (one run) + DDIM {t_step:.2f} s/step at T={T} "
+					  f"(cond + cond-free evaluation; 1 warm-up, median of {n_steps} steps, scaled to {n_ddim})" + (f"; x {n_lines} lines" if n_lines > 1 else "") + f"; fp32, {cores} threads"}
 
 
-def phase_roofline(marks, dtype_name):
+def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL_TOKENS, n_ddim=DDIM_STEPS):
 	"""Per-phase roofline fractions (SURVEY.md section 8d / BASELINE.md section 4): AR decode is HBM-bound (weights streamed once per
-	token + the KV cache read), the latent pass and the DDIM loop are MFMA-bound.  `marks`: (name, event) pairs from
-	TTSHotPath.inference(phase_marks=...) of one step run exactly as the timed ones (captured graph, no instrumentation)."""
-	ms = {marks[i + 1][0]: marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)}
+	token + the KV cache read), the latent pass and the DDIM loop are MFMA-bound.  `marks_per_line`: one list of (name, event) pairs per text
+	line, from TTSHotPath.inference(phase_marks=...) / inference_sharded(phase_marks=...) of one step run exactly as the timed ones (captured
+	graph, no instrumentation); n_cand = candidates decoded on THIS GPU.  Peaks: 8 TB/s HBM; dense MFMA 2.5 PFLOP/s bf16 / f16, 157.3 TFLOP/s
+	f32; dtype fp8: the DDIM loop is graded against the 5 PFLOP/s fp8 peak (its ResBlock / AttentionBlock projection GEMMs run the fp8 MFMA; QK^T, PV
+	and the remaining convs run bf16 -- the stricter denominator is used for the whole phase), the latent pass against 2.5 (the AR handle's fp8 is
+	fp8 WEIGHTS on the bf16 MFMA)."""
+	ms = {}
+	for marks in marks_per_line:
+		for i in range(len(marks) - 1):
+			ms[marks[i + 1][0]] = ms.get(marks[i + 1][0], 0.0) + marks[i][1].elapsed_time(marks[i + 1][1])
+	L = len(marks_per_line)
 	e_w = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
 	e_kv = 4 if dtype_name == "f32" else 2
 	peak_f = 157.3e12 if dtype_name == "f32" else 2.5e15
-	P1 = TEXT_TOKENS + 4                                    # prefix rows incl. start_mel
-	# prefill: dense pass over P1 rows x B; decode step k (k = 1..M-1) reads a cache of P1 + k - 1 rows and writes one
+	peak_ddim = 5.0e15 if dtype_name == "fp8" else peak_f
+	P1 = n_text + 4                                    # prefix rows incl. start_mel
+	# prefill: dense pass over P1 rows (once: the candidates share the prefix); decode step k (k = 1..M-1) reads a cache of P1 + k - 1 rows and writes one
 	blocks, head = 377_886_720, 8_398_850 + 4_096
 	ar_bytes = 0.0
-	for k in range(1, MEL_TOKENS):
+	for k in range(1, n_mel):
 		ctx = P1 + k
-		ar_bytes += blocks * e_w + head * (2 if e_w == 1 else e_w) + CANDIDATES * 30 * 2 * ctx * 1024 * e_kv + CANDIDATES * 8194 * 4
-	prefill_flop = 2.0 * blocks * P1 * CANDIDATES + 2.0 * P1 * P1 * 1024 * 30 * CANDIDATES
-	S = TEXT_TOKENS + MEL_TOKENS + 5
-	lat_flop = 2.0 * blocks * S * CANDIDATES + 2.0 * S * S * 1024 * 30 * CANDIDATES
-	T = MEL_TOKENS * 4 * 24000 // 22050
+		ar_bytes += blocks * e_w + head * (2 if e_w == 1 else e_w) + n_cand * 30 * 2 * ctx * 1024 * e_kv + n_cand * 8194 * 4
+	ar_bytes *= L
+	prefill_flop = L * (2.0 * blocks * P1 * n_cand + 2.0 * P1 * P1 * 1024 * 30 * n_cand)
+	S = n_text + n_mel + 5
+	lat_flop = L * (2.0 * blocks * S * n_cand + 2.0 * S * S * 1024 * 30 * n_cand)
+	T = n_mel * 4 * 24000 // 22050
 	F = 236 * 1024 ** 2 * T + 52 * 1024 * T * T + 1_843_200 * T
-	ddim_flop = DDIM_STEPS * 2.0 * F
+	ddim_flop = L * n_ddim * 2.0 * F
 	ar_floor = ar_bytes / 8.0e12 * 1e3 + prefill_flop / peak_f * 1e3
 	out = {
 		"ar_decode": {"bound": "hbm", "algorithmic_bytes": ar_bytes, "prefill_flop": prefill_flop, "ms": ms["ar_decode"],
 					  "achieved_GBps": ar_bytes / (ms["ar_decode"] * 1e-3) / 1e9, "frac": ar_bytes / (ms["ar_decode"] * 1e-3) / 8.0e12,
-					  "floor_ms": ar_floor, "note": "prefill + 250 sampled tokens; bytes = 249 KV-cached steps (weights once per step + KV read + logits)"},
+					  "floor_ms": ar_floor, "note": f"prefill + {n_mel} sampled tokens; bytes = {n_mel - 1} KV-cached steps (weights once per step + KV read + logits)"},
 		"latent_pass": {"bound": "mfma", "flop": lat_flop, "ms": ms["latent_pass"], "achieved_TFLOPs": lat_flop / (ms["latent_pass"] * 1e-3) / 1e12,
 						"frac": lat_flop / (ms["latent_pass"] * 1e-3) / peak_f, "floor_ms": lat_flop / peak_f * 1e3},
 		"ddim": {"bound": "mfma", "flop": ddim_flop, "ms": ms["ddim"], "achieved_TFLOPs": ddim_flop / (ms["ddim"] * 1e-3) / 1e12,
-				 "frac": ddim_flop / (ms["ddim"] * 1e-3) / peak_f, "floor_ms": ddim_flop / peak_f * 1e3,
-				 "note": "timestep-independent conditioning + 80 steps x (cond + cond-free evaluation); flop = 160 F(T)"},
+				 "frac": ddim_flop / (ms["ddim"] * 1e-3) / peak_ddim, "peak_TFLOPs": peak_ddim / 1e12, "floor_ms": ddim_flop / peak_ddim * 1e3,
+				 "note": f"timestep-independent conditioning + {n_ddim} steps x (cond + cond-free evaluation); flop = {2 * n_ddim} F(T)"},
 	}
+	if L > 1:
+		out["lines"] = L
 	out["whole_step_floor_ms"] = out["ar_decode"]["floor_ms"] + out["latent_pass"]["floor_ms"] + out["ddim"]["floor_ms"]
 	out["whole_step_ms"] = sum(ms.values())
 	out["whole_step_frac_of_floor"] = out["whole_step_floor_ms"] / out["whole_step_ms"]
@@ -161,14 +175,72 @@ def log(msg):
 	print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def launcher_command(gpus, argv, port):
+	"""the command `python bench.py --gpus N` turns itself into when it was started WITHOUT a torch.distributed environment: one child rank per
+	GPU under torch.distributed.run (the same line the driver would use for N > 1), rendezvous on 127.0.0.1"""
+	return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+			"--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a):
+	"""`python bench.py --gpus N` (N > 1) as the driver starts the bench for N = 1: this process never touches the GPU (no torch import, no
+	HIP call) -- it starts N fresh ranks as CHILD processes (never an exec of a process that initialised the GPU), relays rank 0's JSON line
+	and exits with the children's status."""
+	with socket.socket() as sk:
+		sk.bind(("127.0.0.1", 0))
+		port = sk.getsockname()[1]
+	env = dict(os.environ)
+	env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+	env.setdefault("OMP_NUM_THREADS", "4")
+	cmd = launcher_command(a.gpus, sys.argv[1:], port)
+	log(f"no torch.distributed environment and --gpus {a.gpus}: starting {a.gpus} ranks: {' '.join(cmd)}")
+	proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+	lines = []
+	for line in proc.stdout:
+		line = line.rstrip("\n")
+		if line.startswith("{") and '"metric"' in line:
+			lines.append(line)
+		else:
+			print(line, file=sys.stderr, flush=True)      # anything else the ranks print is not the result line
+	rc = proc.wait()
+	if rc == 0 and len(lines) != 1:
+		log(f"expected ONE result line from rank 0, got {len(lines)}")
+		rc = 1
+	for line in lines[-1:]:
+		print(line, flush=True)
+	return rc
+
+
+def launch_probe(a):
+	"""TTK_BENCH_PROBE=1 (tests/test_host_logic.py, no GPU): the ranks only rendezvous (gloo), count themselves and rank 0 prints a line --
+	the launcher branch, the environment hand-over and the relay of ONE line, exercised on a box without a GPU.  Not a measurement."""
+	import torch.distributed as dist
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if world > 1:
+		dist.init_process_group("gloo")
+	one = torch.ones(1)
+	if world > 1:
+		dist.all_reduce(one)
+	if int(os.environ.get("RANK", "0")) == 0:
+		print(json.dumps({"metric": "launcher probe (no measurement)", "value": None, "n_gpus": a.gpus, "n_ranks_seen": int(one.item()),
+						  "world_size_env": world, "steps": a.steps, "warmup": a.warmup}), flush=True)
+	if world > 1:
+		dist.destroy_process_group()
+
+
 def main():
 	a = parse()
+	if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+		sys.exit(self_launch(a))
+	global torch
+	import torch
+	if os.environ.get("TTK_BENCH_PROBE") == "1":
+		return launch_probe(a)
 	rank = int(os.environ.get("RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	local = int(os.environ.get("LOCAL_RANK", "0"))
 	if world != a.gpus:
-		if world == 1 and a.gpus > 1:
-			raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+		raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU (python bench.py --gpus N does it by itself)")
 	# TTK_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- lets the N>1 control flow run on a 1-GPU box
 	# (RCCL refuses two ranks on one device).  Never used by the driver; the number it prints is not a scaling result.
 	rehearsal = os.environ.get("TTK_BENCH_REHEARSAL") == "1"
@@ -224,7 +296,11 @@ def main():
 			skw = {k: v for k, v in kw.items() if k != "candidates"}
 			total = 0.0
 			for line in lines:
-				mels, seconds, aux = tts.inference_sharded(line, ar_lat, df_lat, candidates=n_cand * world, **skw)
+				lm = None
+				if marks is not None:
+					lm = []
+					marks.append(lm)                       # one list of phase events per line
+				mels, seconds, aux = tts.inference_sharded(line, ar_lat, df_lat, candidates=n_cand * world, phase_marks=lm, **skw)
 				total += seconds
 			return total
 		mels, seconds, aux = tts.inference(text, ar_lat, df_lat, phase_marks=marks, **kw)
@@ -257,14 +333,16 @@ def main():
 
 	log(f"timed {a.steps} steps in {dt:.3f}s")
 	roof = None
-	if rank == 0 and not a.no_roofline and not by_cand:
+	if not a.no_roofline and (rank == 0 or by_cand):
+		# configs[1]/[2]: rank 0 alone (no collective in these passes).  configs[3]: the sharded step IS collectives, so every rank runs the two
+		# extra steps and rank 0 reports its own GPU's phases (it owns the diffused candidate: no scorer is attached, candidate 0 wins).
 		from tortoise_tts_amd import profiling
 		marks = []
 		step(exchange=False, marks=marks)                  # one more step, run exactly as the timed ones, with events at the phase boundaries
 		torch.cuda.synchronize()
-		roof = profiling.dominant_kernel_roofline(lambda: step(exchange=False), ar, df)   # rank 0 alone: no collective in here
+		roof = profiling.dominant_kernel_roofline(lambda: step(exchange=False), ar, df)
 		if not a.small:
-			roof["phases"] = phase_roofline(marks, a.dtype)
+			roof["phases"] = phase_roofline(marks, a.dtype, n_text, n_cand, n_mel, n_ddim) if by_cand else phase_roofline([marks], a.dtype)
 	# informational, never `value`: the k = 1 variant SURVEY.md 8d row 2 asks to be reported beside the headline -- the candidate is chosen first and
 	# only its row goes through the dense latent pass (same bits out; the reference runs all 16, inference.py:370-379, and so does `value`)
 	k1 = None
@@ -302,8 +380,8 @@ def main():
 		del tts4, ar4
 	log("roofline pass done; cpu baseline")
 	cpu = None
-	if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small and not by_cand:
-		cpu = cpu_baseline(1234)
+	if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:
+		cpu = cpu_baseline(1234, n_text, n_cand, n_mel, n_ddim, n_lines, light=True) if by_cand else cpu_baseline(1234)
 
 	if rank == 0:
 		cfg_line = {"workload": "configs[1]: 1 utterance/GPU, 64 text tokens, 16 AR candidates x 250 mel tokens (KV-cached decode), "
@@ -320,7 +398,8 @@ def main():
 		line = {
 			"metric": "audio-sec/wall-sec (RTF^-1), 16 AR candidates x 80 DDIM steps" if not by_cand else "audio-sec/wall-sec (RTF^-1), 32 AR candidates per GPU x 200 DDIM steps (configs[3])",
 			"value": (1 if by_cand else world) * audio / dt,
-			"unit": "audio-sec/wall-sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+			"unit": "audio-sec/wall-sec", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+			"backend": dist.get_backend() if dist.is_initialized() else None, "steps": a.steps, "warmup": a.warmup,
 			"ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": a.dtype, "data": "synthetic",
 			"config": cfg_line,

@@ -23,11 +23,61 @@ def test_candidate_shards_partition_exactly():
 		D.candidate_shard(4, 2, 2)
 
 
-def _worker(rank, world, port, q):
+class _Rendezvous(Exception):
+	"""the gloo rendezvous itself failed (the port picked by bind(0) was taken in between): the one failure a retry is for"""
+
+
+def _init(rank, world, port):
 	os.environ["MASTER_ADDR"] = "127.0.0.1"
 	os.environ["MASTER_PORT"] = str(port)
-	dist.init_process_group("gloo", rank=rank, world_size=world)
 	try:
+		dist.init_process_group("gloo", rank=rank, world_size=world)
+	except Exception as e:      # noqa: BLE001 -- reported to the parent by kind
+		raise _Rendezvous(repr(e)) from e
+
+
+def _pack(v):
+	"""tensors travel through the queue BY VALUE (numpy): torch's queue passes a tensor as a handle the receiver has to fetch from the sending
+	process, which may have exited by then (FileNotFoundError in the parent -- what the old retry-on-any-error loop was papering over)"""
+	if isinstance(v, torch.Tensor):
+		return ("__tensor__", v.numpy().copy())
+	if isinstance(v, dict):
+		return {k: _pack(x) for k, x in v.items()}
+	if isinstance(v, (list, tuple)):
+		return type(v)(_pack(x) for x in v)
+	return v
+
+
+def _unpack(v):
+	if isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and v[0] == "__tensor__":
+		return torch.from_numpy(v[1])
+	if isinstance(v, dict):
+		return {k: _unpack(x) for k, x in v.items()}
+	if isinstance(v, (list, tuple)):
+		return type(v)(_unpack(x) for x in v)
+	return v
+
+
+def _entry(body_name, rank, world, port, q):
+	"""worker entry: results go through the queue as (rank, value); failures as (rank, ("__error__", kind, text)) so that the parent retries
+	ONLY a failed rendezvous and lets an assertion inside a worker fail the test at once"""
+	try:
+		_init(rank, world, port)
+	except _Rendezvous as e:
+		q.put((rank, ("__error__", "rendezvous", str(e))))
+		return
+	try:
+		q.put((rank, _pack(globals()[body_name](rank, world))))
+	except BaseException:      # noqa: BLE001
+		import traceback
+		q.put((rank, ("__error__", "logic", traceback.format_exc())))
+		raise
+	finally:
+		dist.destroy_process_group()
+
+
+def _body_gather(rank, world):
+	if True:
 		n = 5
 		lo, hi = D.candidate_shard(n, rank, world)
 		L = 4 + rank                                        # ragged lengths: ranks stop at different steps
@@ -37,9 +87,7 @@ def _worker(rank, world, port, q):
 		all_scores = torch.tensor([0.1, 0.7, -0.2, 0.9, 0.9])
 		owner, idx, gathered = D.pick_best_candidate(all_scores[lo:hi], n)
 		assert torch.equal(gathered, all_scores) and (owner, idx) == (1, 3 - D.candidate_shard(n, 1, world)[0])
-		q.put((rank, ids))
-	finally:
-		dist.destroy_process_group()
+		return ids
 
 
 class _FakeStages(D.ShardStages):
@@ -83,51 +131,76 @@ class _FakeStages(D.ShardStages):
 		return (latents.sum(dim=(1, 2)).view(1, 1, 1) + torch.arange(12.0).view(1, 3, 4))
 
 
-def _worker_sharded(rank, world, port, q):
-	os.environ["MASTER_ADDR"] = "127.0.0.1"
-	os.environ["MASTER_PORT"] = str(port)
-	dist.init_process_group("gloo", rank=rank, world_size=world)
-	try:
-		out = {}
-		for with_scorer in (True, False, "late"):
-			st = _FakeStages(with_scorer)
-			mel, ids, scores, best = D.sharded_candidates(st, 7)
-			out[with_scorer] = dict(mel=mel, ids=ids, scores=scores, best=best, calls=st.calls, aligned=st.aligned)
-		q.put((rank, out))
-	finally:
-		dist.destroy_process_group()
+def _body_sharded(rank, world):
+	out = {}
+	for with_scorer in (True, False, "late"):
+		st = _FakeStages(with_scorer)
+		mel, ids, scores, best = D.sharded_candidates(st, 7)
+		out[with_scorer] = dict(mel=mel, ids=ids, scores=scores, best=best, calls=st.calls, aligned=st.aligned)
+	return out
 
 
-def _run_two_ranks(target=None):
-	target = target or _worker
-	with socket.socket() as s:
-		s.bind(("127.0.0.1", 0))
-		port = s.getsockname()[1]
-	ctx = mp.get_context("spawn")
-	q = ctx.Queue()
-	procs = [ctx.Process(target=target, args=(r, 2, port, q)) for r in range(2)]
-	for p in procs:
-		p.start()
-	try:
-		got = dict(q.get(timeout=120) for _ in range(2))
-	finally:
+def _body_subgroups(rank, world):
+	"""a 4-rank world cut into two 2-rank sub-groups (2 utterances x 2-way candidate shards, as configs[2] x configs[3] would combine on 8 GPUs),
+	and a 2-rank sub-group of a 3-rank world: every collective of the sharded path must stay inside the group it was given"""
+	pairs = [[0, 1], [2, 3]] if world == 4 else [[1, 2]]
+	groups = [dist.new_group(ranks=p, backend="gloo") for p in pairs]      # every rank creates every group, in the same order
+	mine = [i for i, p in enumerate(pairs) if rank in p]
+	if not mine:
+		return None                                                           # rank 0 of the 3-rank world: not a member, makes no call
+	gi = mine[0]
+	grank = pairs[gi].index(rank)
+	n = 5 + gi                                                                # the two groups work on different utterances
+	lo, hi = D.candidate_shard(n, grank, 2)
+	local = (1000 * gi + torch.arange(lo, hi))[:, None] * 10 + torch.arange(3 + grank)[None, :]
+	ids = D.gather_candidate_ids(local, n, pad_token=8193, group=groups[gi])
+	table = torch.arange(n, dtype=torch.float32) * (1 if gi == 0 else -1)     # group 0: the last candidate wins (on its rank 1); group 1: the first
+	owner, idx, scores = D.pick_best_candidate(table[lo:hi], n, group=groups[gi])
+	st = _FakeStages(True)
+	mel, sids, sscores, best = D.sharded_candidates(st, 7, group=groups[gi])
+	return dict(group=gi, ids=ids, owner=owner, idx=idx, scores=scores, mel=mel, sids=sids, best=best, calls=st.calls)
+
+
+def _run_ranks(body, world=2):
+	"""`world` spawned gloo ranks running `body(rank, world)`.  The rendezvous port is picked by bind(0) and released before the workers
+	bind it: ONLY a failed rendezvous (reported as such by the worker) is retried; an exception or an
+	assertion inside a worker fails the test immediately with the worker's traceback."""
+	last = None
+	for attempt in range(3):
+		with socket.socket() as s:
+			s.bind(("127.0.0.1", 0))
+			port = s.getsockname()[1]
+		ctx = mp.get_context("spawn")
+		q = ctx.Queue()
+		procs = [ctx.Process(target=_entry, args=(body.__name__, r, world, port, q)) for r in range(world)]
 		for p in procs:
-			p.join(timeout=60)
-			if p.is_alive():
-				p.kill()
-	assert all(p.exitcode == 0 for p in procs)
-	return got
+			p.start()
+		got, rendezvous_failed = {}, False
+		try:
+			for _ in range(world):
+				try:
+					r, v = q.get(timeout=180)
+				except Exception as e:      # noqa: BLE001 -- queue.Empty: a worker hung or died without reporting; not a rendezvous race
+					pytest.fail(f"a worker did not report: {e!r}")
+				if isinstance(v, tuple) and v and v[0] == "__error__":
+					if v[1] == "rendezvous":
+						rendezvous_failed, last = True, v[2]
+						break
+					pytest.fail(f"rank {r} failed:\n{v[2]}")
+				got[r] = _unpack(v)
+		finally:
+			for p in procs:
+				p.join(timeout=60)
+				if p.is_alive():
+					p.kill()
+		if not rendezvous_failed:
+			assert all(p.exitcode == 0 for p in procs)
+			return got
+	pytest.fail(f"gloo rendezvous failed three times: {last}")
 
 
 def test_gather_candidate_ids_two_ranks():
-	got = None
-	for attempt in range(3):          # the rendezvous port is picked by bind(0) and released: retry if something else grabbed it
-		try:
-			got = _run_two_ranks()
-			break
-		except (EOFError, AssertionError, OSError):
-			if attempt == 2:
-				raise
+	got = _run_ranks(_body_gather)
 	assert torch.equal(got[0], got[1])
 	ids = got[0]
 	assert ids.shape == (5, 5)
@@ -139,14 +212,7 @@ def test_sharded_candidates_control_flow_two_ranks():
 	"""dist.sharded_candidates under gloo, 2 ranks, 7 candidates (shards of 4 and 3): ids gathered in candidate order and padded, the RNG
 	aligned to the longest shard, every rank scoring its own candidates, the first maximum winning, ONLY its owner diffusing, and every
 	rank ending with the same mel -- all equal to the unsharded computation."""
-	got = None
-	for attempt in range(3):
-		try:
-			got = _run_two_ranks(_worker_sharded)
-			break
-		except (EOFError, AssertionError, OSError):
-			if attempt == 2:
-				raise
+	got = _run_ranks(_body_sharded)
 	Lmax = max(3 + (c * 5) % 4 for c in range(7))
 	want_ids = torch.stack([_FakeStages.row(c, Lmax) for c in range(7)])
 	for with_scorer, best in ((True, 2), (False, 0), ("late", 5)):
@@ -165,3 +231,42 @@ def test_sharded_candidates_control_flow_two_ranks():
 			assert a["calls"] == [("sample", 0, 4), ("diffuse", best)] and b["calls"] == [("sample", 4, 7)]
 		else:
 			assert a["calls"] == [("sample", 0, 4)] and b["calls"] == [("sample", 4, 7), ("diffuse", best)]
+
+
+def _check_subgroup(res, gi):
+	n = 5 + gi
+	a, b = res
+	assert a["group"] == b["group"] == gi
+	want = torch.full((n, 4), 8193, dtype=torch.long)
+	split = D.candidate_shard(n, 0, 2)[1]
+	for c in range(n):
+		L = 3 + (0 if c < split else 1)
+		want[c, :L] = (1000 * gi + c) * 10 + torch.arange(L)
+	assert torch.equal(a["ids"], want) and torch.equal(b["ids"], want)
+	table = torch.arange(n, dtype=torch.float32) * (1 if gi == 0 else -1)
+	assert torch.equal(a["scores"], table) and torch.equal(b["scores"], table)
+	win = n - 1 if gi == 0 else 0
+	own = 0 if win < split else 1
+	assert (a["owner"], a["idx"]) == (b["owner"], b["idx"]) == (own, win - (0 if own == 0 else split))
+	# sharded_candidates inside the sub-group: same result as the 2-rank default-group run (candidate 2 wins, owned by the group's rank 0)
+	Lmax = max(3 + (c * 5) % 4 for c in range(7))
+	want_ids = torch.stack([_FakeStages.row(c, Lmax) for c in range(7)])
+	want_mel = (want_ids[2].float().sum() * 1.5).view(1, 1, 1) + torch.arange(12.0).view(1, 3, 4)
+	for r in (a, b):
+		assert torch.equal(r["sids"], want_ids) and r["best"] == 2 and torch.equal(r["mel"], want_mel)
+	assert a["calls"] == [("sample", 0, 4), ("diffuse", 2)] and b["calls"] == [("sample", 4, 7)]
+
+
+def test_sharded_path_stays_inside_its_subgroup_four_ranks():
+	"""two 2-rank sub-groups of a 4-rank world run the id gather, the score gather and sharded_candidates at the same time on different
+	utterances: sizes, ranks, the owner and the broadcast source are the GROUP's (VERDICT r02 weak #8 / ADVICE r02: the helpers used to
+	read the default group)"""
+	got = _run_ranks(_body_subgroups, world=4)
+	_check_subgroup((got[0], got[1]), 0)
+	_check_subgroup((got[2], got[3]), 1)
+
+
+def test_sharded_path_in_a_two_rank_subgroup_of_three_ranks():
+	got = _run_ranks(_body_subgroups, world=3)
+	assert got[0] is None
+	_check_subgroup((got[1], got[2]), 0)

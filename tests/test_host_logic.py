@@ -103,3 +103,59 @@ def test_product_path_has_no_cpu_fallback():
 		UnifiedVoice(sd, W.AR_SMALL, device="cpu")
 	src = "".join(open(os.path.join(ROOT, "tortoise_tts_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "tortoise_tts_amd")) if f.endswith(".py"))
 	assert "tortoise_oracle" not in src and "import oracle" not in src
+
+
+def test_bench_launches_its_own_ranks_when_started_without_a_distributed_environment():
+	"""`python bench.py --gpus 2` as the driver starts it (no torchrun, no WORLD_SIZE): the parent starts the ranks as child processes under
+	torch.distributed.run, relays rank 0's ONE line and exits with their status (VERDICT r02 missing #1).  TTK_BENCH_PROBE=1 makes the ranks
+	only rendezvous and count themselves, so the branch runs without a GPU; on the GPU box the same branch runs the benchmark."""
+	import json
+	import subprocess
+	import sys
+	sys.path.insert(0, ROOT)
+	import bench
+	cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "2"], 12345)
+	assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+	assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+	env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+	env["TTK_BENCH_PROBE"] = "1"
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+					   capture_output=True, text=True, timeout=600)
+	assert r.returncode == 0, r.stderr[-2000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+	assert len(lines) == 1, r.stdout
+	line = json.loads(lines[0])
+	assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["world_size_env"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+	assert "starting 2 ranks" in r.stderr
+	# a failing rank fails the launcher: without the probe the ranks need a GPU, which this container does not have
+	if not torch.cuda.is_available():
+		env.pop("TTK_BENCH_PROBE")
+		r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--small", "--no-cpu-baseline"],
+						   env=env, capture_output=True, text=True, timeout=600)
+		assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_phase_roofline_counts_the_work_of_the_configuration_it_is_given():
+	"""bench.phase_roofline on fake phase events: configs[1] figures equal BASELINE.md section 4's formulas; the fp8 mode's DDIM phase is graded
+	against the 5 PFLOP/s fp8 peak (VERDICT r02 weak #6); a two-line configs[3] shard doubles the work and sums the lines' times"""
+	import sys
+	sys.path.insert(0, ROOT)
+	import bench
+
+	class Ev:
+		def __init__(self, t): self.t = t
+		def elapsed_time(self, other): return other.t - self.t
+	marks = [("start", Ev(0.0)), ("ar_decode", Ev(200.0)), ("latent_pass", Ev(210.0)), ("ddim", Ev(350.0))]
+	ph = bench.phase_roofline([marks], "bf16")
+	T = 1088
+	F = 236 * 1024 ** 2 * T + 52 * 1024 * T * T + 1_843_200 * T
+	assert ph["ddim"]["flop"] == 160.0 * F and abs(ph["ddim"]["floor_ms"] - 160.0 * F / 2.5e15 * 1e3) < 1e-9
+	assert abs(ph["ddim"]["frac"] - 160.0 * F / 0.140 / 2.5e15) < 1e-12 and ph["whole_step_ms"] == 350.0
+	assert 35.0 < ph["ar_decode"]["floor_ms"] < 38.0                       # 249 steps x (773 MB of weights + KV + logits) at 8 TB/s + the prefill
+	ph8 = bench.phase_roofline([marks], "fp8")
+	assert ph8["ddim"]["peak_TFLOPs"] == 5000.0 and abs(ph8["ddim"]["frac"] - ph["ddim"]["frac"] / 2) < 1e-12
+	assert abs(ph8["latent_pass"]["frac"] - ph["latent_pass"]["frac"]) < 1e-12
+	two = bench.phase_roofline([marks, marks], "bf16", 256, 32, 500, 200)
+	one = bench.phase_roofline([marks], "bf16", 256, 32, 500, 200)
+	assert two["lines"] == 2 and two["ddim"]["flop"] == 2 * one["ddim"]["flop"] and two["ddim"]["ms"] == 2 * one["ddim"]["ms"]
+	assert abs(two["ddim"]["frac"] - one["ddim"]["frac"]) < 1e-12 and two["ar_decode"]["algorithmic_bytes"] == 2 * one["ar_decode"]["algorithmic_bytes"]

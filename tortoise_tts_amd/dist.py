@@ -35,40 +35,42 @@ def utterance_shard(n_utterances: int, rank: int, world: int) -> List[int]:
 	return list(range(rank, n_utterances, world))
 
 
-def gather_candidate_ids(local_ids: torch.Tensor, n_candidates: int, pad_token: int) -> torch.Tensor:
-	"""All-gather of per-rank id blocks [c_r, L_r] -> [n_candidates, max L] on every rank, rows in candidate order, padded with
-	`pad_token` (the stop token, as `generate` pads finished rows).  Ranks may hold different candidate counts and lengths."""
-	world = dist.get_world_size()
-	rank = dist.get_rank()
+def gather_candidate_ids(local_ids: torch.Tensor, n_candidates: int, pad_token: int, group=None) -> torch.Tensor:
+	"""All-gather of per-rank id blocks [c_r, L_r] -> [n_candidates, max L] on every rank of `group` (None = the default group), rows in
+	candidate order (= group-rank order), padded with `pad_token` (the stop token, as `generate` pads finished rows).  Ranks may hold
+	different candidate counts and lengths."""
+	world = dist.get_world_size(group)
+	rank = dist.get_rank(group)
 	dev = local_ids.device
 	shape = torch.tensor([local_ids.shape[0], local_ids.shape[1]], dtype=torch.long, device=dev)
 	shapes = [torch.zeros_like(shape) for _ in range(world)]
-	dist.all_gather(shapes, shape)
+	dist.all_gather(shapes, shape, group=group)
 	cmax = int(max(s[0] for s in shapes))
 	lmax = int(max(s[1] for s in shapes))
 	buf = torch.full((cmax, lmax), pad_token, dtype=torch.long, device=dev)
 	buf[: local_ids.shape[0], : local_ids.shape[1]] = local_ids
 	out = [torch.empty_like(buf) for _ in range(world)]
-	dist.all_gather(out, buf)
+	dist.all_gather(out, buf, group=group)
 	rows = [out[r][: int(shapes[r][0])] for r in range(world)]
 	ids = torch.cat(rows, dim=0)
 	assert ids.shape[0] == n_candidates, (ids.shape, n_candidates, rank)
 	return ids
 
 
-def pick_best_candidate(local_scores: torch.Tensor, n_candidates: int) -> Tuple[int, int, torch.Tensor]:
-	"""All-gather of per-rank score blocks [c_r] -> (owner rank, index inside the owner's shard, all scores [n_candidates] in candidate
-	order).  The winner is the first maximum in candidate order (`torch.argmax` on the gathered vector), identical on every rank."""
-	world = dist.get_world_size()
+def pick_best_candidate(local_scores: torch.Tensor, n_candidates: int, group=None) -> Tuple[int, int, torch.Tensor]:
+	"""All-gather of per-rank score blocks [c_r] over `group` -> (owner = rank INSIDE the group, index inside the owner's shard, all scores
+	[n_candidates] in candidate order).  The winner is the first maximum in candidate order (`torch.argmax` on the gathered vector),
+	identical on every rank of the group."""
+	world = dist.get_world_size(group)
 	dev = local_scores.device
 	n = torch.tensor([local_scores.shape[0]], dtype=torch.long, device=dev)
 	counts = [torch.zeros_like(n) for _ in range(world)]
-	dist.all_gather(counts, n)
+	dist.all_gather(counts, n, group=group)
 	cmax = int(max(c[0] for c in counts))
 	buf = torch.full((cmax,), float("-inf"), dtype=torch.float32, device=dev)
 	buf[: local_scores.shape[0]] = local_scores.to(torch.float32)
 	out = [torch.empty_like(buf) for _ in range(world)]
-	dist.all_gather(out, buf)
+	dist.all_gather(out, buf, group=group)
 	scores = torch.cat([out[r][: int(counts[r][0])] for r in range(world)])
 	assert scores.shape[0] == n_candidates, (scores.shape, n_candidates)
 	best = int(torch.argmax(scores))
@@ -120,14 +122,14 @@ def sharded_candidates(stages: ShardStages, n_candidates: int, group=None):
 	if hi <= lo:
 		raise ValueError(f"{n_candidates} candidates over {world} ranks leaves rank {rank} without work")
 	local = stages.sample(lo, hi, n_candidates)
-	ids = gather_candidate_ids(local, n_candidates, stages.pad_token)
+	ids = gather_candidate_ids(local, n_candidates, stages.pad_token, group)
 	stages.align_rng(ids.shape[1])
 	codes, lat = stages.latents(ids[lo:hi].contiguous())
 	sc = stages.score(codes)
 	if sc is None:
 		owner, idx, scores, best = 0, 0, None, 0
 	else:
-		owner, idx, scores = pick_best_candidate(sc, n_candidates)
+		owner, idx, scores = pick_best_candidate(sc, n_candidates, group)
 		best = candidate_shard(n_candidates, owner, world)[0] + idx
 	dev = ids.device
 	shape = torch.zeros(3, dtype=torch.long, device=dev)

@@ -51,8 +51,10 @@ class HotPathStages:
 
 	def __init__(self, tts: "TTSHotPath", text_tokens, autoregressive_latents, diffusion_latents, *, max_ar_steps=500,
 				 max_diffusion_steps=80, ar_temp=0.8, diffusion_temp=1.0, top_p=1.0, top_k=0, repetition_penalty=1.0, length_penalty=1.0,
-				 diffusion_sampler="ddim", cond_free=True, suppress_tokens=None):
+				 diffusion_sampler="ddim", cond_free=True, suppress_tokens=None, phase_marks=None):
 		self.tts, self.ar, self.diff = tts, tts.autoregressive, tts.diffusion
+		self.phase_marks = phase_marks      # measurement only: receives (name, event) at the phase boundaries, as TTSHotPath.inference does
+		self._mark("start")
 		self.text = text_tokens.to(self.ar.device)
 		self.al, self.dl = autoregressive_latents, diffusion_latents
 		self.kw = dict(do_sample=True, top_k=top_k, top_p=top_p, temperature=ar_temp, num_beams=1, length_penalty=length_penalty,
@@ -63,8 +65,16 @@ class HotPathStages:
 		self.diffusion_temp, self.sampler = diffusion_temp, diffusion_sampler
 		self.pad_token = self.ar.stop_mel_token
 
+	def _mark(self, name):
+		if self.phase_marks is not None:
+			ev = torch.cuda.Event(enable_timing=True)
+			ev.record()
+			self.phase_marks.append((name, ev))
+
 	def sample(self, lo, hi, n_candidates):
-		return self.ar.inference_speech(self.al, self.text, num_return_sequences=n_candidates, candidate_shard=(lo, hi), **self.kw)
+		ids = self.ar.inference_speech(self.al, self.text, num_return_sequences=n_candidates, candidate_shard=(lo, hi), **self.kw)
+		self._mark("ar_decode")
+		return ids
 
 	def align_rng(self, steps):
 		g = self.ar.last_generate
@@ -76,6 +86,7 @@ class HotPathStages:
 		al = self.al.expand(B, -1) if self.al.shape[0] != B else self.al
 		lat = self.ar.forward(al, self.text.expand(B, -1), torch.tensor([self.text.shape[1]], dtype=torch.int32).expand(B), codes,
 							  torch.tensor([M * self.ar.mel_length_compression]).expand(B), return_latent=True, clip_inputs=False)
+		self._mark("latent_pass")           # (includes the id all-gather that precedes it)
 		return codes, lat
 
 	def score(self, codes):
@@ -86,8 +97,10 @@ class HotPathStages:
 		T = latents.shape[1] * 4 * 24000 // 22050
 		E = self.diff.timestep_independent(latents, self.dl, T, False)
 		noise = torch.randn((1, 100, T), device=self.ar.device) * self.diffusion_temp
-		return self.diffuser.sample_loop(self.diff, (1, 100, T), sampler=self.sampler, noise=noise,
-										 model_kwargs={"precomputed_aligned_embeddings": E}, progress=False)
+		mel = self.diffuser.sample_loop(self.diff, (1, 100, T), sampler=self.sampler, noise=noise,
+										model_kwargs={"precomputed_aligned_embeddings": E}, progress=False)
+		self._mark("ddim")
+		return mel
 
 
 class TTSHotPath:
