@@ -96,6 +96,7 @@ struct ttk_ar {
 	const int64_t* rng_args = nullptr; const int64_t* rng_draws = nullptr; float* rng_q = nullptr;
 	int head_split = 1;     // decode head as LayerNorm launch + plain GEMV (TTK_AR_HEAD_SPLIT=0: norms inside the GEMV)
 	int lnfold = 1;         // ln_1 + c_attn and ln_2 + c_fc of the decode step with the LayerNorm folded into the matrix (TTK_AR_LNFOLD=0: LN prologue)
+	int lean = 1;           // decode launches on the compile-time-specialised kernels of gemv.hip where one exists (TTK_AR_LEAN=0: k_skinny everywhere)
 	float* slab; int* tickets;   // split-K scratch of the mlp.c_proj decode GEMV, one set per row group
 	// Waves per workgroup of the decode GEMVs that read their rows in fragment order (TTK_AR_WV_PROJ / _PROJ2 / _LN).  A wave requests its
 	// operands in batches of 8 k-steps (bf16; 4 in f32), so K / 32 / waves should be a multiple of that: with 8 waves on K = 1024 every wave
@@ -187,6 +188,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	const int wv_prologue = d >= 1024 ? 8 : 4;       // LayerNorm prologue form: 8 waves x 2 rows normalise the 16 candidates in one pass
 	const bool whole = r0 == 0 && nrows == h->B;      // fragment-order activations exist for the whole batch only
 	void* xf = whole ? h->x_frag : nullptr;
+	const bool lean = h->lean && whole && h->lnfold && h->hfrag;      // gemv.hip's specialised launches: the whole batch, fragment-order activations
 	for (int l = 0; l < c.layers; ++l) {
 		const ARLayer& L = h->L[l];
 		char* kc = (char*)h->kc + (size_t)l * h->kv_layer_stride * es + r0 * kv_row;
@@ -197,7 +199,10 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		if (fold_qkv) { p.Wp = L.attn.wfrag_fold; p.w8 = 0; p.bias = L.attn.bias_fold; p.g1 = L.attn.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln1_g; p.b1 = L.ln1_b; }
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
-		launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
+		GemvParams gq = {};
+		gq.Wp = p.Wp; gq.a = xf; gq.bias = p.bias; gq.csum = p.g1; gq.qbuf = qbuf; gq.kcache = kc; gq.vcache = vc; gq.d_pos = h->d_pos;
+		gq.M = nrows; gq.N = 3 * d; gq.K = d; gq.max_ctx = c.max_ctx; gq.H = H; gq.q_scale = 0.125f;
+		if (!(lean && fold_qkv && launch_gemv(dt, GV_QKV, gq, s))) launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
 		AttnDecodeParams a = {};
 		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 && h->share_prefix && h->nsplit == 1;
 		a.row_info = h->lines_mode && r0 == 0 ? h->d_rowinfo : nullptr;
@@ -205,14 +210,18 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		p = {};
 		p.Wp = L.proj.wfrag; p.w8 = L.proj.w8; p.wscale = L.proj.wscale; p.N = d; p.K = d; p.M = nrows; p.bias = L.proj.bias; p.a = attn_out; p.lda = d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.narrow = h->narrow; p.out_T = h->lnfold ? xf : nullptr;
-		launch_skinny(dt, p, d >= 1024 ? h->wv_proj : 4, s);
+		GemvParams gp = {};
+		gp.Wp = p.Wp; gp.a = attn_out; gp.bias = p.bias; gp.out_f32 = x; gp.out_T = p.out_T; gp.M = nrows; gp.N = d; gp.K = d; gp.w8 = p.w8; gp.wscale = p.wscale;
+		if (!(lean && p.a_frag && h->narrow == 4 && launch_gemv(dt, GV_PROJ, gp, s))) launch_skinny(dt, p, d >= 1024 ? h->wv_proj : 4, s);
 		p = {};
 		p.Wp = L.fc.wfrag; p.w8 = L.fc.w8; p.wscale = L.fc.wscale; p.N = 4 * d; p.K = d; p.M = nrows; p.bias = L.fc.bias;
 		const bool fold_fc = h->lnfold && whole && L.fc.wfrag_fold;
 		if (fold_fc) { p.Wp = L.fc.wfrag_fold; p.w8 = 0; p.bias = L.fc.bias_fold; p.g1 = L.fc.csum; p.a = xf; p.lda = d; p.a_frag = 1; }
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b; }
 		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf; p.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
-		launch_skinny(dt, p, fold_fc ? wv_small : wv_prologue, s);
+		GemvParams gf = {};
+		gf.Wp = p.Wp; gf.a = xf; gf.bias = p.bias; gf.csum = p.g1; gf.out_T = hbuf; gf.M = nrows; gf.N = 4 * d; gf.K = d;
+		if (!(lean && fold_fc && p.out_frag && launch_gemv(dt, GV_FC, gf, s))) launch_skinny(dt, p, fold_fc ? wv_small : wv_prologue, s);
 		p = {};
 		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		p.mode = SK_RESIDUAL; p.out_f32 = x; p.ldc = d; p.out_T = h->lnfold ? xf : nullptr;
@@ -220,7 +229,9 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		if (d >= 1024 && !h->narrow2) {   // 64 n-tiles x 4 K-slices = 256 workgroups; each row group has its own slab and tickets
 			p.ksplit = 4; p.slab = h->slab + (size_t)gi * (d / 16) * 4 * 4 * 256; p.tickets = h->tickets + (size_t)gi * (d / 16);
 		}
-		launch_skinny(dt, p, d >= 1024 ? h->wv_proj2 : 4, s);
+		GemvParams g2 = {};
+		g2.Wp = p.Wp; g2.a = hbuf; g2.bias = p.bias; g2.out_f32 = x; g2.out_T = p.out_T; g2.M = nrows; g2.N = d; g2.K = 4 * d; g2.w8 = p.w8; g2.wscale = p.wscale;
+		if (!(lean && p.a_frag && h->narrow2 == 4 && launch_gemv(dt, GV_PROJ, g2, s))) launch_skinny(dt, p, d >= 1024 ? h->wv_proj2 : 4, s);
 	}
 	SkinnyParams p = {};
 	p.Wp = h->head.wfrag; p.N = c.number_mel_codes; p.K = d; p.M = nrows; p.bias = h->head.bias;
@@ -235,7 +246,11 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		// norms inside the GEMV every one of the 513 workgroups normalised all 16 rows, two passes each -- 17 us for 16.8 MB of weights
 		launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, hid);
 		p.a = h->attn_out; p.lda = d; p.a_frag = 1;
-		launch_skinny(dt, p, 4, s);      // 4-wave workgroups: five fit a CU, so the 513 tiles run as one round (two 8-wave ones fit: 512 slots)
+		GemvParams gh = {};
+		gh.Wp = p.Wp; gh.a = h->attn_out; gh.bias = p.bias; gh.out_f32 = p.out_f32; gh.d_pos = p.d_pos; gh.noise = p.qbuf; gh.rng = p.slab; gh.draws = (const int64_t*)p.tickets;
+		gh.M = nrows; gh.N = c.number_mel_codes; gh.K = d; gh.row0 = r0;
+		if (!(lean && launch_gemv(dt, GV_HEAD, gh, s)))
+			launch_skinny(dt, p, 4, s);      // 4-wave workgroups: five fit a CU, so the 513 tiles run as one round (two 8-wave ones fit: 512 slots)
 	} else {
 		p.ln_count = 2; p.x = x; p.ldx = d;
 		p.g1 = h->lnf_g; p.b1 = h->lnf_b; p.g2 = h->fn_g; p.b2 = h->fn_b; p.ln_out = hid;
@@ -330,6 +345,8 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 		h->head_split = eh ? (atoi(eh) != 0) : 1;
 		const char* el = getenv("TTK_AR_LNFOLD");
 		h->lnfold = el ? (atoi(el) != 0) : 1;
+		const char* eg = getenv("TTK_AR_LEAN");
+		h->lean = eg ? (atoi(eg) != 0) : 1;
 		const char* e = getenv("TTK_AR_SPLIT");
 		h->nsplit = e ? atoi(e) : 1;
 		if (h->nsplit != 1 && h->nsplit != 2 && h->nsplit != 4) h->nsplit = 1;

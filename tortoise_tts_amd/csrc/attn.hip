@@ -349,6 +349,17 @@ __device__ __forceinline__ int64_t decode_out_index(const AttnDecodeParams& p, i
 	return ((((int64_t)(b >> 4) * (p.H * HD / 32) + (n >> 5)) * 64 + ((n >> 3) & 3) * 16 + (b & 15)) * 8 + (n & 7));
 }
 
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2   // tests/diag/ar_chain.cpp: every wave stamps, [workgroup][wave (16 slots)][8]; slot 7 = XCC id
+#define TTK_ASTAMP(i) do { if (p.stamps && (threadIdx.x & 63) == 0) { unsigned long long* st_ = p.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8; \
+	st_[(i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0) st_[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); } } while (0)
+#define TTK_ASTAMPD(i, dep) do { if (p.stamps) { unsigned tmp_; unsigned long long t_; \
+	asm volatile("s_nop 7\n\tv_readfirstlane_b32 %0, %2\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tmp_), "=s"(t_) : "v"(dep) : "memory"); \
+	if ((threadIdx.x & 63) == 0) p.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 + (i)] = t_; } } while (0)
+#else
+#define TTK_ASTAMP(i) do {} while (0)
+#define TTK_ASTAMPD(i, dep) do {} while (0)
+#endif
+
 template <typename T, int NW, int UN, bool ROWS = false>
 __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	typedef typename Frag<T>::type FragT;
@@ -357,6 +368,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	const int h = blockIdx.x, b = blockIdx.y;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int slot = lane >> 3, dg = lane & 7;
+	TTK_ASTAMP(0);
 #ifdef TTK_ABL      // diagnostic builds only (tests/diag/ar_ablate.sh): 256 = the whole kernel, 128 = the K / V loads
 	if (TTK_ABL & 256) return;
 #endif
@@ -372,18 +384,11 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	const T* Kc = (const T*)p.kcache + (((int64_t)b * p.H + h) * p.max_ctx + start) * HD;
 	const T* Vc = (const T*)p.vcache + (((int64_t)b * p.H + h) * p.max_ctx + start) * HD;
 	const int64_t to_shared = -(int64_t)(b - grp) * p.H * p.max_ctx * HD;      // element offset from this candidate's slice to its line's first
-	float q[8];
-	{
-		const float* qp = p.qbuf + ((int64_t)b * p.H + h) * HD + 8 * dg;
-#pragma unroll
-		for (int j = 0; j < 8; ++j) q[j] = qp[j] * LOG2E;   // log2-domain scores: exp2 is a single v_exp_f32
-	}
 	const int groups = (n + 7) / 8;
-	float m = NEG_BIG, l = 0.f, acc[8];
-#pragma unroll
-	for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-	for (int gb = wave; gb < groups; gb += NW * UN) {
-		FragT kf[UN], vf[UN];
+	// The first round's K / V requests leave right behind the position words, BEFORE the query is asked for: placed after the query (whose
+	// scaling the compiler hoists in front of the loop, with its wait) they were a third dependent round trip -- arguments, position, query, keys.
+	FragT kf[UN], vf[UN];
+	auto request = [&](int gb) {
 #pragma unroll
 		for (int u = 0; u < UN; ++u) {     // unconditional, clamped: all 2*UN requests leave before the first use
 			int key = (gb + u * NW) * 8 + slot;
@@ -395,6 +400,20 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 			kf[u] = *(const FragT*)(Kc + off);
 			vf[u] = *(const FragT*)(Vc + off);
 		}
+	};
+	request(wave);      // waves beyond the last key group re-read the last row (never used)
+	__builtin_amdgcn_sched_barrier(0);
+	float q[8];
+	{
+		const float* qp = p.qbuf + ((int64_t)b * p.H + h) * HD + 8 * dg;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) q[j] = qp[j] * LOG2E;   // log2-domain scores: exp2 is a single v_exp_f32
+	}
+	TTK_ASTAMPD(1, (float)(n + shared) + q[0]);      // cache length, shared-prefix length and the query are there
+	float m = NEG_BIG, l = 0.f, acc[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+	for (int gb = wave; gb < groups;) {
 #pragma unroll
 		for (int u = 0; u < UN; ++u) {
 			const int key = (gb + u * NW) * 8 + slot;
@@ -413,7 +432,10 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 				m = m_new;
 			}
 		}
+		gb += NW * UN;
+		if (gb < groups) request(gb);
 	}
+	TTK_ASTAMPD(2, acc[0] + l);                      // this wave's keys are in and reduced
 	// merge the NP partial softmaxes through LDS: L1 groups of 32 in parallel, then the L1 results
 	__shared__ float sm[NP], sl[NP], sacc[NP][HD + 1];
 	__shared__ float sm2[L1], sl2[L1], so2[L1][HD];
@@ -422,6 +444,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 #pragma unroll
 	for (int j = 0; j < 8; ++j) sacc[ps][8 * dg + j] = acc[j];
 	__syncthreads();
+	TTK_ASTAMP(3);
 	if (tid < HD * L1) {
 		const int part = tid >> 6, e = tid & 63;
 		float mn = NEG_BIG;
@@ -449,6 +472,11 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 			((T*)p.out)[decode_out_index(p, b, h, tid)] = cvt<T>(ot / lt);
 		}
 	}
+	TTK_ASTAMP(5);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	TTK_ASTAMP(6);
+#endif
 }
 
 template <typename T, int NW, int UN>

@@ -42,10 +42,20 @@ namespace ttk {
 #define TTK_ABL 0
 #endif
 
-#ifdef TTK_STAMPS
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2   // tests/diag/ar_chain.cpp: every wave stamps, [workgroup][wave (16 slots)][8]; slot 7 = XCC id
+#define TTK_STAMP(i) do { if (p.stamps && (threadIdx.x & 63) == 0) { unsigned long long* st_ = p.stamps + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8; \
+	st_[(i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0) st_[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); } } while (0)
+// stamp taken only once `dep` (a VGPR value: an accumulator, a loaded word) is really there: the asm reads it, so the wave stalls on the MFMA /
+// the load that produces it first -- a bare s_memrealtime has no data dependency and floats above the arithmetic it is meant to follow
+#define TTK_STAMPD(i, dep) do { if (p.stamps) { unsigned tmp_; unsigned long long t_; \
+	asm volatile("s_nop 7\n\tv_readfirstlane_b32 %0, %2\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tmp_), "=s"(t_) : "v"(dep) : "memory"); \
+	if ((threadIdx.x & 63) == 0) p.stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (i)] = t_; } } while (0)
+#elif defined(TTK_STAMPS)
 #define TTK_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TTK_STAMPD(i, dep) TTK_STAMP(i)
 #else
 #define TTK_STAMP(i) do {} while (0)
+#define TTK_STAMPD(i, dep) do {} while (0)
 #endif
 
 // Weight fragment as it sits in memory: the MFMA operand itself, or (W8, bf16 arithmetic only) 8 fp8-e4m3 bytes that are widened to
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		}
 	}
 
-	TTK_STAMP(3);
+	TTK_STAMPD(3, acc[0][0]);
 	// ---- cross-wave reduction through LDS, then epilogue by the first 256 threads
 	float vsum[MT];
 	if (TTK_ABL & 4) {
@@ -422,6 +432,10 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 		}
 	}
 	TTK_STAMP(5);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores acknowledged
+	TTK_STAMP(6);
+#endif
 }
 
 template <typename T, int MT, bool W8>

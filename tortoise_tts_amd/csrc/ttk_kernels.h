@@ -111,6 +111,30 @@ struct SkinnyParams {
 };
 void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s);
 
+// ---------------------------------------------------------------- lean decode GEMV (gemv.hip)
+// The launches of the KV-cached decode step at the benchmarked geometry (K = 1024 / 4096, whole batch, activations in fragment order, LayerNorm
+// folded), one compile-time specialisation per role; bit-identical to k_skinny on the same operands.  launch_gemv returns false (and launches
+// nothing) for a geometry it has no instantiation for: the caller then takes launch_skinny.
+enum GemvRole { GV_QKV = 0, GV_PROJ = 1, GV_FC = 2, GV_HEAD = 3 };
+struct GemvParams {
+	const void* Wp;             // weights in fragment order [n_tile][K/32][lane][8] (GV_QKV / GV_FC: gamma o W)
+	const void* a;              // rows in A-fragment order [m_tile][K/32][lane][8], T-typed, rows >= M zero (GV_QKV / GV_FC: un-normalised)
+	const float* bias;          // [N] (GV_QKV / GV_FC: b + beta W)
+	const float* csum;          // GV_QKV / GV_FC: column sums of the T-typed folded matrix
+	float* out_f32;             // GV_PROJ: residual stream f32 [M][N], updated in place; GV_HEAD: logits [M][N]
+	void* out_T;                // GV_PROJ (optional) / GV_FC: T-typed output in A-fragment order [m_tile][N/32][lane][8]
+	float* qbuf; void* kcache; void* vcache;   // GV_QKV: q f32 [M][d] pre-scaled, caches T [M][H][max_ctx][64]
+	const int* d_pos;           // GV_QKV: cache row to append at; GV_HEAD (optional): incremented by the launch
+	float* noise; const void* rng; const int64_t* draws;   // GV_HEAD (optional): Exp(1) noise rows [M][N], device RngArgs, per-row draw counters
+	int M, N, max_ctx, H, row0; // row0: first row of this batch inside the noise tensor's row numbering
+	float q_scale, wscale;
+	int K, w8;                  // host side only (dispatch): K in {1024, 4096}; w8: Wp holds fp8 bytes (GV_PROJ, bf16 arithmetic)
+#ifdef TTK_STAMPS
+	unsigned long long* stamps; // diagnostic build only
+#endif
+};
+bool launch_gemv(int dt, int role, const GemvParams& p, hipStream_t s);
+
 // ---------------------------------------------------------------- norms (norm.hip)
 // y = LN2?(LN1(x)) per row; out is T or f32; frag: out in the skinny GEMV's A-fragment order instead of row-major; out2 (optional): also f32 [rows][d]
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
@@ -159,6 +183,9 @@ struct AttnDecodeParams {
 	int shared_rows;          // != 0: cache rows [0, d_pos[1]) are identical for every candidate (one conditioning latent + one text line: the
 	                          // prefill computed the same prefix B times): read them from candidate 0's slice, which the 16 workgroups of a head
 	                          // -- equal blockIdx.x, so one XCD -- then share in L2 instead of fetching B copies from HBM
+#ifdef TTK_STAMPS
+	unsigned long long* stamps;   // diagnostic build only
+#endif
 };
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s);
 
