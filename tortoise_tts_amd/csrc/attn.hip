@@ -364,7 +364,6 @@ template <typename T, int NW, int UN, bool ROWS = false>
 __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	typedef typename Frag<T>::type FragT;
 	constexpr int NP = NW * 8;           // (wave, slot) partial softmaxes
-	constexpr int L1 = NP / 32;          // first merge level: L1 groups of 32 partials
 	const int h = blockIdx.x, b = blockIdx.y;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int slot = lane >> 3, dg = lane & 7;
@@ -436,41 +435,37 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 		if (gb < groups) request(gb);
 	}
 	TTK_ASTAMPD(2, acc[0] + l);                      // this wave's keys are in and reduced
-	// merge the NP partial softmaxes through LDS: L1 groups of 32 in parallel, then the L1 results
+	// merge the NP partial softmaxes through LDS in two levels.  Level 1 is wave-private: a wave folds its own 8 slots (lane = head dim) as soon as
+	// its keys are done -- no workgroup barrier in front of it, so it runs inside the time the wave would otherwise wait for the slowest one -- and
+	// publishes ONE partial; after the only barrier 64 threads fold the NW wave partials.  (First version: barrier, 4 waves folding 32 partials
+	// each while 12 idled, barrier, 4 more: 36 dependent steps behind two barriers against 8 + NW behind one.)
 	__shared__ float sm[NP], sl[NP], sacc[NP][HD + 1];
-	__shared__ float sm2[L1], sl2[L1], so2[L1][HD];
+	__shared__ float sm2[NW], sl2[NW], so2[NW][HD];
 	const int ps = wave * 8 + slot;
 	if (dg == 0) { sm[ps] = m; sl[ps] = l; }
 #pragma unroll
 	for (int j = 0; j < 8; ++j) sacc[ps][8 * dg + j] = acc[j];
-	__syncthreads();
-	TTK_ASTAMP(3);
-	if (tid < HD * L1) {
-		const int part = tid >> 6, e = tid & 63;
+	__builtin_amdgcn_wave_barrier();      // same wave, LDS is in order: the reads below see the writes above
+	{
 		float mn = NEG_BIG;
 #pragma unroll
-		for (int i = 0; i < 32; ++i) mn = fmaxf(mn, sm[part * 32 + i]);
+		for (int i = 0; i < 8; ++i) mn = fmaxf(mn, sm[wave * 8 + i]);
 		float lt = 0.f, ot = 0.f;
 #pragma unroll
-		for (int i = 0; i < 32; ++i) { const float a = __builtin_amdgcn_exp2f(sm[part * 32 + i] - mn); lt += sl[part * 32 + i] * a; ot += sacc[part * 32 + i][e] * a; }
-		if (L1 == 1) {
-			((T*)p.out)[decode_out_index(p, b, h, e)] = cvt<T>(ot / lt);
-		} else {
-			if (e == 0) { sm2[part] = mn; sl2[part] = lt; }
-			so2[part][e] = ot;
-		}
+		for (int i = 0; i < 8; ++i) { const float a = __builtin_amdgcn_exp2f(sm[wave * 8 + i] - mn); lt += sl[wave * 8 + i] * a; ot += sacc[wave * 8 + i][lane] * a; }
+		if (lane == 0) { sm2[wave] = mn; sl2[wave] = lt; }
+		so2[wave][lane] = ot;
 	}
-	if (L1 > 1) {
-		__syncthreads();
-		if (tid < HD) {
-			float mn = NEG_BIG;
+	__syncthreads();
+	TTK_ASTAMP(3);
+	if (tid < HD) {
+		float mn = NEG_BIG;
 #pragma unroll
-			for (int i = 0; i < L1; ++i) mn = fmaxf(mn, sm2[i]);
-			float lt = 0.f, ot = 0.f;
+		for (int i = 0; i < NW; ++i) mn = fmaxf(mn, sm2[i]);
+		float lt = 0.f, ot = 0.f;
 #pragma unroll
-			for (int i = 0; i < L1; ++i) { const float a = __builtin_amdgcn_exp2f(sm2[i] - mn); lt += sl2[i] * a; ot += so2[i][tid] * a; }
-			((T*)p.out)[decode_out_index(p, b, h, tid)] = cvt<T>(ot / lt);
-		}
+		for (int i = 0; i < NW; ++i) { const float a = __builtin_amdgcn_exp2f(sm2[i] - mn); lt += sl2[i] * a; ot += so2[i][tid] * a; }
+		((T*)p.out)[decode_out_index(p, b, h, tid)] = cvt<T>(ot / lt);
 	}
 	TTK_ASTAMP(5);
 #if defined(TTK_STAMPS) && TTK_STAMPS == 2

@@ -150,6 +150,54 @@ __global__ __launch_bounds__(64 * NW) void k_gemv(GemvParams p) {
 	float fs1[MT], fs2[MT];
 #pragma unroll
 	for (int mt = 0; mt < MT; ++mt) { acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; fs1[mt] = 0.f; fs2[mt] = 0.f; }
+	// Narrow tiles (GV_PROJ), 16-bit types: a lane's B fragment is column 4*sub + (n & 3), so requesting it per lane asks for every 16-byte chunk
+	// four times over -- 1 KiB of requests per k-step for 256 distinct bytes, and with the 128 KB of rows a workgroup of mlp.c_proj pulls, the CU's
+	// 64 B/clk request path was what bounded the launch (256 KB of requests: ~2 us).  Instead one DENSE request per four k-steps (lane = (k-step,
+	// k-group, column): 64 distinct chunks), parked in a wave-private LDS strip and read back with the broadcast pattern the MFMA wants (four
+	// lanes per address: free on LDS).  Same bits into the same MFMAs.
+	constexpr bool WLDS = NARROW && ES == 2;
+	if constexpr (WLDS) {
+		static_assert(KPW % 4 == 0, "dense weight requests cover four k-steps");
+		constexpr int WL = KPW / 4;
+		WRaw* wl = (WRaw*)(rstat) + wave * (KPW * 16);                     // [k-step][k-group][column] chunks of this wave (behind the reduce area)
+		const WRaw* wd = (const WRaw*)p.Wp + ((int64_t)nt * KS + ks0 + (lane >> 4)) * 64 + ((lane >> 2) & 3) * 16 + 4 * sub + (lane & 3);
+		WRaw wq[WL];
+#pragma unroll
+		for (int i = 0; i < WL; ++i) wq[i] = GV_WLOAD(wd + i * 4 * 64);
+		FragT a0[PRE][MT];
+#pragma unroll
+		for (int u = 0; u < PRE; ++u)
+#pragma unroll
+			for (int mt = 0; mt < MT; ++mt) a0[u][mt] = ap[((int64_t)mt * KS + u) * 64];
+		GV_STAMP(2);
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int i = 0; i < WL; ++i) wl[i * 64 + lane] = wq[i];
+		const int rd = ((lane >> 4) << 2) + (lane & 3);                    // chunk of (k-group, column) inside a k-step's 16
+#pragma unroll
+		for (int kb = 0; kb < KPW; kb += PRE) {
+			FragT a[PRE][MT];
+			if (kb + PRE < KPW) {      // the next batch of rows leaves before this one is multiplied
+#pragma unroll
+				for (int u = 0; u < PRE; ++u)
+#pragma unroll
+					for (int mt = 0; mt < MT; ++mt) a[u][mt] = ap[((int64_t)mt * KS + kb + PRE + u) * 64];
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int u = 0; u < PRE; ++u) {
+				const WRaw b = wl[(kb + u) * 16 + rd];
+#pragma unroll
+				for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(a0[u][mt], WF::dec(b), acc[mt]);
+			}
+			if (kb + PRE < KPW) {
+#pragma unroll
+				for (int u = 0; u < PRE; ++u)
+#pragma unroll
+					for (int mt = 0; mt < MT; ++mt) a0[u][mt] = a[u][mt];
+			}
+		}
+	} else {
 #pragma unroll
 	for (int kb = 0; kb < KPW; kb += PRE) {
 		WRaw b[PRE];
@@ -169,6 +217,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemv(GemvParams p) {
 				if (FOLD) fold_stats<T>(a[u][mt], fs1[mt], fs2[mt]);
 				acc[mt] = mma16<T>(a[u][mt], WF::dec(b[u]), acc[mt]);
 			}
+	}
 	}
 	if (FOLD) {   // the four lanes of a row (k-groups) -> the wave's partial; lane group 0 publishes it
 #pragma unroll
@@ -240,7 +289,8 @@ static void gemv_go(const GemvParams& p, hipStream_t s, hipEvent_t ea, hipEvent_
 	constexpr bool FOLD = ROLE == GV_QKV || ROLE == GV_FC;
 	const int tiles = (p.N + 15) / 16;
 	const int grid = ROLE == GV_PROJ ? tiles * 4 : tiles;
-	const size_t lds = (size_t)NW * MT * 64 * 4 * sizeof(float) + (FOLD ? (size_t)NW * MT * 16 * 2 * sizeof(float) : 0);
+	const size_t lds = (size_t)NW * MT * 64 * 4 * sizeof(float) + (FOLD ? (size_t)NW * MT * 16 * 2 * sizeof(float) : 0)
+					   + (ROLE == GV_PROJ && sizeof(T) == 2 ? (size_t)NW * KPW * 16 * (W8 ? 8 : 16) : 0);      // wave-private weight strips of the narrow tiles
 	hipExtLaunchKernelGGL((k_gemv<T, MT, ROLE, NW, KPW, W8>), dim3(grid), dim3(64 * NW), (unsigned)lds, s, ea, eb, 0, p);
 }
 
