@@ -92,6 +92,13 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
  * from the same forward's logits (stream_generator.py:1172) -- for the first token that is the prefill's row.                     */
 int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream);
 
+/* The same rows for EVERY decode step of a captured token loop, without a per-step pointer: while set, each ttk_ar_decode / ttk_ar_decode_next
+ * also writes final_norm(ln_f(h)) [B, D] f32 of its new rows to base + index[0] * stride (elements), `index` a device int64 the sampling launch
+ * advances (the `col` of ttk_sample_args: tokens sampled so far), so step n's rows land in slot n of a [slots, B, D] buffer although the
+ * captured launch arguments never change -- what the streaming generator (unified_voice.py:670-679, stream_generator.py:1172) yields next to
+ * token n.  Pass base = NULL to switch it off.  Needs the default decode form (TTK_AR_HEAD_SPLIT=1, TTK_AR_SPLIT=1).                       */
+int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t stride);
+
 /* One sampled token per candidate, the body of HF `_sample` that stream_generator.py drives (warpers :56-101; HF:generation/
  * utils.py:2894-2937): probs = softmax(scores / temperature); next = multinomial(probs, 1) = argmax(probs / q) with q the caller's
  * Exp(1) noise [B, V] (torch `exponential_`, so the generator stream is the reference's); finished rows get `stop_token`;
@@ -99,7 +106,8 @@ int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream);
  * col[b] += 1; unfinished[b] &= next != stop_token.  suppress (optional) is a [V] byte mask of ids forced to -inf before the
  * temperature (SuppressTokensLogitsProcessor); any other warper is applied by the caller, who then passes temperature 1.
  * live_rows / all_done (optional): *live_rows (device int, caller sets it to the number of unfinished rows) is decremented when a
- * row finishes, and the row that brings it to 0 stores 1 to *all_done (device or pinned host int) -- HF's
+ * row finishes, and the row that brings it to 0 stores the number of tokens sampled so far (col + 1 >= 1: the generation ended WITH that
+ * token) to *all_done (device or pinned host int, zeroed by the caller) -- HF's
  * `unfinished_sequences.max() == 0` stopping test without a host round trip per token.  Pointers are device memory unless said
  * otherwise; only enqueues one kernel, so it may be captured in a HIP graph.                                               */
 int ttk_sample_step(const float* scores, int64_t ld, int B, int V, const float* q, int64_t ldq,

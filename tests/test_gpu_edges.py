@@ -114,6 +114,37 @@ def test_streaming_generator_stops_with_the_last_row(small_ar):
 	assert bool((out[-1][0] == cfg.stop_mel_token).all())
 
 
+def test_streaming_generator_is_the_sampling_loop_token_by_token(small_ar):
+	"""a6 on the fused path: the generator's tokens are the columns of what `inference_speech` returns for the same call, the
+	latents stay valid after it ends, the torch generator is left where the non-streaming loop leaves it; a consumer that walks away after three
+	tokens leaves it three draws in and the model usable (ring and noise switched off again)"""
+	model, _ = small_ar
+	text = torch.randint(1, 255, (1, 9), generator=gen(50)).to(DEV)
+	cond = torch.randn(1, 128, generator=gen(51)).to(DEV)
+	kw = dict(temperature=0.9, top_k=40, top_p=0.95, repetition_penalty=1.5)
+	ids = model.compute_embeddings(cond, text)
+	out = list(model.get_generator(inputs=ids, max_length=ids.shape[1] + 30, do_sample=True, num_return_sequences=4, **kw))
+	off_stream = torch.cuda.default_generators[0].get_offset()
+	toks = torch.stack([t for t, _ in out], 1).clone()
+	lats = torch.stack([l for _, l in out], 0).clone()
+	want = model.inference_speech(cond, text, do_sample=True, num_return_sequences=4, max_generate_length=30, **kw)
+	assert torch.equal(toks, want) and torch.cuda.default_generators[0].get_offset() == off_stream
+	assert torch.isfinite(lats).all() and torch.equal(lats, torch.stack([l for _, l in out], 0))      # untouched by the call that followed
+	# walk away after three tokens
+	g3 = model.get_generator(inputs=ids, max_length=ids.shape[1] + 30, do_sample=True, num_return_sequences=4, **kw)
+	first = [next(g3)[0].clone() for _ in range(3)]
+	g3.close()
+	torch.cuda.synchronize()
+	assert torch.equal(torch.stack(first, 1), want[:, :3])
+	torch.manual_seed(0); torch.cuda.manual_seed_all(0)
+	ref = torch.empty((4, 8194), device=DEV)
+	for _ in range(3):
+		ref.exponential_(1)
+	assert torch.cuda.default_generators[0].get_offset() == off_stream // toks.shape[1] * 3
+	again = model.inference_speech(cond, text, do_sample=True, num_return_sequences=4, max_generate_length=30, **kw)
+	assert torch.equal(again, want)
+
+
 @pytest.mark.parametrize("b,M,T", [(1, 1, 4), (2, 7, 30), (1, 40, 174), (3, 70, 129)])
 def test_diffusion_odd_lengths(small_diff, b, M, T):
 	"""Frame counts that straddle the 64-key attention tiles and the 128-row GEMM tiles; nearest-neighbour expansion M -> T."""

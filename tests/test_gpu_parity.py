@@ -268,7 +268,9 @@ def test_fused_sample_step_is_the_reference_sampling_chain():
 		assert torch.equal(ids, ref_ids[:, :steps - 1]) and torch.equal(hist[:, 3:], ref_ids) and bool((hist[:, :3] == -7).all())
 		assert torch.equal(unf2, unf) and bool((col == steps).all()) and torch.equal(after, after_ref)
 		# the all-done flag rises exactly at the step after which HF's `unfinished_sequences.max() == 0` holds
-		ref_done = [int(((ref_ids[:, :k + 1] == stop_id).any(dim=1)).all()) for k in range(steps)]
+		# ... and holds the number of tokens sampled at that step from then on (0 before): a host that runs ahead can tell where the end was
+		fin = [bool(((ref_ids[:, :k + 1] == stop_id).any(dim=1)).all()) for k in range(steps)]
+		ref_done = [(fin.index(True) + 1) if f else 0 for f in fin]
 		assert done_at == ref_done and int(live.item()) == int(unf.sum())
 	# argument checking: a null pointer / bad temperature is an error code with a message, not a crash
 	assert lib.ttk_sample_step(None, 0, 1, 1, None, 0, None, 1.0, 0, None, None, None, 0, 0, None, None, 0, 0, None, None, None) != 0

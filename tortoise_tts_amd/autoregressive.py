@@ -294,9 +294,7 @@ class UnifiedVoice:
 		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 50), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0),
 					suppress, typical_mass)
 		if stream:
-			pipe = LogitsPipeline(temperature=pipe_key[0], top_k=pipe_key[1], top_p=pipe_key[2], repetition_penalty=pipe_key[3],
-								  suppress_tokens=suppress, typical_mass=typical_mass, vocab=c.number_mel_codes, device=self.device)
-			return self._loop_stream(cond, text, B, max_new, pipe)
+			return self._loop_stream(cond, text, B, max_new, pipe_key, c.stop_mel_token not in suppress)
 		can_stop = c.stop_mel_token not in suppress
 		with torch.cuda.device(self.device):
 			st = self._gen_state(B, max_new, pipe_key, C, lo)
@@ -416,30 +414,85 @@ class UnifiedVoice:
 			states[key] = _GenState(self, B, max_new, pipe_key, C, lo, lines)
 		return states[key]
 
-	def _loop_stream(self, cond, text, B, max_new, pipe):
+	def _loop_stream(self, cond, text, B, max_new, pipe_key, can_stop):
 		"""stream_generator.py:1106-1190, pinned by the reference's own loop (tests/golden/sample_stream.npz): token k is yielded with
 		final_norm(hidden) of the forward it was sampled from -- the prefill's last row for the first token -- and every token is
-		yielded, the last one included; the loop ends after the token with which the last row finishes or after max_new tokens."""
+		yielded, the last one included; the loop ends after the token with which the last row finishes or after max_new tokens.
+
+		Same machinery as the non-streaming loop: the fused sampling launch (processors, warpers, multinomial, padding, next input row), the noise
+		drawn in the mel-head launch, ONE captured token step replayed per token.  Between two yields nothing runs on the host but a graph launch
+		and an event wait: the yielded tokens are a column of the state's id buffer, the latents a slot of a per-call [max_new, B, d] buffer that
+		the step's LayerNorm launch fills directly (ttk_ar_set_hidden_ring: the slot index is the device-side token counter, so the captured launch
+		serves every step).  The host runs LAG steps ahead of the consumer; HF's `unfinished_sequences.max() == 0` test (a host round trip per
+		token) is the pinned word the sampling kernel leaves -- the token count at which the last row finished -- read after the event of the
+		token about to be yielded.  The yielded tensors are views: the latents stay valid after the generator ends, the tokens until the next
+		generation of the same shape on this model."""
 		c = self.cfg
+		LAG = 2
 		with torch.cuda.device(self.device):
+			st = self._gen_state(B, max_new, pipe_key, B, 0)
 			setup_seed(0)
-			logits = self._prefill(cond, text, B)
-			hidden = torch.empty((B, c.model_dim), device=self.device, dtype=torch.float32)
-			_lib.check(self.lib.ttk_ar_last_hidden(self._h, hidden.data_ptr(), _lib.stream_ptr()), "ttk_ar_last_hidden")
-			unfinished = torch.ones(B, dtype=torch.long, device=self.device)
-			hist = torch.ones((B, text.shape[1] + 4), dtype=torch.long, device=self.device)
-			hist[:, -1] = c.start_mel_token
-			for n in range(max_new):
-				scores = pipe(hist if pipe.needs_history else None, logits)
-				nxt = multinomial1(torch.nn.functional.softmax(scores, dim=-1))
-				nxt = nxt * unfinished + c.stop_mel_token * (1 - unfinished)
-				yield nxt, hidden.clone()
-				unfinished = unfinished * (nxt != c.stop_mel_token).long()
-				if pipe.needs_history:
-					hist = torch.cat([hist, nxt[:, None]], dim=-1)
-				if n + 1 >= max_new or int(unfinished.max()) == 0:
-					return
-				self._decode(nxt, logits, hidden)
+			gen = torch.cuda.default_generators[self.device.index or 0]
+			off_start = gen.get_offset()
+			st.reset(c)
+			if st.own_rng:
+				st.arm_noise(gen, 0)
+			hid = torch.empty((max_new, B, c.model_dim), device=self.device, dtype=torch.float32)
+			fast = self.use_graph and st.graphable and st.own_rng        # captured step; else the same launches issued eagerly
+			n_done = 0
+			try:
+				st.logits.copy_(self._prefill(cond, text, B))
+				_lib.check(self.lib.ttk_ar_last_hidden(self._h, hid[0].data_ptr(), _lib.stream_ptr()), "ttk_ar_last_hidden")
+				_lib.check(self.lib.ttk_ar_set_hidden_ring(self._h, hid.data_ptr(), st.col.data_ptr(), B * c.model_dim), "ttk_ar_set_hidden_ring")
+				events, produced = [], 0
+				while True:
+					while produced < min(max_new, n_done + 1 + LAG):       # tokens n_done .. n_done + LAG sampled or in flight
+						if produced == 0:
+							st.sample(0)
+							if st.rng_step is None:
+								st.rng_step = gen.get_offset() - off_start       # what one torch-drawn token consumes (0 with the head-drawn noise)
+						elif fast and st.stream_graph is not None:
+							_lib.check(self.lib.ttk_graph_launch(st.stream_graph_exec, _lib.stream_ptr()), "ttk_graph_launch")
+						elif fast and produced >= 2:
+							# capture {decode_next into the ring; sample}: step 1 ran eagerly (warm kernels), the stream is idle of other work
+							torch.cuda.synchronize(self.device)
+							g = torch.cuda.CUDAGraph()
+							ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
+							with torch.inference_mode(False):
+								ctx.__enter__()
+							try:
+								self._decode_next(st.logits)
+								st.sample(0)
+							except BaseException:
+								with torch.inference_mode(False):
+									ctx.__exit__(*__import__("sys").exc_info())
+								raise
+							with torch.inference_mode(False):
+								ctx.__exit__(None, None, None)
+							st.stream_graph, st.stream_graph_exec = g, g.raw_cuda_graph_exec()
+							continue
+						else:
+							self._decode_next(st.logits)
+							st.sample(produced)
+						ev = torch.cuda.Event()
+						ev.record()
+						events.append(ev)
+						produced += 1
+					events[n_done].synchronize()                               # token n_done and its flag are there
+					yield st.ids[:, n_done], hid[n_done]
+					n_done += 1
+					end = int(st.done[0]) if can_stop else 0                   # tokens sampled when the last row finished (0: still running)
+					if n_done >= max_new or (end and end <= n_done):
+						return
+			finally:
+				_lib.check(self.lib.ttk_ar_set_hidden_ring(self._h, None, None, 0), "ttk_ar_set_hidden_ring")
+				if st.own_rng:
+					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
+					# the generator where the reference's loop leaves it: one draw per token it produced (steps sampled ahead of an early end drew nothing
+					# from torch; without the head-drawn noise they did, and are handed back)
+					gen.set_offset(off_start + n_done * st.noise_step)
+				elif st.rng_step:
+					gen.set_offset(off_start + n_done * st.rng_step)
 
 
 class _GenState:
@@ -501,6 +554,8 @@ class _GenState:
 		self.args = a
 		self.graph = None
 		self.graph_exec = None
+		self.stream_graph = None          # the streaming generator's captured step (it also fills the hidden ring)
+		self.stream_graph_exec = None
 
 	def _noise_geometry(self, dev):
 		"""(threads, offset step per draw) of ATen's launch for `self.q.exponential_()` (ATen/native/cuda/DistributionTemplates.h:

@@ -94,6 +94,7 @@ struct ttk_ar {
 	int share_prefix = 1;   // TTK_AR_SHARE_PREFIX=0: every candidate reads its own copy
 	// multinomial noise drawn by the mel-head launch (ttk_ar_set_noise): device RngArgs, per-row draw counters, q rows of this handle's candidates
 	const int64_t* rng_args = nullptr; const int64_t* rng_draws = nullptr; float* rng_q = nullptr;
+	float* ring_base = nullptr; const int64_t* ring_idx = nullptr; int64_t ring_stride = 0;      // ttk_ar_set_hidden_ring
 	int head_split = 1;     // decode head as LayerNorm launch + plain GEMV (TTK_AR_HEAD_SPLIT=0: norms inside the GEMV)
 	int lnfold = 1;         // ln_1 + c_attn and ln_2 + c_fc of the decode step with the LayerNorm folded into the matrix (TTK_AR_LNFOLD=0: LN prologue)
 	int lean = 1;           // decode launches on the compile-time-specialised kernels of gemv.hip where one exists (TTK_AR_LEAN=0: k_skinny everywhere)
@@ -244,7 +245,8 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	if (h->head_split && whole) {
 		// ln_f + final_norm ONCE (4 workgroups), the mel head as a plain 513-tile GEMV over the normalised rows in fragment order: with the
 		// norms inside the GEMV every one of the 513 workgroups normalised all 16 rows, two passes each -- 17 us for 16.8 MB of weights
-		launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, hid);
+		if (h->ring_base && !hid) launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, h->ring_base, h->ring_idx, h->ring_stride);
+		else launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, hid);
 		p.a = h->attn_out; p.lda = d; p.a_frag = 1;
 		GemvParams gh = {};
 		gh.Wp = p.Wp; gh.a = h->attn_out; gh.bias = p.bias; gh.out_f32 = p.out_f32; gh.d_pos = p.d_pos; gh.noise = p.qbuf; gh.rng = p.slab; gh.draws = (const int64_t*)p.tickets;
@@ -455,6 +457,7 @@ static int decode_impl(ttk_ar* h, const int64_t* tok, float* logits_out, float* 
 	TTK_REQUIRE(h->Pmax + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "%s: KV cache full (max_ctx=%d)", who, c.max_ctx);
 	TTK_REQUIRE((h->lnfold && h->nsplit == 1) || B <= 32, TTK_E_STATE, "%s: the LayerNorm-prologue decode kernels (TTK_AR_LNFOLD=0 / TTK_AR_SPLIT) hold at most 32 candidates' rows in LDS; B=%d", who, B);
 	TTK_REQUIRE(h->k + 2 < c.max_mel_seq_len, TTK_E_STATE, "%s: mel position table exhausted (%d rows)", who, c.max_mel_seq_len);
+	TTK_REQUIRE(!h->ring_base || (h->head_split && h->nsplit == 1), TTK_E_STATE, "%s: the hidden ring needs the default decode form (TTK_AR_HEAD_SPLIT=1, TTK_AR_SPLIT=1)", who);
 	hipStream_t s = (hipStream_t)stream;
 	// x[b] = mel_embedding[tok] + mel_pos[k + 1]; *d_pos = P + k rows are cached  =>  offset 1 - P   (unified_voice.py:213-214)
 	// (tok == null: ttk_ar_sample_next has written the rows already)
@@ -506,6 +509,13 @@ int ttk_ar_set_noise(ttk_ar* h, const int64_t* rng_args, const int64_t* draws, f
 	TTK_REQUIRE(h, TTK_E_ARG, "ttk_ar_set_noise: null handle");
 	TTK_REQUIRE((rng_args && draws && q) || (!rng_args && !draws && !q), TTK_E_ARG, "ttk_ar_set_noise: pass all three pointers or none");
 	h->rng_args = rng_args; h->rng_draws = draws; h->rng_q = q;
+	return TTK_OK;
+}
+
+int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t stride) {
+	TTK_REQUIRE(h, TTK_E_ARG, "ttk_ar_set_hidden_ring: null handle");
+	TTK_REQUIRE(!base || (index && stride >= 0), TTK_E_ARG, "ttk_ar_set_hidden_ring: a ring needs its device index and a stride");
+	h->ring_base = base; h->ring_idx = base ? index : nullptr; h->ring_stride = base ? stride : 0;
 	return TTK_OK;
 }
 

@@ -364,6 +364,8 @@ template <typename T, int NW, int UN, bool ROWS = false>
 __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	typedef typename Frag<T>::type FragT;
 	constexpr int NP = NW * 8;           // (wave, slot) partial softmaxes
+	TTK_PIN_ARGS(TTK_S(p.qbuf), TTK_S(p.kcache), TTK_S(p.vcache), TTK_S(p.d_pos), TTK_S(p.H), TTK_S(p.max_ctx), TTK_S(p.out), TTK_S(p.out_frag),
+				 TTK_S(p.row_info), TTK_S(p.shared_rows));
 	const int h = blockIdx.x, b = blockIdx.y;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int slot = lane >> 3, dg = lane & 7;

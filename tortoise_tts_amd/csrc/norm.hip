@@ -16,10 +16,11 @@ namespace ttk {
 // frag != 0: `out` is written in the MFMA A-fragment order of the skinny decode GEMV ([m_tile][d/32][lane][8], skinny.hip) instead of row-major
 template <typename OT>
 __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
-							const float* g2, const float* b2, OT* out, int64_t ldo, int frag, float* out2) {
+							const float* g2, const float* b2, OT* out, int64_t ldo, int frag, float* out2, const int64_t* out2_idx, int64_t out2_stride) {
 	const int lane = threadIdx.x & 63;
 	const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (row >= rows) return;
+	if (out2 && out2_idx) out2 += out2_idx[0] * out2_stride;      // slot of a ring the caller advances on the device (ttk_ar_set_hidden_ring)
 	const int nchunk = d / 4;
 	float4 v[16];
 #pragma unroll
@@ -67,15 +68,16 @@ __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const 
 }
 
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
-					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s, int frag, float* out2) {
+					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s, int frag, float* out2,
+					  const int64_t* out2_idx, int64_t out2_stride) {
 	ProfScope prof(PROF_LAYERNORM, (double)rows * d * (4.0 + (out_f32 ? 4.0 : dtype_size(dt))), s);
 	const int grid = (rows + 3) / 4;
 	if (out_f32 || dt == DT_F32)
-		hipLaunchKernelGGL((k_layernorm<float>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (float*)out, ldo, frag, out2);
+		hipLaunchKernelGGL((k_layernorm<float>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (float*)out, ldo, frag, out2, out2_idx, out2_stride);
 	else if (dt == DT_F16)
-		hipLaunchKernelGGL((k_layernorm<f16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (f16*)out, ldo, frag, out2);
+		hipLaunchKernelGGL((k_layernorm<f16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (f16*)out, ldo, frag, out2, out2_idx, out2_stride);
 	else
-		hipLaunchKernelGGL((k_layernorm<bf16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (bf16*)out, ldo, frag, out2);
+		hipLaunchKernelGGL((k_layernorm<bf16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (bf16*)out, ldo, frag, out2, out2_idx, out2_stride);
 }
 
 // ---------------------------------------------------------------- GroupNorm32

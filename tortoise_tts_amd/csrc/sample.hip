@@ -286,10 +286,11 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(SampleParams p) 
 		p.unfinished[b] = still;
 		s_next = nxt;
 		// stopping criterion without a host round trip per token: the row that finishes last raises a flag the host can poll (the
-		// flag may live in pinned host memory; it only ever goes 0 -> 1 within a generation, so a late read is merely late)
+		// flag may live in pinned host memory; it changes once within a generation, 0 -> the number of tokens sampled when the last row
+		// finished, so a late read is merely late and a reader that runs ahead can still tell WHERE the generation ended)
 		if (p.live_rows && live != 0 && still == 0) {
 			if (__hip_atomic_fetch_add(p.live_rows, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1 && p.all_done)
-				__hip_atomic_store(p.all_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(p.all_done, (int)(c0 + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 	}
 	if (p.x_out) {

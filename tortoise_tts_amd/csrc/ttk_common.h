@@ -134,6 +134,13 @@ __device__ __forceinline__ void l2_touch_for_next(const void* base, int64_t byte
 			}
 		}
 }
+// Kernel arguments into SGPRs as ONE batch of scalar loads behind one wait, at the top of the kernel.  Left alone hipcc sinks every argument's
+// load next to its first use, behind branches: the generic decode GEMV made four DEPENDENT round trips to its argument block (~0.3 us each,
+// cold scalar cache after every kernel boundary) before its first weight request, the dense GEMM six (tests/diag/ar_chain.cpp).  An empty asm
+// that names the fields as SGPR inputs pins them: all loads are issued together, one s_waitcnt follows.  Up to 30 operands per statement.
+#define TTK_PIN_ARGS(...) asm volatile("" :: __VA_ARGS__)
+#define TTK_S(x) "s"(x)
+
 __device__ __forceinline__ unsigned lds_byte_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 
 }  // namespace ttk
