@@ -92,6 +92,13 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
  * from the same forward's logits (stream_generator.py:1172) -- for the first token that is the prefill's row.                     */
 int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream);
 
+/* What the decode step's folded LayerNorm (ln_1 + c_attn, ln_2 + c_fc as one matrix over the UN-normalised rows, T-typed) could not represent
+ * well since the last call: bit 0 = a row of the residual stream had |mean| > 8 std (more than 3 of the operand's significand bits went to the
+ * common offset the norm removes: results drift from the reference's LayerNorm-then-matmul; TTK_AR_LNFOLD=0 selects the form that normalises
+ * in f32 first), bit 1 = non-finite row statistics (an f16 operand above 65504).  Synchronises `stream`, clears the word.  No reference
+ * counterpart: the fold is this library's, so is the duty to say when it does not apply.                                                   */
+int ttk_ar_health(ttk_ar* h, int* flags_out, void* stream);
+
 /* The same rows for EVERY decode step of a captured token loop, without a per-step pointer: while set, each ttk_ar_decode / ttk_ar_decode_next
  * also writes final_norm(ln_f(h)) [B, D] f32 of its new rows to base + index[0] * stride (elements), `index` a device int64 the sampling launch
  * advances (the `col` of ttk_sample_args: tokens sampled so far), so step n's rows land in slot n of a [slots, B, D] buffer although the

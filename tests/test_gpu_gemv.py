@@ -106,3 +106,60 @@ def test_rows_do_not_depend_on_the_batch_they_ride_in(ar_sd, dtype):
 				ref = out
 			else:
 				assert torch.equal(out, ref), (B, (out - ref).abs().max().item())
+
+
+def _with_env(name, value, fn):
+	old = os.environ.get(name)
+	os.environ[name] = value
+	try:
+		return fn()
+	finally:
+		if old is None:
+			os.environ.pop(name)
+		else:
+			os.environ[name] = old
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_folded_layernorm_on_outlier_channels_and_on_a_common_offset(ar_sd, dtype):
+	"""the folded launches multiply the UN-normalised residual row (T-typed) and finish the norm in the epilogue, so their rounding
+	error scales with |x|, not |x - mean|.  (a) outlier channels -- what trained GPT-2 streams have: a few channels hundreds of times the rest --
+	inflate the row's std with them, the normalised value carries the same relative error either way: fold == LayerNorm-prologue form within the
+	16-bit bar.  (b) a COMMON offset of 40 std is what the fold cannot carry: the launch says so (ttk_ar_health -> RuntimeWarning) instead of
+	drifting silently, and the prologue form (TTK_AR_LNFOLD=0) still matches the f32 arithmetic."""
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	import warnings
+	g = torch.Generator().manual_seed(91)
+	text = torch.randint(1, 255, (1, 20), generator=g)
+	cond = torch.randn(1, 1024, generator=g)
+	toks = torch.randint(0, 8192, (16, 6), generator=g)
+	mk = lambda sd, dt, fold: _with_env("TTK_AR_LNFOLD", "1" if fold else "0", lambda: UnifiedVoice(sd, W.AR_FULL, dtype=dt, device=DEV, max_batch=16, max_ctx=20 + 4 + 16))
+	tol = 3e-2 if dtype == "bf16" else 4e-3
+	# (a) outlier channels in the embeddings the decode rows are built from
+	sd = dict(ar_sd)
+	emb = sd["mel_embedding.weight"].clone()
+	scale = emb.std().item()
+	emb[:, 7] += 300 * scale
+	emb[:, 500] -= 150 * scale
+	sd["mel_embedding.weight"] = emb
+	with torch.inference_mode(), warnings.catch_warnings():
+		warnings.simplefilter("error")                                   # no health warning on this stream
+		ref = forced(mk(sd, "f32", False), cond, text, toks)
+		a = forced(mk(sd, dtype, True), cond, text, toks)
+		b = forced(mk(sd, dtype, False), cond, text, toks)
+		m = mk(sd, dtype, True)
+		m.inference_speech(cond.to(DEV), text.to(DEV), do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16, max_generate_length=6)
+		assert m.last_health == 0
+	for k in range(1, a.shape[1]):
+		assert relerr(a[:, k], ref[:, k]) < tol and relerr(b[:, k], ref[:, k]) < tol, (k, relerr(a[:, k], ref[:, k]), relerr(b[:, k], ref[:, k]))
+	# (b) a common offset: every channel of every mel embedding row shifted by 40 std
+	sd = dict(ar_sd)
+	sd["mel_embedding.weight"] = ar_sd["mel_embedding.weight"] + 40 * scale
+	with torch.inference_mode():
+		ref = forced(mk(sd, "f32", False), cond, text, toks)
+		b = forced(mk(sd, dtype, False), cond, text, toks)
+		assert relerr(b[:, 1], ref[:, 1]) < tol                           # the prologue form normalises in f32 first: unaffected
+		m = mk(sd, dtype, True)
+		with pytest.warns(RuntimeWarning, match="TTK_AR_LNFOLD=0"):
+			m.inference_speech(cond.to(DEV), text.to(DEV), do_sample=True, temperature=0.8, top_k=0, num_return_sequences=16, max_generate_length=4)
+		assert m.last_health & 1

@@ -331,6 +331,88 @@ def test_warpers_inside_the_sampling_kernel_equal_the_torch_op_chain(temp, top_k
 		assert torch.equal(ids, torch.stack([torch.where(mask, -float("inf"), lg).argmax(-1) for lg in logits], 1))   # greedy = argmax of what is left
 
 
+def _probe_kept(lib, lg, probe, temp, top_k, top_p):
+	"""is token probe[b] of row b still there after the kernel's warpers?  The noise is 1 everywhere except a vanishing value at the probe: a kept
+	probe wins argmax(p / q) whatever its probability, a removed one (p = 0) cannot."""
+	from tortoise_tts_amd import _lib
+	B, V = lg.shape
+	q = torch.ones((B, V), device=DEV)
+	q[torch.arange(B, device=DEV), probe] = 1e-30
+	unf = torch.ones(B, dtype=torch.long, device=DEV)
+	tok = torch.empty(B, dtype=torch.long, device=DEV)
+	ids = torch.full((B, 1), -1, dtype=torch.long, device=DEV)
+	col = torch.zeros(B, dtype=torch.long, device=DEV)
+	a = _lib.SampleArgs()
+	a.scores, a.ld, a.B, a.V, a.q, a.ldq = lg.data_ptr(), V, B, V, q.data_ptr(), V
+	a.temperature, a.top_k, a.top_p, a.repetition_penalty = temp, top_k, top_p, 1.0
+	a.stop_token, a.unfinished, a.tok, a.ids, a.ids_ld, a.ids_cols, a.col = V + 5, unf.data_ptr(), tok.data_ptr(), ids.data_ptr(), 1, 1, col.data_ptr()
+	_lib.check(lib.ttk_sample_step_warped(_lib.C.byref(a), _lib.stream_ptr()), "ttk_sample_step_warped")
+	torch.cuda.synchronize()
+	return tok == probe
+
+
+def test_top_p_boundary_stress():
+	"""the in-kernel top-p takes its cut from exact 2^-40 fixed-point masses, HF's TopPLogitsWarper from an f32 `cumsum` (a parallel
+	scan: its rounding pattern is the library's) of the sorted f32 probabilities.  Probing the kernel's kept set at the boundary -- the least
+	likely token the torch chain keeps, the most likely one it removes -- over 24 batches x 16 rows x 8 values of top_p (peaked and flat rows):
+	the two disagree only where the ascending cumulative mass at that token, summed in f64, lies within f32 rounding of 1 - top_p (a tie the
+	two roundings break differently), and in well under 1 % of the rows.  `UnifiedVoice(..., hf_exact_top_p=True)` runs HF's warper as torch
+	ops in front of the kernel for callers that need its rounding bit for bit."""
+	from tortoise_tts_amd import _lib
+	from tortoise_tts_amd.sampling import LogitsPipeline
+	lib = _lib.load()
+	B, V = 16, 8194
+	g = torch.Generator().manual_seed(77)
+	checked, ties = 0, []
+
+	def cum_mass_at(scaled_row, idx):
+		"""ascending cumulative softmax mass up to and including token idx, in f64"""
+		p = torch.softmax(scaled_row.double(), dim=-1)
+		return float(p[scaled_row <= scaled_row[idx]].sum())
+
+	for trial in range(24):
+		scale = [0.5, 1.0, 2.0, 4.0, 8.0, 16.0][trial % 6]
+		lg = (torch.randn((B, V), generator=g) * scale).to(DEV)
+		temp = [1.0, 0.8, 1.3][trial % 3]
+		for top_p in (0.05, 0.3, 0.5, 0.7, 0.9, 0.95, 0.99, 0.999):
+			sc = LogitsPipeline(temperature=temp, top_p=top_p, vocab=V, device=DEV)(None, lg)
+			kept = torch.isfinite(sc)
+			scaled = lg / temp
+			least_kept = torch.where(kept, scaled, torch.full_like(scaled, float("inf"))).argmin(dim=-1)
+			ok_kept = _probe_kept(lib, lg, least_kept, temp, 0, top_p)
+			has_removed = (~kept).any(dim=-1)
+			top_removed = torch.where(~kept, scaled, torch.full_like(scaled, float("-inf"))).argmax(dim=-1)
+			wrongly_kept = _probe_kept(lib, lg, top_removed, temp, 0, top_p) & has_removed
+			for b in torch.nonzero(~ok_kept | wrongly_kept).flatten().tolist():
+				idx = int(top_removed[b]) if bool(wrongly_kept[b]) else int(least_kept[b])
+				cm = cum_mass_at(scaled[b].cpu(), idx)
+				# the torch chain removes a token iff its cumulative mass <= 1 - top_p: a disagreement about it must sit ON that threshold
+				ties.append((trial, top_p, b, abs(cm - (1 - top_p))))
+			checked += B
+	assert checked == 24 * 8 * 16
+	assert all(t[3] < 2e-6 for t in ties), ties                      # only ties within f32 rounding of the threshold
+	assert len(ties) <= checked // 100, (len(ties), checked)
+	print(f"\n[top-p] {len(ties)} boundary ties in {checked} rows: {ties}")
+
+
+def test_top_k_treats_the_two_zeros_as_equal():
+	"""`scores < kth` compares values: with a k-th largest score of +0.0 the -0.0 entries stay, as in torch (the radix key of -0.0 sorts below
+	+0.0 as a bit pattern; the kernel canonicalises it)"""
+	from tortoise_tts_amd import _lib
+	lib = _lib.load()
+	B, V = 4, 8194
+	lg = torch.full((B, V), -5.0, device=DEV)
+	lg[:, :10] = 3.0
+	lg[:, 100:120] = 0.0
+	lg[:, 200:220] = -0.0
+	assert bool(torch.signbit(lg[:, 200]).all())
+	kth = torch.topk(lg, 15)[0][..., -1, None]
+	assert bool((kth == 0).all()) and not bool((lg[:, 200:220] < kth).any())               # torch keeps them
+	for probe in (200, 219, 100, 5):
+		assert bool(_probe_kept(lib, lg, torch.full((B,), probe, device=DEV), 1.0, 15, 1.0).all()), probe
+	assert not bool(_probe_kept(lib, lg, torch.full((B,), 300, device=DEV), 1.0, 15, 1.0).any())      # -5: below the k-th largest
+
+
 def test_sampling_kernel_rejects_what_it_cannot_do():
 	from tortoise_tts_amd import _lib
 	lib = _lib.load()

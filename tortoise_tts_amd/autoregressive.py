@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import dataclasses
 import os
+import warnings
 from typing import Dict, Iterator, Optional, Tuple
 
 import torch
@@ -29,7 +30,12 @@ from .weights import ARConfig, ar_shapes
 
 class UnifiedVoice:
 	def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: ARConfig = ARConfig(), dtype: str = "bf16",
-				 device: str = "cuda:0", max_batch: int = 16, max_ctx: Optional[int] = None, use_graph: bool = True):
+				 device: str = "cuda:0", max_batch: int = 16, max_ctx: Optional[int] = None, use_graph: bool = True,
+				 hf_exact_top_p: bool = False):
+		"""hf_exact_top_p: run HF's TopPLogitsWarper as torch ops in front of the sampling kernel when top_p < 1 (its f32 cumsum rounding, bit for
+		bit) instead of the kernel's exact fixed-point cut -- the two differ only on rows whose cumulative mass ties with 1 - top_p within f32
+		rounding (csrc/sample.hip; tests/test_gpu_parity.py::test_top_p_boundary_stress); costs the per-token torch launches the kernel removed."""
+		self.hf_exact_top_p = hf_exact_top_p
 		self.cfg = cfg
 		self.device = torch.device(device)
 		if self.device.type != "cuda":
@@ -119,6 +125,20 @@ class UnifiedVoice:
 	def _decode_next(self, logits: torch.Tensor, hidden: Optional[torch.Tensor] = None):
 		"""the same step started from the input row the fused sampling launch (ttk_ar_sample_next) left in the handle"""
 		_lib.check(self.lib.ttk_ar_decode_next(self._h, logits.data_ptr(), _lib.ptr(hidden), _lib.stream_ptr()), "ttk_ar_decode_next")
+
+	def _check_health(self):
+		"""after a generation: did the decode step's folded LayerNorm meet rows it cannot represent well (include/ttk.h: ttk_ar_health)?  The
+		reference has no such failure mode -- it normalises in f32 before the matmul -- so the deviation is reported where it can occur."""
+		flags = _lib.C.c_int(0)
+		_lib.check(self.lib.ttk_ar_health(self._h, _lib.C.byref(flags), _lib.stream_ptr()), "ttk_ar_health")
+		self.last_health = flags.value
+		if flags.value & 1:
+			warnings.warn("tortoise_tts_amd: a row of the GPT-2 residual stream had |mean| > 8 std during decoding; the folded-LayerNorm launches lose "
+						  "precision on such rows (set TTK_AR_LNFOLD=0 before building the model for the form that normalises in f32 first)", RuntimeWarning)
+		if flags.value & 2:
+			warnings.warn("tortoise_tts_amd: non-finite LayerNorm statistics during decoding (an fp16 operand above 65504?); "
+						  "use dtype='bf16' or TTK_AR_LNFOLD=0", RuntimeWarning)
+		return flags.value
 
 	# ------------------------------------------------------------------ reference surface
 	def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths, types=None,
@@ -242,6 +262,7 @@ class UnifiedVoice:
 				if st.own_rng:
 					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
 			step = st.noise_step if st.own_rng else (gen.get_offset() - off_start) // max(n, 1)
+			self._check_health()
 			ids = st.ids[:, :n]
 			first_stop = torch.where((ids == c.stop_mel_token).any(dim=1), (ids == c.stop_mel_token).float().argmax(dim=1), torch.full((B,), n, device=ids.device)).view(G, C)
 			done = bool(can_stop) & (first_stop < n).all(dim=1)
@@ -313,6 +334,7 @@ class UnifiedVoice:
 				gen.set_offset(off_start + n * st.noise_step)        # what n torch draws would have consumed
 			# what the sampling consumed from the generator: dist.py aligns a shard's stream with the unsharded run's from this
 			self.last_generate = dict(steps=n, rng_start=off_start, rng_step=(gen.get_offset() - off_start) // max(n, 1))
+			self._check_health()
 			return st.ids[:, :n].clone(), None
 
 	def _token_loop(self, st, gen, off_start, prefill, max_new, can_stop):
@@ -493,6 +515,7 @@ class UnifiedVoice:
 					gen.set_offset(off_start + n_done * st.noise_step)
 				elif st.rng_step:
 					gen.set_offset(off_start + n_done * st.rng_step)
+				self._check_health()
 
 
 class _GenState:
@@ -533,7 +556,7 @@ class _GenState:
 		# asked for, runs as torch ops in front of it in HF's order (after the processors, before temperature), which means the
 		# processors then run as torch ops too and the kernel sees finished scores for that part
 		p = self.pipe
-		self.in_kernel = p.typical_mass is None and c.number_mel_codes <= 9216
+		self.in_kernel = p.typical_mass is None and c.number_mel_codes <= 9216 and not (model.hf_exact_top_p and p.top_p is not None)
 		self.graphable = self.in_kernel or not p.needs_history      # torch-op penalty: its history slice grows with the host's step count
 		a = _lib.SampleArgs()
 		a.ld, a.B, a.V = self.logits.stride(0), B, c.number_mel_codes

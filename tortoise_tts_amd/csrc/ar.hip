@@ -94,6 +94,7 @@ struct ttk_ar {
 	int share_prefix = 1;   // TTK_AR_SHARE_PREFIX=0: every candidate reads its own copy
 	// multinomial noise drawn by the mel-head launch (ttk_ar_set_noise): device RngArgs, per-row draw counters, q rows of this handle's candidates
 	const int64_t* rng_args = nullptr; const int64_t* rng_draws = nullptr; float* rng_q = nullptr;
+	int* d_health = nullptr;  // GemvParams.health of the folded launches (ttk_ar_health reads and clears it)
 	float* ring_base = nullptr; const int64_t* ring_idx = nullptr; int64_t ring_stride = 0;      // ttk_ar_set_hidden_ring
 	int head_split = 1;     // decode head as LayerNorm launch + plain GEMV (TTK_AR_HEAD_SPLIT=0: norms inside the GEMV)
 	int lnfold = 1;         // ln_1 + c_attn and ln_2 + c_fc of the decode step with the LayerNorm folded into the matrix (TTK_AR_LNFOLD=0: LN prologue)
@@ -202,7 +203,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		p.mode = SK_QKV; p.qbuf = qbuf; p.kcache = kc; p.vcache = vc; p.d_pos = h->d_pos; p.max_ctx = c.max_ctx; p.H = H; p.q_scale = 0.125f;
 		GemvParams gq = {};
 		gq.Wp = p.Wp; gq.a = xf; gq.bias = p.bias; gq.csum = p.g1; gq.qbuf = qbuf; gq.kcache = kc; gq.vcache = vc; gq.d_pos = h->d_pos;
-		gq.M = nrows; gq.N = 3 * d; gq.K = d; gq.max_ctx = c.max_ctx; gq.H = H; gq.q_scale = 0.125f;
+		gq.M = nrows; gq.N = 3 * d; gq.K = d; gq.max_ctx = c.max_ctx; gq.H = H; gq.q_scale = 0.125f; gq.health = h->d_health;
 		if (!(lean && fold_qkv && launch_gemv(dt, GV_QKV, gq, s))) launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
 		AttnDecodeParams a = {};
 		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 && h->share_prefix && h->nsplit == 1;
@@ -221,7 +222,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		else { p.ln_count = 1; p.x = x; p.ldx = d; p.g1 = L.ln2_g; p.b1 = L.ln2_b; }
 		p.mode = SK_ACT_T; p.act = ACT_GELU_NEW; p.out_T = hbuf; p.out_frag = h->hfrag && r0 == 0 && nrows == h->B;
 		GemvParams gf = {};
-		gf.Wp = p.Wp; gf.a = xf; gf.bias = p.bias; gf.csum = p.g1; gf.out_T = hbuf; gf.M = nrows; gf.N = 4 * d; gf.K = d;
+		gf.Wp = p.Wp; gf.a = xf; gf.bias = p.bias; gf.csum = p.g1; gf.out_T = hbuf; gf.M = nrows; gf.N = 4 * d; gf.K = d; gf.health = h->d_health;
 		if (!(lean && fold_fc && p.out_frag && launch_gemv(dt, GV_FC, gf, s))) launch_skinny(dt, p, fold_fc ? wv_small : wv_prologue, s);
 		p = {};
 		p.Wp = L.proj2.wfrag; p.w8 = L.proj2.w8; p.wscale = L.proj2.wscale; p.N = d; p.K = 4 * d; p.M = nrows; p.bias = L.proj2.bias; p.a = hbuf; p.lda = 4 * d; p.a_frag = h->hfrag && r0 == 0 && nrows == h->B;
@@ -312,6 +313,7 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	AR_TRY(h->arena.alloc(&h->vc, h->kv_layer_stride * cfg->layers * h->es));
 	AR_TRY(h->arena.alloc((void**)&h->d_pos, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)));
 	h->d_rowinfo = (int2*)(h->d_pos + 4);
+	h->d_health = h->d_pos + 2;      // (words 2, 3 of the block are otherwise unused; zeroed with it below)
 	if (hipMemset(h->d_pos, 0, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
@@ -516,6 +518,15 @@ int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t
 	TTK_REQUIRE(h, TTK_E_ARG, "ttk_ar_set_hidden_ring: null handle");
 	TTK_REQUIRE(!base || (index && stride >= 0), TTK_E_ARG, "ttk_ar_set_hidden_ring: a ring needs its device index and a stride");
 	h->ring_base = base; h->ring_idx = base ? index : nullptr; h->ring_stride = base ? stride : 0;
+	return TTK_OK;
+}
+
+int ttk_ar_health(ttk_ar* h, int* flags_out, void* stream) {
+	TTK_REQUIRE(h && flags_out, TTK_E_ARG, "ttk_ar_health: null argument");
+	hipStream_t s = (hipStream_t)stream;
+	TTK_HIP(hipMemcpyAsync(flags_out, h->d_health, sizeof(int), hipMemcpyDeviceToHost, s));
+	TTK_HIP(hipStreamSynchronize(s));
+	if (*flags_out) launch_set_int(h->d_health, 0, s);
 	return TTK_OK;
 }
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemv(GemvParams p) {
 	// every argument into SGPRs NOW, as one batch of scalar loads behind one wait (left alone the compiler fetches each field next to its first
 	// use: four dependent round trips before the first weight request)
 	asm volatile("" :: "s"(p.Wp), "s"(p.a), "s"(p.bias), "s"(p.csum), "s"(p.out_f32), "s"(p.out_T), "s"(p.qbuf), "s"(p.kcache), "s"(p.vcache),
-				 "s"(p.d_pos), "s"(p.noise), "s"(p.rng), "s"(p.draws), "s"(p.M), "s"(p.N), "s"(p.max_ctx), "s"(p.H), "s"(p.row0), "s"(p.q_scale), "s"(p.wscale));
+				 "s"(p.d_pos), "s"(p.noise), "s"(p.rng), "s"(p.draws), "s"(p.health), "s"(p.M), "s"(p.N), "s"(p.max_ctx), "s"(p.H), "s"(p.row0), "s"(p.q_scale), "s"(p.wscale));
 	GV_STAMP(0);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	int nt, sub = 0;
@@ -247,8 +247,14 @@ __global__ __launch_bounds__(64 * NW) void k_gemv(GemvParams p) {
 #pragma unroll
 			for (int w = 0; w < NW; ++w) { const float2 t = *(const float2*)(rstat + ((w * MT + mt) * 16 + 4 * (l2 >> 4) + r) * 2); a1 += t.x; a2 += t.y; }
 			const float mean = a1 / (float)(32 * KS);
-			const float rstd = rsqrtf(fmaxf(a2 / (float)(32 * KS) - mean * mean, 0.f) + 1e-5f);      // E[x^2] - mean^2 in f32, as the LN prologue does
+			const float var = fmaxf(fmaf(-mean, mean, a2 / (float)(32 * KS)), 0.f);      // the fused form k_skinny's `a2 / K - mean * mean` contracts to
+			const float rstd = rsqrtf(var + 1e-5f);      // E[x^2] - mean^2 in f32, as the LN prologue does
 			v = (vs - mean * fcs) * rstd + bias;
+			// what the fold cannot represent well is reported, not hidden (one workgroup looks; the branch is never taken on a healthy stream)
+			if (p.health && blockIdx.x == 0 && (l2 & 15) == 0) {
+				const int bad = (mean * mean > 64.f * (var + 1e-5f) ? 1 : 0) | (a2 - a2 != 0.f ? 2 : 0);
+				if (bad) atomicOr(p.health, bad);
+			}
 		} else {
 			v = (W8 ? vs * p.wscale : vs) + bias;
 		}

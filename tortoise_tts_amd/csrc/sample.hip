@@ -17,6 +17,12 @@
 // pass) -- counts for top-k, fixed-point probability mass (p * 2^40 as 64-bit integers, so the sums are exact and independent of the
 // order in which the atomics land: bitwise reproducible) for top-p.  Everything at or above the threshold VALUE is kept, which is what
 // `scores < kth` / the sorted cumulative sum do except inside a group of exactly equal scores that straddles the top-p boundary.
+// Known deviation of top-p: HF's TopPLogitsWarper takes the cut from an f32 `cumsum` (a parallel scan) of the sorted f32
+// probabilities compared with 1 - top_p, i.e. from sums that carry f32 rounding; here the masses are exact 2^-40 fixed-point integers.  A row
+// whose ascending cumulative mass at some token ties with 1 - top_p within f32 rounding (~1e-6) can therefore keep one token more or less than
+// the torch chain.  Measured (tests/test_gpu_parity.py::test_top_p_boundary_stress, 3072 rows x 8 values of top_p): a fraction of a percent of
+// the rows, every one of them such a tie.  top_p is 1 (off) in TTS.inference's and the CLI's defaults; a caller that needs HF's rounding bit for
+// bit builds the model with hf_exact_top_p=True (tortoise_tts_amd/autoregressive.py): the torch warper then runs in front of this kernel.
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 #include "ttk_host.h"
@@ -66,9 +72,11 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 	return s;
 }
 
-// order-preserving key: a < b  <=>  key(a) < key(b)   (-inf lowest; NaNs sort to the ends and are not expected here)
+// order-preserving key: a < b  <=>  key(a) < key(b)   (-inf lowest; NaNs sort to the ends and are not expected here).  -0.0 takes +0.0's key:
+// the torch chain compares VALUES (`scores < kth`), for which the two zeros are equal; as bit patterns -0.0 would sort below +0.0 and a k-th
+// largest score of +0.0 would drop the -0.0 entries torch keeps.
 __device__ __forceinline__ unsigned fkey(float f) {
-	const unsigned u = __float_as_uint(f);
+	const unsigned u = __float_as_uint(f + 0.0f);      // -0.0 + 0.0 = +0.0 (round to nearest); every other value unchanged
 	return (u >> 31) ? ~u : (u | 0x80000000u);
 }
 

@@ -126,6 +126,9 @@ struct GemvParams {
 	float* qbuf; void* kcache; void* vcache;   // GV_QKV: q f32 [M][d] pre-scaled, caches T [M][H][max_ctx][64]
 	const int* d_pos;           // GV_QKV: cache row to append at; GV_HEAD (optional): incremented by the launch
 	float* noise; const void* rng; const int64_t* draws;   // GV_HEAD (optional): Exp(1) noise rows [M][N], device RngArgs, per-row draw counters
+	int* health;                // GV_QKV / GV_FC (optional): device word that collects what the folded LayerNorm cannot represent well -- bit 0: a row
+	                            // with |mean| > 8 std (the T-typed un-normalised operand then spends > 3 of its bits on the common offset that the
+	                            // norm removes), bit 1: non-finite row statistics (an f16 operand above 65504)
 	int M, N, max_ctx, H, row0; // row0: first row of this batch inside the noise tensor's row numbering
 	float q_scale, wscale;
 	int K, w8;                  // host side only (dispatch): K in {1024, 4096}; w8: Wp holds fp8 bytes (GV_PROJ, bf16 arithmetic)

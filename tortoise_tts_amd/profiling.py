@@ -12,7 +12,9 @@ from __future__ import annotations
 from . import _lib
 
 KINDS = ["gemm", "skinny_gemm", "attn_fwd", "attn_decode", "groupnorm_stats", "groupnorm_apply", "layernorm"]
-KERNEL_NAMES = {"gemm": "ttk::k_gemm", "skinny_gemm": "ttk::k_skinny", "attn_fwd": "ttk::k_attn_fwd", "attn_decode": "ttk::k_attn_decode",
+# "skinny_gemm" = the weight-streaming decode GEMVs: at the benchmarked geometry all of them are ttk::k_gemv instantiations (csrc/gemv.hip); the one
+# ttk::k_skinny launch per utterance left in the tally is the prefill's mel head
+KERNEL_NAMES = {"gemm": "ttk::k_gemm", "skinny_gemm": "ttk::k_gemv", "attn_fwd": "ttk::k_attn_fwd", "attn_decode": "ttk::k_attn_decode",
 				"groupnorm_stats": "ttk::k_gn_stats", "groupnorm_apply": "ttk::k_gn_apply", "layernorm": "ttk::k_layernorm"}
 MFMA_BOUND = {"gemm", "attn_fwd"}
 PEAK_TFLOPS = {_lib.TTK_BF16: 2500.0, _lib.TTK_F16: 2500.0, _lib.TTK_F32: 157.3, _lib.TTK_FP8W: 2500.0, _lib.TTK_FP8: 5000.0}   # fp8w: fp8 weight storage, bf16 MFMA; fp8: fp8 MFMA
