@@ -292,17 +292,11 @@ def main():
 	gathered = [torch.empty((CANDIDATES, MEL_TOKENS), dtype=torch.long, device=gdev) for _ in range(world)] if world > 1 and not by_cand else None
 
 	def step(exchange=True, marks=None):
-		if by_cand:     # one long-form utterance: its lines one after the other, each with its candidates sharded over the ranks
+		if by_cand:     # one long-form utterance: its lines sampled one after the other, each with its candidates sharded over the ranks; the lines' winners
+			# are diffused as one ragged batch on their owner (TTSHotPath.inference_sharded_lines: each line's mel equals its own call's)
 			skw = {k: v for k, v in kw.items() if k != "candidates"}
-			total = 0.0
-			for line in lines:
-				lm = None
-				if marks is not None:
-					lm = []
-					marks.append(lm)                       # one list of phase events per line
-				mels, seconds, aux = tts.inference_sharded(line, ar_lat, df_lat, candidates=n_cand * world, phase_marks=lm, **skw)
-				total += seconds
-			return total
+			res = tts.inference_sharded_lines(lines, ar_lat, df_lat, candidates=n_cand * world, phase_marks=marks, **skw)
+			return sum(r[1] for r in res)
 		mels, seconds, aux = tts.inference(text, ar_lat, df_lat, phase_marks=marks, **kw)
 		if voc is not None:
 			voc.inference(mels)

@@ -236,6 +236,13 @@ int ttk_diff_step(ttk_diff* h, float* x, const ttk_step* st, const float* noise,
  * forked from and joined back to `stream` inside the call (results are ordered on `stream`; identical to the one-stream loop bit for bit). */
 int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream);
 
+/* The DDIM loop for several utterances of DIFFERENT length as one batch (no reference counterpart: the reference diffuses a text's lines one at
+ * a time, inference.py:237-422; its network is batch-capable, diffusion.py:1517-1574, and its ramped conditioning-free guidance asserts b = 1
+ * only because it reads t[0], :391-393 -- every element of this batch is at the same step).  Element e occupies a slot of Tp frames (Tp % 64 == 0)
+ * of which tlen[e] (HOST array, 1..Tp) are real: x [b, in, Tp] f32 in place, E [b, C, Tp] f32; padding frames are ignored on input and
+ * undefined on output.  Element e comes out bit for bit as ttk_diff_sample_ddim(b = 1, T = tlen[e]) gives it.  b <= 32.                      */
+int ttk_diff_sample_ddim_lines(ttk_diff* h, float* x, const float* E, int b, int Tp, const int* tlen, const ttk_step* steps, int n_steps, void* stream);
+
 /* Whole ancestral-sampler loop (p_sample_loop_progressive, diffusion.py:556-644 -- what the second caller of the path, train.py:178, runs with
  * 30 steps): the same two-stream loop with p_sample's update (:510-554).  noise [n_steps, b, in, T] f32: the `th.randn_like(x)` draws of the
  * steps in the order the loop makes them (block j belongs to the j-th executed step, steps[n-1-j]); the caller draws them so the generator

@@ -140,6 +140,17 @@ def _body_sharded(rank, world):
 	return out
 
 
+def _body_sharded_lines(rank, world):
+	"""three lines of one text under 2 gloo ranks: winners on rank 0 (line 0: candidate 2), rank 1 (line 1: candidate 5), rank 0 (line 2, no scorer:
+	candidate 0); each owner diffuses ITS lines in one run_diffusion call"""
+	sts = [_FakeStages(True), _FakeStages("late"), _FakeStages(False)]
+	batches = []
+	for st in sts:
+		st.run_diffusion = (lambda prepared, st=st: (batches.append(len(prepared)), [st.diffuse(c, l) for c, l in prepared])[1])
+	res = D.sharded_candidates_lines(sts, 7)
+	return dict(res=[dict(mel=m, ids=i, scores=s, best=b) for m, i, s, b in res], calls=[st.calls for st in sts], batches=batches)
+
+
 def _body_subgroups(rank, world):
 	"""a 4-rank world cut into two 2-rank sub-groups (2 utterances x 2-way candidate shards, as configs[2] x configs[3] would combine on 8 GPUs),
 	and a 2-rank sub-group of a 3-rank world: every collective of the sharded path must stay inside the group it was given"""
@@ -270,3 +281,21 @@ def test_sharded_path_in_a_two_rank_subgroup_of_three_ranks():
 	got = _run_ranks(_body_subgroups, world=3)
 	assert got[0] is None
 	_check_subgroup((got[1], got[2]), 0)
+
+
+def test_sharded_lines_one_diffusion_per_owner_two_ranks():
+	"""dist.sharded_candidates_lines: the per-line exchange of sharded_candidates, then ONE run_diffusion per owner over the lines it owns (rank 0
+	owns lines 0 and 2, rank 1 line 1), every mel broadcast; each line's result equals its own sharded_candidates result"""
+	got = _run_ranks(_body_sharded_lines)
+	Lmax = max(3 + (c * 5) % 4 for c in range(7))
+	want_ids = torch.stack([_FakeStages.row(c, Lmax) for c in range(7)])
+	for k, best in enumerate((2, 5, 0)):
+		want_mel = (want_ids[best].float().sum() * 1.5).view(1, 1, 1) + torch.arange(12.0).view(1, 3, 4)
+		for r in (0, 1):
+			res = got[r]["res"][k]
+			assert torch.equal(res["ids"], want_ids) and res["best"] == best and torch.equal(res["mel"], want_mel)
+	assert got[0]["batches"] == [2] and got[1]["batches"] == [1]
+	# the LAST line an owner holds runs its batch: rank 0's lines 0 and 2 (winners 2 and 0) through line 2's stages, rank 1's line 1 through its own
+	dif = lambda r, k: [c for c in got[r]["calls"][k] if c[0] == "diffuse"]
+	assert dif(0, 2) == [("diffuse", 2), ("diffuse", 0)] and dif(0, 0) == [] and dif(0, 1) == []
+	assert dif(1, 1) == [("diffuse", 5)] and dif(1, 0) == [] and dif(1, 2) == []

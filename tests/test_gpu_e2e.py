@@ -179,6 +179,41 @@ def test_inference_sharded_equals_inference_on_one_rank(small):
 	assert torch.equal(a0["scores"], a1["scores"])
 
 
+def test_sharded_lines_diffused_together_equal_the_per_line_calls(small):
+	"""`TTSHotPath.inference_sharded_lines` (configs[3]: the lines of one text, their winners diffused as ONE ragged DDIM batch) through a 1-rank
+	RCCL group: every line's mel, ids, scores and choice equal its own `inference_sharded` call -- lines of different length, stop token live so
+	the mel lengths differ too"""
+	import torch.distributed as dist
+	from tortoise_tts_amd.clvp import CLVP
+	from tortoise_tts_amd.inference import TTSHotPath
+	tts, _, _ = small
+	ccfg = W.CLVPConfig(dim=128, depth=2, heads=2, num_speech_tokens=8194)
+	full = TTSHotPath(tts.autoregressive, tts.diffusion, clvp=CLVP(W.synth_state_dict(W.clvp_shapes(ccfg), 34), ccfg, dtype="f32", device=DEV))
+	g = torch.Generator().manual_seed(901)
+	lines = [torch.randint(1, 255, (1, n), generator=g) for n in (8, 5, 11)]
+	_, al, dl = _inputs(900, 8)
+	kws = [dict(max_ar_steps=m, max_diffusion_steps=3, candidates=5, top_k=16, suppress_tokens=[W.AR_SMALL.stop_mel_token]) for m in (14,)]
+	import os, socket
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+	os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+	dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+	try:
+		with torch.inference_mode():
+			single = [full.inference_sharded(t, al.to(DEV), dl.to(DEV), return_all=True, **kws[0]) for t in lines]
+			marks = []
+			batch = full.inference_sharded_lines(lines, al.to(DEV), dl.to(DEV), return_all=True, phase_marks=marks, **kws[0])
+		torch.cuda.synchronize()
+	finally:
+		dist.destroy_process_group()
+	assert len(batch) == 3
+	for (m0, s0, a0), (m1, s1, a1) in zip(single, batch):
+		assert s0 == s1 and torch.equal(m0, m1) and torch.equal(a0["codes"], a1["codes"]) and a0["best"] == a1["best"] and torch.equal(a0["scores"], a1["scores"])
+	# phase marks: every line has its sampling and latent-pass marks, the shared diffusion ends the last line's list
+	assert [[n for n, _ in lm] for lm in marks] == [["start", "ar_decode", "latent_pass"]] * 2 + [["start", "ar_decode", "latent_pass", "ddim"]]
+
+
 def test_tokens_to_waveform_with_the_vocoder(small):
 	"""text tokens + latents -> mel (hot path) -> waveform (BigVGAN on libttk), against the same chain through the two oracles"""
 	import bigvgan_oracle as BO

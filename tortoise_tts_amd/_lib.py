@@ -107,6 +107,7 @@ SYMBOLS = {
 	"ttk_diff_step": (_I, [_P, _P, C.POINTER(StepC), _P, _P]),
 	"ttk_diff_sample_ddim": (_I, [_P, _P, _P, _I, _I, C.POINTER(StepC), _I, _P]),
 	"ttk_diff_sample_p": (_I, [_P, _P, _P, _I, _I, C.POINTER(StepC), _I, _P, _P]),
+	"ttk_diff_sample_ddim_lines": (_I, [_P, _P, _P, _I, _I, C.POINTER(C.c_int), C.POINTER(StepC), _I, _P]),
 }
 
 _lib = None

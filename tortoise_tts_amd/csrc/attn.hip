@@ -94,6 +94,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	constexpr int QW = 16 * QT, QB = NWV * QW;        // queries per wave / per workgroup
 	const int q0 = blockIdx.x * QB + wave * QW;       // first query row of this wave
 	const int li = lane & 15, g = lane >> 4;
+	// ragged batch: sequence b holds TL valid rows in its slot of p.T rows.  Every bound below is the sequence's own (TL); p.T is only the stride.
+	const int TL = p.tlen ? p.tlen[b] : p.T;
+	if ((int)blockIdx.x * QB >= TL) return;           // a query block of padding rows (uniform for the workgroup: before any barrier)
 	const T* base = (const T*)p.qkv + (int64_t)b * p.T * p.ld;
 	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
 
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	// array of vectors ends up in scratch memory).
 	auto load_q = [&](int qt, int ks) -> FragT {
 		int row = q0 + 16 * qt + li;
-		row = row < p.T ? row : p.T - 1;
+		row = row < TL ? row : TL - 1;
 		const FragT f = *(const FragT*)(base + (int64_t)row * p.ld + qc + 32 * ks + 8 * g);
 		FragT o;
 #pragma unroll
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 		for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 	}
 
-	int nkt = (p.T + 63) / 64;
-	if (CAUSAL) { const int last_q = min((int)blockIdx.x * QB + QB - 1, p.T - 1); nkt = min(nkt, last_q / 64 + 1); }
+	int nkt = (TL + 63) / 64;
+	if (CAUSAL) { const int last_q = min((int)blockIdx.x * QB + QB - 1, TL - 1); nkt = min(nkt, last_q / 64 + 1); }
 
 	// staging registers as named scalars (indexed arrays captured by the lambdas were placed in scratch memory)
 	uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	auto ld1 = [&](int kt, int i, uint4& k, uint4& v) {
 		const int id = tid + NTH * i, row = id / NCH, c = id % NCH;
 		int key = kt * 64 + row;
-		key = key < p.T ? key : p.T - 1;
+		key = key < TL ? key : TL - 1;
 		const T* src = base + (int64_t)key * p.ld + c * (16 / ES);
 		k = *(const uint4*)(src + kc);
 		v = *(const uint4*)(src + vc);
@@ -191,13 +194,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 			// ---- bias, masks, online softmax in the log2 domain (lane owns query column li of each q tile; keys 16nt + 4g + r).
 			// Wave-uniform fast path: a tile with no sequence edge, no causal diagonal and every |key - q| >= 64 (the T5 bucket is
 			// saturated there) needs one fma per score; only the ~3 tiles around the diagonal take the per-element path.
-			const bool edge = k0 + 64 > p.T;
+			const bool edge = k0 + 64 > TL;
 			const bool diag = CAUSAL && (k0 + 63 > q0);
-			const bool near_band = BIAS && (k0 - (q0 + QW - 1) < 64) && (q0 - (k0 + 63) < 64);
-			const float cbias = BIAS ? (k0 > q0 ? bias_s[128] : bias_s[0]) : 0.f;
 #pragma unroll
 			for (int qt = 0; qt < QT; ++qt) {
 				const int qi = q0 + 16 * qt + li;
+				// the band test and the saturated bias per 16-QUERY TILE, not per wave: a tile then takes the same path (and rounds the same way)
+				// whether its wave owns one tile or two -- a sequence gives the same bits in a batch that is large enough for 128-query blocks
+				const int qa = q0 + 16 * qt;
+				const bool near_band = BIAS && (k0 - (qa + 15) < 64) && (qa - (k0 + 63) < 64);
+				const float cbias = BIAS ? (k0 > qa ? bias_s[128] : bias_s[0]) : 0.f;
 				const bool slow = edge || diag || near_band;
 				float tmax = NEG_BIG;
 				if (slow) {   // per-element bias lookup and masks; scores become log2-domain values in place
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 							float bv = 0.f;
 							if (BIAS) { int rel = key - qi; rel = rel < -64 ? -64 : (rel > 64 ? 64 : rel); bv = bias_s[rel + 64]; }
 							float v = fmaf(s[qt][nt][r], LOG2E, bv);
-							if (key >= p.T || (CAUSAL && key > qi)) v = NEG_BIG;
+							if (key >= TL || (CAUSAL && key > qi)) v = NEG_BIG;
 							s[qt][nt][r] = v;
 							tmax = fmaxf(tmax, v);
 						}
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 		l += __shfl_xor(l, 32);
 		const float inv = 1.0f / l;
 		const int qi = q0 + 16 * qt + li;
-		if (qi < p.T) {
+		if (qi < TL) {
 			if (p.out_f8) {      // operand of an fp8 projection GEMM: four consecutive head dims = one 32-bit store
 				unsigned char* dst = (unsigned char*)p.out + ((int64_t)b * p.T + qi) * p.ldo + h * HD;
 #pragma unroll

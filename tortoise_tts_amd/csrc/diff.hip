@@ -48,6 +48,11 @@ struct ttk_diff {
 	int pipe = 1;           // ttk_diff_sample_ddim overlaps step i+1's integrator with step i's body (TTK_DIFF_PIPE=0: sequential)
 	int cur_b = 0, cur_T = 0, staged = 0;
 	int fuse_stats = 1;
+	// ragged batch (ttk_diff_sample_ddim_lines): per-sequence valid rows inside the common slot of cur_T rows, [cond b | uncond b]; d_need marks
+	// the sequences whose GroupNorm statistics cannot come from a GEMM epilogue (length not a multiple of its 64-row blocks): they get the
+	// separate statistics launch, exactly as a batch of their own length would
+	int* d_tlen = nullptr; int* d_need = nullptr;
+	const int* tlen = nullptr; const int* need = nullptr;      // = d_tlen / d_need while a ragged loop runs, else null
 };
 
 // gn_T > 0: the output is a GroupNorm input of gn_T rows per batch element; its statistics are produced in the epilogue when the
@@ -88,10 +93,12 @@ static void gn(ttk_diff* h, const float* x, int nb, int T, const float* gamma, c
 			   const float* ms_pre = nullptr) {
 	const int C = h->cfg.model_channels;
 	if (!ms_pre) {
-		if (h->L->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->L->ms.p, s);   // else: left by the producing GEMM
+		if (h->L->ms_owner != (const void*)x) launch_gn_stats(x, nb, T, C, (float*)h->L->ms.p, s, h->tlen);   // else: left by the producing GEMM
+		else if (h->need) launch_gn_stats(x, nb, T, C, (float*)h->L->ms.p, s, h->tlen, h->need);           // ... except for the ragged sequences of a batch
 		h->L->ms_owner = nullptr;
 	}
 	GnApplyParams p = {};
+	if (h->tlen && Tout == T && !row_idx) { p.tlen = h->tlen; p.chunk_rows = gn_rows_per_chunk(C); }
 	p.x = x; p.ms = ms_pre ? ms_pre : (const float*)h->L->ms.p; p.gamma = gamma; p.beta = beta; p.scale = scale; p.shift = shift; p.ss_stride = ss_stride;
 	p.row_idx = row_idx; p.nb = nb; p.T = T; p.Tout = Tout; p.C = C; p.nchunks = gn_num_chunks(T, C); p.act = act; p.out = out; p.out_f32 = out_f32;
 	if (next && h->prefetch) { p.pf = next->w; p.pf_bytes = (int64_t)next->Npad * next->Kpad * next->wes; p.pf_taps = next->ntap; }
@@ -106,7 +113,7 @@ static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, h
 	gemm1(h, h->L->a.p, C, A.qkv, rows, h->L->qkv.p, 3 * C, 0, ACT_NONE, nullptr, s);
 	AttnParams a = {};
 	a.qkv = h->L->qkv.p; a.ld = 3 * C; a.q_off = 0; a.k_off = 64; a.v_off = 128; a.head_stride = 192;   // head-major [H][3][64], arch_utils.py:79
-	a.out = h->L->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f;
+	a.out = h->L->ao.p; a.ldo = C; a.nb = nb; a.T = T; a.H = h->cfg.num_heads; a.causal = 0; a.bias = A.relbias; a.scale = 0.125f; a.tlen = h->tlen;
 	if (h->prefetch) { a.pf = A.proj.w; a.pf_bytes = (int64_t)A.proj.Npad * A.proj.Kpad * A.proj.wes; a.pf_taps = 1; }
 	a.out_f8 = A.proj.wes == 1;
 	launch_attn_fwd(h->dt, a, s);
@@ -274,6 +281,8 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 	}
 	for (int i = 0; i < 3; ++i) D_TRY(load_res(h, wm, "layers." + std::to_string(cfg->num_layers + i) + ".", &h->tail[i], slot++));
 	h->n_emb = slot;
+	D_TRY(h->arena.alloc((void**)&h->d_tlen, 128 * sizeof(int)));
+	D_TRY(h->arena.alloc((void**)&h->d_need, 128 * sizeof(int)));
 	// all emb_layers.1 linears stacked into one [n_emb * 2C][C] matrix ("__emb_cat.*", built by the Python packer)
 	D_TRY(upload_mat(h->arena, wm, h->dt, "__emb_cat.weight", "__emb_cat.bias", PK_NK, h->n_emb * 2 * C, C, false, &h->emb_cat));
 #undef D_TRY
@@ -343,7 +352,7 @@ int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream) {
 	launch_bcast_rows(DT_F32, h->uncond, b * T, C, ecl + (size_t)b * T * C, s);
 	// the staged embedding is the same in every step: its GroupNorm statistics once, here
 	TTK_TRY(h->ms_ecl.reserve((size_t)2 * b * 32 * gn_num_chunks(T, C) * 3 * 4));
-	launch_gn_stats(ecl, 2 * b, T, C, (float*)h->ms_ecl.p, s);
+	launch_gn_stats(ecl, 2 * b, T, C, (float*)h->ms_ecl.p, s, h->tlen);
 	h->cur_b = b; h->cur_T = T; h->staged = 1;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
@@ -354,7 +363,7 @@ static int step_body(ttk_diff* h, float* x, const ttk_step* st, const float* noi
 	const int b = h->cur_b, T = h->cur_T;
 	const bool cf = st->cfk >= 0.f;
 	const int nb = cf ? 2 * b : b;
-	launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, cf ? 2 : 1, s);
+	launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, cf ? 2 : 1, s, h->tlen);
 	float* out = (float*)h->outb.p;
 	body(h, nb, T, emb_row, 0, cs, out, s, cs_consumed);
 	StepCoefs k = {};
@@ -444,6 +453,39 @@ static int sample_loop(ttk_diff* h, float* x, const float* E, int b, int T, cons
 
 int ttk_diff_sample_ddim(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, void* stream) {
 	return sample_loop(h, x, E, b, T, steps, n_steps, nullptr, 0, stream, "ttk_diff_sample_ddim");
+}
+
+// Several utterances of DIFFERENT length as one batch (no reference counterpart: the reference diffuses one line at a time, inference.py:237-422;
+// its network is batch-capable, diffusion.py:1517-1574, and its ramped conditioning-free guidance asserts b = 1 only because it indexes t[0], :391-393).
+// Element e occupies a slot of Tp frames of which tlen[e] are real: x [b, in, Tp], E [b, C, Tp], padding frames ignored on input and left
+// undefined on output.  Every kernel that looks across frames takes the element's own length -- attention masks keys beyond it and skips
+// query blocks beyond it, GroupNorm statistics cover exactly its frames, chunked from its first frame, the k = 3 convolutions read zeros beyond
+// its last frame -- and everything else is row-wise, so element e comes out BIT FOR BIT as ttk_diff_sample_ddim(b = 1, T = tlen[e]) gives it,
+// while every GEMM of a step runs over the rows of all elements (2 b Tp instead of 2 T: more than one tile per CU).
+int ttk_diff_sample_ddim_lines(ttk_diff* h, float* x, const float* E, int b, int Tp, const int* tlen, const ttk_step* steps, int n_steps, void* stream) {
+	TTK_REQUIRE(h && x && E && tlen && steps, TTK_E_ARG, "ttk_diff_sample_ddim_lines: null argument");
+	TTK_REQUIRE(b >= 1 && 2 * b <= 64, TTK_E_ARG, "ttk_diff_sample_ddim_lines: %d elements (1..32)", b);
+	TTK_REQUIRE(Tp >= 64 && Tp % 64 == 0, TTK_E_ARG, "ttk_diff_sample_ddim_lines: the slot length %d must be a multiple of 64 frames", Tp);
+	const int C = h->cfg.model_channels;
+	for (int i = 0; i < n_steps; ++i) TTK_REQUIRE(steps[i].cfk >= 0.f, TTK_E_ARG, "ttk_diff_sample_ddim_lines: step %d has no conditioning-free evaluation (the batch is laid out as [cond | uncond])", i);
+	int host_len[128], host_need[128], any_need = 0;
+	for (int e = 0; e < b; ++e) {
+		TTK_REQUIRE(tlen[e] >= 1 && tlen[e] <= Tp, TTK_E_ARG, "ttk_diff_sample_ddim_lines: element %d has %d frames, slot %d", e, tlen[e], Tp);
+		// a batch of its own length would take its statistics from the GEMM epilogues iff gemm_fuses_gn_stats says so for that length
+		const int nd = !(h->fuse_stats && gemm_fuses_gn_stats(2 * tlen[e], C, C, tlen[e]));
+		host_len[e] = host_len[b + e] = tlen[e];
+		host_need[e] = host_need[b + e] = nd;
+		any_need |= nd;
+	}
+	hipStream_t s = (hipStream_t)stream;
+	TTK_HIP(hipMemcpyAsync(h->d_tlen, host_len, (size_t)2 * b * sizeof(int), hipMemcpyHostToDevice, s));
+	TTK_HIP(hipMemcpyAsync(h->d_need, host_need, (size_t)2 * b * sizeof(int), hipMemcpyHostToDevice, s));
+	TTK_HIP(hipStreamSynchronize(s));      // the staging arrays live on this stack frame
+	h->tlen = h->d_tlen;
+	h->need = any_need ? h->d_need : nullptr;
+	const int rc = sample_loop(h, x, E, b, Tp, steps, n_steps, nullptr, 0, stream, "ttk_diff_sample_ddim_lines");
+	h->tlen = nullptr; h->need = nullptr;
+	return rc;
 }
 
 int ttk_diff_sample_p(ttk_diff* h, float* x, const float* E, int b, int T, const ttk_step* steps, int n_steps, const float* noise, void* stream) {

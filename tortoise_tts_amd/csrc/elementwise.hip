@@ -84,13 +84,14 @@ void launch_cast(int dt, const float* src, void* dst, int64_t n, hipStream_t s) 
 
 // channel-first f32 [nb][C][T] -> channels-last T-typed [rep*nb*T][ldo], zero padded columns C..ldo (LDS tile transpose)
 template <typename T>
-__global__ void k_cf_to_cl(const float* src, int nb, int C, int Tn, T* dst, int64_t ldo, int rep) {
+__global__ void k_cf_to_cl(const float* src, int nb, int C, int Tn, T* dst, int64_t ldo, int rep, const int* tlen) {
 	__shared__ float tile[32][33];
 	const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+	const int tl = tlen ? tlen[b] : Tn;      // ragged batch: frames [tl, Tn) of element b are padding and become ZERO rows (the k = 3 convs' edge)
 	for (int i = ty; i < 32; i += 8) {
 		const int c = c0 + i, t = t0 + tx;
-		tile[i][tx] = (c < C && t < Tn) ? src[((int64_t)b * C + c) * Tn + t] : 0.f;
+		tile[i][tx] = (c < C && t < tl) ? src[((int64_t)b * C + c) * Tn + t] : 0.f;
 	}
 	__syncthreads();
 	for (int i = ty; i < 32; i += 8) {
@@ -99,11 +100,11 @@ __global__ void k_cf_to_cl(const float* src, int nb, int C, int Tn, T* dst, int6
 			for (int r = 0; r < rep; ++r) dst[(((int64_t)r * nb + b) * Tn + t) * ldo + c] = cvt<T>(tile[tx][i]);
 	}
 }
-void launch_cf_to_cl(int dt, const float* src, int nb, int C, int T, void* dst, int64_t ldo, int rep, hipStream_t s) {
+void launch_cf_to_cl(int dt, const float* src, int nb, int C, int T, void* dst, int64_t ldo, int rep, hipStream_t s, const int* tlen) {
 	dim3 grid((T + 31) / 32, (unsigned)((ldo + 31) / 32), nb);
-	if (dt == DT_BF16) hipLaunchKernelGGL((k_cf_to_cl<bf16>), grid, dim3(256), 0, s, src, nb, C, T, (bf16*)dst, ldo, rep);
-	else if (dt == DT_F16) hipLaunchKernelGGL((k_cf_to_cl<f16>), grid, dim3(256), 0, s, src, nb, C, T, (f16*)dst, ldo, rep);
-	else hipLaunchKernelGGL((k_cf_to_cl<float>), grid, dim3(256), 0, s, src, nb, C, T, (float*)dst, ldo, rep);
+	if (dt == DT_BF16) hipLaunchKernelGGL((k_cf_to_cl<bf16>), grid, dim3(256), 0, s, src, nb, C, T, (bf16*)dst, ldo, rep, tlen);
+	else if (dt == DT_F16) hipLaunchKernelGGL((k_cf_to_cl<f16>), grid, dim3(256), 0, s, src, nb, C, T, (f16*)dst, ldo, rep, tlen);
+	else hipLaunchKernelGGL((k_cf_to_cl<float>), grid, dim3(256), 0, s, src, nb, C, T, (float*)dst, ldo, rep, tlen);
 }
 
 __global__ void k_cl_to_cf(const float* src, int nb, int C, int Tn, float* dst) {

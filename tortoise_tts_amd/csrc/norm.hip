@@ -84,10 +84,13 @@ void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, cons
 // stats: grid (32 groups, nb, nchunks).  Each workgroup holds its (rows x cpg) chunk (<= 2048 values) in registers, computes the
 // chunk's (count, mean, M2) with an exact two-pass, and writes the triple; the consumer merges the chunk triples with Chan's
 // parallel-variance formula (k_gn_apply), so no second reduction launch and no atomics (bitwise reproducible).
-__global__ __launch_bounds__(256) void k_gn_stats(const float* x, int T, int C, int rows_per_chunk, float* part) {
+__global__ __launch_bounds__(256) void k_gn_stats(const float* x, int T, int C, int rows_per_chunk, float* part, const int* tlen, const int* need) {
 	const int g = blockIdx.x, b = blockIdx.y, ch = blockIdx.z, cpg = C / 32;
+	if (need && !need[b]) return;             // this sequence keeps the triples the producing GEMM's epilogue wrote
+	const int Tl = tlen ? tlen[b] : T;        // ragged batch: the sequence's own length inside its T-row slot
 	const int t0 = ch * rows_per_chunk;
-	const int rows = min(rows_per_chunk, T - t0);
+	if (t0 >= Tl) return;                     // chunk beyond the sequence: k_gn_apply does not read it
+	const int rows = min(rows_per_chunk, Tl - t0);
 	const float* base = x + ((int64_t)b * T + t0) * C + g * cpg;
 	const int n = rows * cpg;
 	__shared__ float sh[4];
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float* x, int T, int C, 
 int gn_rows_per_chunk(int C) { const int r = 2048 / (C / 32); return r < 1 ? 1 : r; }
 int gn_num_chunks(int T, int C) { const int r = gn_rows_per_chunk(C); return (T + r - 1) / r; }
 
-void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStream_t s) {
+void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStream_t s, const int* tlen, const int* need) {
 	ProfScope prof(PROF_GN_STATS, 4.0 * nb * T * C, s);
-	hipLaunchKernelGGL(k_gn_stats, dim3(32, nb, gn_num_chunks(T, C)), dim3(256), 0, s, x, T, C, gn_rows_per_chunk(C), part);
+	hipLaunchKernelGGL(k_gn_stats, dim3(32, nb, gn_num_chunks(T, C)), dim3(256), 0, s, x, T, C, gn_rows_per_chunk(C), part, tlen, need);
 }
 
 // apply: a block owns a strip of output rows of ONE batch element.  It first merges that element's 32 groups' chunk statistics
@@ -138,6 +141,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	const int strip = rpp * GN_PASSES;
 	const int strips = (p.Tout + strip - 1) / strip;
 	const int b = blockIdx.x / strips, t0 = (blockIdx.x - b * strips) * strip;
+	const int Tl = p.tlen ? p.tlen[b] : p.Tout;                                            // ragged batch: valid rows of this sequence
+	const int nch = p.tlen ? (Tl + p.chunk_rows - 1) / p.chunk_rows : p.nchunks;           // ... and the chunk triples that describe them
 	// the rows this thread normalises are requested FIRST: they do not depend on the statistics, and issued ahead of the chunk triples
 	// the two round trips overlap (the loads retire in order, so the triples arrive with or after the rows, never before they were asked)
 	const int c = (threadIdx.x % c4n) * 4, rr = threadIdx.x / c4n;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group
 			const int k = sub + 8 * i;
-			const bool ok = k < p.nchunks;
+			const bool ok = k < nch;
 			const int kk = ok ? k : 0;
 			const float a0 = part[3 * kk], a1 = part[3 * kk + 1], a2 = part[3 * kk + 2];
 			cn[i] = ok ? a0 : 0.f; cm[i] = ok ? a1 : 0.f; c2[i] = ok ? a2 : 0.f;
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 		if (to >= p.Tout) continue;
 		float o0 = xv[i].x * a0 + d0, o1 = xv[i].y * a1 + d1, o2 = xv[i].z * a2 + d2, o3 = xv[i].w * a3 + d3;
 		if (p.act == ACT_SILU) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+		if (to >= Tl) { o0 = 0.f; o1 = 0.f; o2 = 0.f; o3 = 0.f; }      // padding rows of a ragged batch: zeros, what a k = 3 conv reads beyond a sequence's end
 		OT* dst = (OT*)p.out + ((int64_t)b * p.Tout + to) * p.C + c;
 		if (sizeof(OT) == 1) {
 			*(unsigned*)dst = pack4_fp8(o0, o1, o2, o3);

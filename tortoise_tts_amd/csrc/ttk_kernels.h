@@ -145,13 +145,19 @@ void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, cons
 					  const int64_t* out2_idx = nullptr, int64_t out2_stride = 0);      // out2_idx: out2 += out2_idx[0] * out2_stride on the device
 // GroupNorm32 over channels-last x f32 [nb][T][C], 32 groups: per-chunk statistics part[nb][32][nchunks][3] = (count, mean, M2)
 int gn_num_chunks(int T, int C);
-void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStream_t s);
+int gn_rows_per_chunk(int C);
+// Ragged batches (sequences of different length sharing one row stride T; tlen = device int [nb], null = all T rows valid): the statistics
+// of sequence b cover its first tlen[b] rows, chunked from its first row exactly as a batch of its own would be.  need (optional, device
+// int [nb]): only sequences with need[b] != 0 are computed -- the others keep the triples a GEMM epilogue left for them.
+void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStream_t s, const int* tlen = nullptr, const int* need = nullptr);
 // y[nb][Tout][C] (T-typed or f32) = act( gn(x)*gamma+beta [ *(1+scale[b][c]) + shift[b][c] ] ), optional nearest
 // row gather (row_idx[Tout] into [0,T)) used by timestep_independent's F.interpolate.
 struct GnApplyParams {
 	const float* x; const float* ms; const float* gamma; const float* beta;
 	const float* scale; const float* shift; int64_t ss_stride;   // per-batch stride of scale/shift rows (0 = shared)
 	const int* row_idx; int nb, T, Tout, C; int nchunks; int act; void* out; int out_f32;
+	const int* tlen; int chunk_rows;   // ragged batch (needs Tout == T, no row_idx): sequence b has tlen[b] valid rows -- its statistics are its first
+	                                   // ceil(tlen[b] / chunk_rows) chunk triples, its rows [tlen[b], T) are written as ZEROS (the k = 3 convs' edge padding)
 	int out_f8;        // out is fp8-e4m3 bytes (operand of an fp8 GEMM); overrides out_f32
 	// optional: weights of the GEMM that consumes this output, touched so that they sit in L2 when it starts.  The matrix is `pf_taps`
 	// blocks of `pf_bytes` each; block bytes are split into 8 equal slices, slice x = the n-range the GEMM's tile order gives XCD x, and
@@ -167,6 +173,8 @@ struct AttnParams {
 	void* out; int64_t ldo;               // T [nb*T][ldo], column h*64 + d
 	int out_f8;                           // out is fp8-e4m3 bytes instead of T (operand of an fp8 GEMM; bf16 kernel only)
 	int nb, T, H, causal;
+	const int* tlen;                      // optional, device int [nb]: sequence b has tlen[b] valid rows of the T its slot holds (ragged batch): keys beyond are
+	                                      // masked, query blocks beyond are skipped -- every query sees exactly what a batch of its own length would
 	const float* bias;                    // [H][129] relative-position bias (already scaled) or null
 	float scale;                          // multiplies q.k
 	const void* pf; int64_t pf_bytes; int pf_taps;   // optional L2 touch of the following GEMM's weights (see GnApplyParams)
@@ -209,7 +217,8 @@ void launch_decode_embed(const float* emb, const int64_t* tok, const float* pos,
 void launch_copy_rows(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int d, hipStream_t s);
 void launch_cast(int dt, const float* src, void* dst, int64_t n, hipStream_t s);
 // [nb][C][T] f32  ->  [rep*nb*T][ldo] T, zero padded to ldo columns; the nb*T block is written `rep` times
-void launch_cf_to_cl(int dt, const float* src, int nb, int C, int T, void* dst, int64_t ldo, int rep, hipStream_t s);
+// tlen (optional, device int [nb]): frames [tlen[b], T) of element b are padding and are written as zero rows (ragged batches)
+void launch_cf_to_cl(int dt, const float* src, int nb, int C, int T, void* dst, int64_t ldo, int rep, hipStream_t s, const int* tlen = nullptr);
 // [nb*T][C] f32 -> [nb][C][T] f32
 void launch_cl_to_cf(const float* src, int nb, int C, int T, float* dst, hipStream_t s);
 // rows of a [1][C] f32 vector broadcast to T-typed [rows][C]

@@ -295,6 +295,42 @@ class SpacedDiffusion:
 		return x
 
 
+def _sample_loop_lines(self, model: DiffusionTTS, noises, embeddings):
+	"""DDIM loops of several utterances of different length as ONE batch (include/ttk.h: ttk_diff_sample_ddim_lines; no reference counterpart --
+	the reference diffuses a text's lines one after the other, inference.py:237-422).  noises: list of [1, 100, T_i] start noises, embeddings:
+	list of [1, C, T_i] precomputed aligned embeddings.  Returns a list of [1, 100, T_i] f32, element i bit for bit what
+	`sample_loop(model, (1, 100, T_i), noise=noises[i], ...)` returns.  Draws nothing from the torch generator: the caller makes the reference's
+	per-line draws (start noise, DDIM's ignored per-step randn_like) in line order, as TTSHotPath.inference_lines does."""
+	if not self.conditioning_free:
+		raise NotImplementedError("line batches run the conditioned and the conditioning-free evaluation as one [cond | uncond] batch")
+	if not isinstance(model, DiffusionTTS):
+		raise _lib.TTKError("sample_loop_lines needs the libttk-backed DiffusionTTS (no fallback path)")
+	dev = model.device
+	b = len(noises)
+	if b == 0 or len(embeddings) != b:
+		raise ValueError("one start noise and one embedding per line")
+	Ts = [int(n.shape[-1]) for n in noises]
+	if any(e.shape[-1] != t or n.shape[0] != 1 or e.shape[0] != 1 for n, e, t in zip(noises, embeddings, Ts)):
+		raise ValueError("noises[i] [1, 100, T_i] and embeddings[i] [1, C, T_i] must agree in T_i")
+	Tp = (max(Ts) + 63) // 64 * 64
+	C = embeddings[0].shape[1]
+	with torch.cuda.device(dev):
+		x = torch.zeros((b, noises[0].shape[1], Tp), device=dev, dtype=torch.float32)
+		E = torch.zeros((b, C, Tp), device=dev, dtype=torch.float32)
+		for i, (n, e, t) in enumerate(zip(noises, embeddings, Ts)):
+			x[i, :, :t] = n[0].to(dev, torch.float32)
+			E[i, :, :t] = e[0].to(dev, torch.float32)
+		n_steps = self.num_timesteps
+		steps = (_lib.StepC * n_steps)(*[self.step_coefs(i, "ddim") for i in range(n_steps)])
+		tlen = (_lib.C.c_int * b)(*Ts)
+		_lib.check(model.lib.ttk_diff_sample_ddim_lines(model._h, x.data_ptr(), E.data_ptr(), b, Tp, tlen, steps, n_steps, _lib.stream_ptr()),
+				   "ttk_diff_sample_ddim_lines")
+		return [x[i:i + 1, :, :t].contiguous() for i, t in enumerate(Ts)]
+
+
+SpacedDiffusion.sample_loop_lines = _sample_loop_lines
+
+
 def get_diffuser(steps=80, cond_free=True, cond_free_k=2, trained_diffusion_steps=4000) -> SpacedDiffusion:
 	"""diffusion.py:1576-1590."""
 	return SpacedDiffusion(use_timesteps=space_timesteps(trained_diffusion_steps, [steps]),

@@ -109,6 +109,15 @@ class ShardStages:
 		"""mel [1, 100, T] of ONE candidate (codes [1, L], latents [1, L, d]); only the winner's owner calls this"""
 		raise NotImplementedError
 
+	# several lines of one text (sharded_candidates_lines): the owner's random draws stay where `diffuse` would make them, the loops run together
+	def prepare_diffusion(self, codes: torch.Tensor, latents: torch.Tensor):
+		"""everything of `diffuse` that draws from the generator (start noise ...), made right after this line's sampling; returns an opaque item"""
+		return (codes, latents)
+
+	def run_diffusion(self, prepared) -> List[torch.Tensor]:
+		"""mels of the prepared items, as one batch where the implementation can; default: one `diffuse` per item"""
+		return [self.diffuse(c, l) for c, l in prepared]
+
 
 def sharded_candidates(stages: ShardStages, n_candidates: int, group=None):
 	"""One utterance, candidates sharded over the ranks of `group` (weights replicated, no data-path collective):
@@ -143,3 +152,45 @@ def sharded_candidates(stages: ShardStages, n_candidates: int, group=None):
 		mel = torch.empty([int(v) for v in shape], dtype=torch.float32, device=dev)
 	dist.broadcast(mel, src=src, group=group)
 	return mel, ids, scores, best
+
+
+def sharded_candidates_lines(stages_list, n_candidates: int, group=None):
+	"""`sharded_candidates` for the lines of one text: per line the same exchange (shard sampling, id all-gather, RNG alignment, latent pass and
+	scores on every shard, first maximum wins), with the winner's owner making that line's random draws at once (`prepare_diffusion`: the next
+	line's `generate` reseeds) -- and then ONE diffusion per owner over all the lines it owns (`run_diffusion`: a ragged batch on libttk), the
+	mels broadcast line by line.  Returns [(mel, ids, scores, best)] per line, each equal to that line's own `sharded_candidates` result."""
+	world = dist.get_world_size(group)
+	rank = dist.get_rank(group)
+	picked = []
+	for st in stages_list:
+		lo, hi = candidate_shard(n_candidates, rank, world)
+		if hi <= lo:
+			raise ValueError(f"{n_candidates} candidates over {world} ranks leaves rank {rank} without work")
+		local = st.sample(lo, hi, n_candidates)
+		ids = gather_candidate_ids(local, n_candidates, st.pad_token, group)
+		st.align_rng(ids.shape[1])
+		codes, lat = st.latents(ids[lo:hi].contiguous())
+		sc = st.score(codes)
+		if sc is None:
+			owner, idx, scores, best = 0, 0, None, 0
+		else:
+			owner, idx, scores = pick_best_candidate(sc, n_candidates, group)
+			best = candidate_shard(n_candidates, owner, world)[0] + idx
+		prep = st.prepare_diffusion(codes[idx:idx + 1], lat[idx:idx + 1]) if rank == owner else None
+		picked.append(dict(owner=owner, ids=ids, scores=scores, best=best, prep=prep))
+	mine = [k for k, p in enumerate(picked) if p["owner"] == rank]
+	mels = {}
+	if mine:
+		# (the LAST owned line's stages run the batch: their phase marks then end with the shared diffusion, right behind that line's own stages)
+		for k, m in zip(mine, stages_list[mine[-1]].run_diffusion([picked[k]["prep"] for k in mine])):
+			mels[k] = m.to(torch.float32).contiguous()
+	out = []
+	for k, p in enumerate(picked):
+		dev = p["ids"].device
+		shape = torch.tensor(mels[k].shape, dtype=torch.long, device=dev) if k in mels else torch.zeros(3, dtype=torch.long, device=dev)
+		src = dist.get_global_rank(group, p["owner"]) if group is not None else p["owner"]
+		dist.broadcast(shape, src=src, group=group)
+		mel = mels[k] if k in mels else torch.empty([int(v) for v in shape], dtype=torch.float32, device=dev)
+		dist.broadcast(mel, src=src, group=group)
+		out.append((mel, p["ids"], p["scores"], p["best"]))
+	return out

@@ -54,7 +54,6 @@ class HotPathStages:
 				 diffusion_sampler="ddim", cond_free=True, suppress_tokens=None, phase_marks=None):
 		self.tts, self.ar, self.diff = tts, tts.autoregressive, tts.diffusion
 		self.phase_marks = phase_marks      # measurement only: receives (name, event) at the phase boundaries, as TTSHotPath.inference does
-		self._mark("start")
 		self.text = text_tokens.to(self.ar.device)
 		self.al, self.dl = autoregressive_latents, diffusion_latents
 		self.kw = dict(do_sample=True, top_k=top_k, top_p=top_p, temperature=ar_temp, num_beams=1, length_penalty=length_penalty,
@@ -72,6 +71,7 @@ class HotPathStages:
 			self.phase_marks.append((name, ev))
 
 	def sample(self, lo, hi, n_candidates):
+		self._mark("start")
 		ids = self.ar.inference_speech(self.al, self.text, num_return_sequences=n_candidates, candidate_shard=(lo, hi), **self.kw)
 		self._mark("ar_decode")
 		return ids
@@ -92,15 +92,31 @@ class HotPathStages:
 	def score(self, codes):
 		return None if self.tts.clvp is None else self.tts.clvp(self.text, codes, return_loss=False)
 
-	def diffuse(self, codes, latents):
+	def prepare_diffusion(self, codes, latents):
+		"""the part of `diffuse` that touches the torch generator, in the reference's order (inference.py:381-404, diffusion.py:685): calm-token
+		trim, frame count, the start noise and DDIM's ignored per-step draws.  Returns what `run_diffusion` needs."""
 		latents = trim_calm_tokens(codes, latents)
 		T = latents.shape[1] * 4 * 24000 // 22050
-		E = self.diff.timestep_independent(latents, self.dl, T, False)
 		noise = torch.randn((1, 100, T), device=self.ar.device) * self.diffusion_temp
-		mel = self.diffuser.sample_loop(self.diff, (1, 100, T), sampler=self.sampler, noise=noise,
-										model_kwargs={"precomputed_aligned_embeddings": E}, progress=False)
+		if self.sampler == "ddim":
+			for _ in range(self.diffuser.num_timesteps):
+				torch.randn_like(noise)
+		return latents, noise, T
+
+	def run_diffusion(self, prepared):
+		"""mels [1, 100, T_i] of the prepared lines: one ragged DDIM batch (SpacedDiffusion.sample_loop_lines) when there are several and the
+		sampler is ddim with conditioning-free guidance, else one loop per line; each mel bit for bit its own loop's either way"""
+		Es = [self.diff.timestep_independent(latents, self.dl, T, False) for latents, _, T in prepared]
+		if len(prepared) > 1 and self.sampler == "ddim" and self.diffuser.conditioning_free:
+			mels = self.diffuser.sample_loop_lines(self.diff, [n for _, n, _ in prepared], Es)
+		else:
+			mels = [self.diffuser.sample_loop(self.diff, (1, 100, T), sampler=self.sampler, noise=n, model_kwargs={"precomputed_aligned_embeddings": E},
+											  progress=False, consume_rng=self.sampler != "ddim") for (_, n, T), E in zip(prepared, Es)]
 		self._mark("ddim")
-		return mel
+		return mels
+
+	def diffuse(self, codes, latents):
+		return self.run_diffusion([self.prepare_diffusion(codes, latents)])[0]
 
 
 class TTSHotPath:
@@ -123,6 +139,29 @@ class TTSHotPath:
 		if return_all:
 			return mels, seconds, dict(codes=fix_stop_tokens(ids, self.autoregressive.stop_mel_token), mel=mel, scores=scores, best=best)
 		return mels, seconds
+
+	@torch.inference_mode()
+	def inference_sharded_lines(self, lines, autoregressive_latents, diffusion_latents, *, candidates, group=None, return_all=False, phase_marks=None, **kw):
+		"""`inference_sharded` for the lines of ONE long-form text (BASELINE configs[3]: "2 lines"): every line's candidates are sharded over the
+		ranks as there, line by line (sample, id gather, latent pass, scores, winner), and the winners are then DIFFUSED TOGETHER -- the lines a rank
+		owns as one ragged DDIM batch (dist.sharded_candidates_lines) -- before the mels are broadcast.  Each line's result equals its own
+		`inference_sharded` call.  phase_marks (measurement only): a list that receives one list of (name, event) per line; the shared
+		diffusion's end is the "ddim" mark of every line it served.  Returns a list of (mels, seconds[, aux])."""
+		from . import dist as D
+		stages = []
+		for text in lines:
+			lm = None
+			if phase_marks is not None:
+				lm = []
+				phase_marks.append(lm)
+			stages.append(HotPathStages(self, text, autoregressive_latents, diffusion_latents, phase_marks=lm, **kw))
+		out = []
+		for st, (mel, ids, scores, best) in zip(stages, D.sharded_candidates_lines(stages, candidates, group)):
+			T = mel.shape[-1]
+			mels = denormalize_tacotron_mel(mel)[:, :, :T]
+			seconds = T * HOP / SAMPLE_RATE
+			out.append((mels, seconds, dict(codes=fix_stop_tokens(ids, self.autoregressive.stop_mel_token), mel=mel, scores=scores, best=best)) if return_all else (mels, seconds))
+		return out
 
 	@torch.inference_mode()
 	def inference_to_wav(self, text_tokens, autoregressive_latents, diffusion_latents, **kw):
@@ -203,12 +242,13 @@ class TTSHotPath:
 	@torch.inference_mode()
 	def inference_lines(self, lines, autoregressive_latents, diffusion_latents, *, max_ar_steps=500, max_diffusion_steps=80, ar_temp=0.8,
 						diffusion_temp=1.0, top_p=1.0, top_k=0, repetition_penalty=1.0, length_penalty=1.0, cond_free=True,
-						candidates=1, suppress_tokens=None, ar_batch_lines=None):
+						candidates=1, suppress_tokens=None, ar_batch_lines=None, ddim_batch_lines=None):
 		"""The reference's `for line in lines` loop (inference.py:237-422) software-pipelined and batched:
 		(1) the autoregressive sampling of up to `ar_batch_lines` consecutive lines runs as ONE decode batch (UnifiedVoice.inference_speech_lines:
 		the GPT-2 weights are streamed once per token for all of them; default: as many as fit max_batch, at most 4; 1 = one line per batch);
-		(2) the diffusion of line i runs while the sampling of later lines does: the diffusion of line i runs while the
-		autoregressive sampling of line i+1 does.  The two phases of different lines are independent and both are latency-bound chains of
+		(2) the lines sampled together are also DIFFUSED together, as one ragged batch (`ddim_batch_lines`, default: the sampled batch; 1 = line by
+		line): each line's mel stays bit for bit its own loop's (SpacedDiffusion.sample_loop_lines) while every GEMM of a step runs over the rows of
+		all of them; (3) the diffusion of a batch runs while the sampling of later lines does.  The two phases of different lines are independent and both are latency-bound chains of
 		small kernels, so they interleave on the CUs -- provided BOTH keep being fed: the sampling loop needs the host once per token
 		(graph replay), and enqueuing a diffusion is ~10k launches from one C call, so the diffusion is issued from a worker thread on its
 		own HIP stream (ctypes releases the GIL for the call).  Measured at the benchmark's shape: 422.7 ms per line sequentially, 3 % less
@@ -231,22 +271,32 @@ class TTSHotPath:
 		s_ar.wait_stream(main)
 		s_df.wait_stream(main)
 
-		def diffuse(latents, noise, T, ready):
+		def diffuse(group, ready):
+			"""the DDIM loops of one sampled batch of lines as ONE ragged batch (SpacedDiffusion.sample_loop_lines: every GEMM of a step runs over
+			the rows of all lines, each line's mel bit for bit what its own loop gives); a single line takes the single-line entry"""
 			with torch.inference_mode(), torch.cuda.device(dev), torch.cuda.stream(s_df):
 				s_df.wait_event(ready)
-				E = diff.timestep_independent(latents, diffusion_latents, T, False)
-				mel = diffuser.sample_loop(diff, (1, 100, T), sampler="ddim", noise=noise,
-										   model_kwargs={"precomputed_aligned_embeddings": E}, progress=False, consume_rng=False)
-				mels = denormalize_tacotron_mel(mel)[:, :, :T]
-				for t_ in (latents, noise, E):
-					t_.record_stream(s_df)
+				Es = [diff.timestep_independent(latents, diffusion_latents, T, False) for latents, _, T in group]
+				if len(group) == 1:
+					mel = [diffuser.sample_loop(diff, (1, 100, group[0][2]), sampler="ddim", noise=group[0][1],
+												model_kwargs={"precomputed_aligned_embeddings": Es[0]}, progress=False, consume_rng=False)]
+				else:
+					mel = diffuser.sample_loop_lines(diff, [noise for _, noise, _ in group], Es)
+				mels = [denormalize_tacotron_mel(m)[:, :, :T] for m, (_, _, T) in zip(mel, group)]
+				for (latents, noise, _), E in zip(group, Es):
+					for t_ in (latents, noise, E):
+						t_.record_stream(s_df)
 				return mels
 
 		out, pending = [], []
 		lines = [t.to(dev) for t in lines]
 		G = ar_batch_lines or max(1, min(4, ar.max_batch // max(candidates, 1)))
 		G = max(1, min(G, ar.max_batch // max(candidates, 1)))
+		DG = G if ddim_batch_lines is None else max(1, int(ddim_batch_lines))      # lines diffused as one batch (1 = line by line)
+		if not cond_free:
+			DG = 1                                                                     # the ragged batch is laid out as [cond | uncond]
 		with ThreadPoolExecutor(max_workers=1) as pool:          # one worker: diffusions stay in line order on s_df
+			group, meta = [], []
 			for i, text_tokens in enumerate(lines):
 				with torch.cuda.stream(s_ar):
 					if i % G == 0:      # sample this line and the next G - 1 as one batch
@@ -268,11 +318,17 @@ class TTSHotPath:
 					noise = torch.randn((1, 100, T), device=dev) * diffusion_temp
 					for _ in range(max_diffusion_steps):                    # DDIM's ignored per-step draws, in reference order
 						torch.randn_like(noise)
-					ready = torch.cuda.Event()
-					ready.record(s_ar)
-				pending.append((pool.submit(diffuse, latents, noise, T, ready), T, codes))
-			for fut, T, codes in pending:
-				out.append((fut.result(), T * HOP / SAMPLE_RATE, codes))
+					group.append((latents, noise, T))
+					meta.append((T, codes))
+					last_of_batch = (i % G == G - 1) or i == len(lines) - 1
+					if len(group) >= DG or last_of_batch:
+						ready = torch.cuda.Event()
+						ready.record(s_ar)
+						pending.append((pool.submit(diffuse, group, ready), meta))
+						group, meta = [], []
+			for fut, meta in pending:
+				for mels, (T, codes) in zip(fut.result(), meta):
+					out.append((mels, T * HOP / SAMPLE_RATE, codes))
 		main.wait_stream(s_ar)
 		main.wait_stream(s_df)
 		return out
