@@ -383,6 +383,14 @@ def main():
 					"text_tokens": TEXT_TOKENS, "candidates": CANDIDATES, "mel_tokens": MEL_TOKENS, "ddim_steps": DDIM_STEPS,
 					"mel_frames": MEL_TOKENS * 4 * 24000 // 22050, "parallelism": f"utterances x{world}" if world > 1 else "single GPU",
 					"small_models": bool(a.small), "vocoder_in_step": bool(a.with_vocoder)}
+		if a.dtype in ("fp8", "fp8w"):      # BASELINE config 5: say exactly which contractions are fp8
+			cfg_line["workload"] += ("; config 5 arithmetic: " + (
+				"diffusion ResBlock / AttentionBlock projection GEMMs on v_mfma_f32_16x16x32_fp8_fp8 (e4m3 weights x power-of-two tensor scale, e4m3 activations); "
+				"QK^T / PV, the k=3 input/output convs and the time-embedding linears on the bf16 MFMA; autoregressive side: fp8 WEIGHT bytes widened next to the bf16 MFMA "
+				"(16-row GEMVs), bf16 KV cache" if a.dtype == "fp8" else
+				"fp8-e4m3 block-GEMM WEIGHTS in both networks (power-of-two tensor scale), every contraction on the bf16 MFMA"))
+			cfg_line["fp8_contractions"] = "diffusion block projection GEMMs" if a.dtype == "fp8" else "none (weights only)"
+			cfg_line["ar_handle_dtype"] = "fp8w"
 		if by_cand:
 			cfg_line = {"workload": f"configs[3]: one long-form utterance = 2 lines x 256 text tokens, {n_cand * world} AR candidates ({n_cand} per GPU) x 500 mel "
 									"tokens, latent pass + candidate choice on every shard, 200 DDIM steps with cond-free guidance at T=2176 (23.2 s audio per line) "

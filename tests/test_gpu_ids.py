@@ -25,17 +25,47 @@ BF16_DRAW_AGREEMENT_FLOOR = 0.97       # measured 0.99
 F32_LOGITS_ABS = 1e-3                  # the f32 bar of tests/test_gpu_bench_shapes.py
 
 
+def replay_draws(logits, ids):
+	"""the oracle's sampling step repeated on `logits` [B, MEL, V] with the oracle's noise (`generate` reseeds to 0; torch.multinomial(p, 1) is
+	argmax(p / q), q = exponential_(1) per step on the [B, V] probabilities): the token every step draws, [B, MEL] on the device"""
+	torch.manual_seed(0); torch.cuda.manual_seed_all(0)
+	mask = torch.zeros(W.AR_FULL.number_mel_codes, dtype=torch.bool, device=DEV)
+	mask[STOP] = True
+	q = torch.empty((B, W.AR_FULL.number_mel_codes), device=DEV)
+	out = torch.empty((B, MEL), dtype=torch.long, device=DEV)
+	for k in range(MEL):
+		q.exponential_(1)
+		p = torch.softmax(logits[:, k].to(DEV).masked_fill(mask, float("-inf")) / TEMP, dim=-1)
+		out[:, k] = torch.argmax(p / q, dim=-1)
+	return out
+
+
 @pytest.fixture(scope="module")
 def case():
+	"""(sd, text, cond, ids, logits): the ORACLE's ids for configs[1] and its logits along them.
+
+	Default (about 40 s): by induction instead of the oracle's O(n^2) KV-cached loop (torch.cat per step, as the reference's DynamicCache: 200 s
+	here).  The f32 product samples a sequence; ONE dense causal pass of the oracle over [prefix | that sequence] (`teacher_forced_logits`, pinned
+	equal to the cached steps by tests/test_oracle_golden.py) gives the oracle's logits at every step GIVEN that history; if the oracle's draw on
+	its own logits (its processors, its noise) equals the fed token at EVERY step, then the oracle's own loop -- which sees the same history at step
+	k provided steps < k agreed -- produces exactly this sequence.  The f32 test asserts that; a failing step is reported as the first divergence.
+	TTK_TEST_FULL_ORACLE_LOOP=1 runs `O.inference_speech` itself (the loop the smaller id tests run)."""
+	import os
 	sd = W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0)
 	g = torch.Generator().manual_seed(1234)
 	text = torch.randint(1, 255, (1, TEXT), generator=g)
 	cond = torch.randn(1, 1024, generator=g)
 	with torch.inference_mode():
-		ids, logits = O.inference_speech(O.AROracle(sd, W.AR_FULL), cond, text, num_return_sequences=B, max_generate_length=MEL, temperature=TEMP, top_k=0,
-										 suppress_tokens=[STOP], sample_device="cuda", return_logits=True)
+		if os.environ.get("TTK_TEST_FULL_ORACLE_LOOP") == "1":
+			ids, logits = O.inference_speech(O.AROracle(sd, W.AR_FULL), cond, text, num_return_sequences=B, max_generate_length=MEL, temperature=TEMP, top_k=0,
+											 suppress_tokens=[STOP], sample_device="cuda", return_logits=True)
+			induction = None
+		else:
+			ids = free_run(build(sd, "f32"), cond, text)                           # candidate sequence
+			logits = O.AROracle(sd, W.AR_FULL).teacher_forced_logits(cond, text, ids, list(range(MEL)))
+			induction = replay_draws(logits, ids).cpu()                            # what the oracle draws at every step given that history
 	assert ids.shape == (B, MEL) and logits.shape == (B, MEL, W.AR_FULL.number_mel_codes)
-	return sd, text, cond, ids, logits
+	return sd, text, cond, ids, logits, induction
 
 
 def build(sd, dtype):
@@ -68,14 +98,21 @@ def first_divergence(a, b):
 
 
 def test_f32_ids_equal_the_oracle_at_the_benchmarked_configuration(case):
-	sd, text, cond, ref_ids, ref_logits = case
+	sd, text, cond, ref_ids, ref_logits, induction = case
 	with torch.inference_mode():
 		model = build(sd, "f32")
-		ids = free_run(model, cond, text)
-		if torch.equal(ids, ref_ids):
-			print(f"\n[ids] f32, configs[1] ({B} x {MEL} draws): equal to the oracle bit for bit")
-			return
-		fd = first_divergence(ids, ref_ids)
+		if induction is not None:
+			# ref_ids IS the product's sequence; the oracle, given that history, must draw the same token at every step
+			if torch.equal(induction, ref_ids):
+				print(f"\n[ids] f32, configs[1] ({B} x {MEL} draws): the oracle draws the product's token at every step: equal bit for bit")
+				return
+			ids, fd = ref_ids, first_divergence(ref_ids, induction)
+		else:
+			ids = free_run(model, cond, text)
+			if torch.equal(ids, ref_ids):
+				print(f"\n[ids] f32, configs[1] ({B} x {MEL} draws): equal to the oracle bit for bit")
+				return
+			fd = first_divergence(ids, ref_ids)
 		lg = forced_logits(model, cond, text, ref_ids).cpu()
 		worst = 0.0
 		for b, k in enumerate(fd):
@@ -89,7 +126,7 @@ def test_f32_ids_equal_the_oracle_at_the_benchmarked_configuration(case):
 
 
 def test_bf16_draws_agree_with_the_oracle_at_the_benchmarked_configuration(case):
-	sd, text, cond, ref_ids, ref_logits = case
+	sd, text, cond, ref_ids, ref_logits, _ = case
 	with torch.inference_mode():
 		model = build(sd, "bf16")
 		lg = forced_logits(model, cond, text, ref_ids)                     # product logits along the ORACLE's token sequence
