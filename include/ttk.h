@@ -131,8 +131,10 @@ int ttk_sample_step(const float* scores, int64_t ld, int B, int V, const float* 
  *   top_k (TopKLogitsWarper): scores below the k-th largest become -inf; 0 = off;
  *   top_p (TopPLogitsWarper): ascending cumulative softmax <= 1 - top_p becomes -inf, the largest score always stays; >= 1 or 0 = off.
  * The CLI's defaults (__main__.py:17-21: top-k 16) therefore stay on this one launch: no torch.topk / torch.sort per token, no host
- * round trip, capturable.  top-k / top-p / the penalty need V <= 9216 (the row is held in registers); TypicalLogitsWarper
- * (unified_voice.py:47-75) is not included -- a caller that wants it applies it in front and passes the finished scores.      */
+ * round trip, capturable.  top-k / top-p / typical sampling / the penalty need V <= 9216 (the row is held in registers).
+ *   typical_mass (TypicalLogitsWarper, unified_voice.py:47-75; what `inference_speech(typical_sampling=True)` adds as a custom processor): tokens in
+ *     ascending |-log p - H| are kept until their probability mass reaches typical_mass, the others become -inf; runs after the penalty and the
+ *     suppression, before the temperature; 0 or >= 1 = off.                                                                              */
 typedef struct {
 	const float* scores; int64_t ld; int B, V;
 	const float* q; int64_t ldq;              /* Exp(1) noise of torch.multinomial, drawn by the caller */
@@ -143,6 +145,8 @@ typedef struct {
 	int64_t *unfinished, *tok, *ids; int64_t ids_ld, ids_cols; int64_t* col;
 	int64_t* history; int64_t hist_ld, hist_off;   /* optional unless repetition_penalty is on */
 	int *live_rows, *all_done;                /* optional, see ttk_sample_step */
+	float typical_mass;                       /* TypicalLogitsWarper (unified_voice.py:47-75), applied after the processors and before the temperature,
+	                                           * where the reference's custom logits_processor runs; 0 or >= 1 = off */
 } ttk_sample_args;
 int ttk_sample_step_warped(const ttk_sample_args* a, void* stream);
 

@@ -87,11 +87,21 @@ def test_argument_errors():
 		ar.inference_speech_lines(al, [torch.full((1, 4), 300, device=DEV), _texts([3])[0]], num_return_sequences=2, **kw)
 
 
-def test_typical_sampling_falls_back_to_the_per_line_calls():
+def test_typical_sampling_in_line_batches_and_against_the_torch_op_form():
+	"""typical sampling runs inside the sampling kernel since round 3: a line batch equals the per-line calls (as for every other warper), and both
+	equal a model built with hf_exact_top_p=True, which runs the reference's TypicalLogitsWarper as torch ops in front of the kernel"""
 	cfg = W.AR_SMALL
 	ar = _model(cfg, "f32", max_batch=8, max_ctx=96)
 	al = torch.randn(1, cfg.model_dim, generator=torch.Generator().manual_seed(3)).to(DEV)
 	kw = dict(do_sample=True, temperature=0.9, top_k=0, max_generate_length=12, typical_sampling=True, typical_mass=0.8)
 	_check(ar, al, _texts([5, 8], seed=2), 3, kw)
+	exact = _model(cfg, "f32", max_batch=8, max_ctx=96, hf_exact_top_p=True)
+	same = ar
+	t = _texts([7], seed=5)[0]
+	with torch.inference_mode():
+		a = same.inference_speech(al, t, num_return_sequences=4, **kw)
+		off_a = torch.cuda.default_generators[0].get_offset()
+		b = exact.inference_speech(al, t, num_return_sequences=4, **kw)
+		assert torch.equal(a, b) and torch.cuda.default_generators[0].get_offset() == off_a
 	with pytest.raises(NotImplementedError):
 		ar.inference_speech_lines(al, _texts([5, 8]), num_return_sequences=2, do_sample=True, input_tokens=torch.zeros(1, 2))

@@ -451,3 +451,76 @@ def test_early_stop_without_per_token_sync_keeps_ids_and_rng_stream(lib, bias):
 				after = torch.rand(8, device=DEV)
 				assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (use_graph, got.shape, ref.shape)
 				assert torch.equal(after, after_ref), use_graph
+
+
+@pytest.mark.parametrize("mass,temp,top_k,pen", [(0.9, 0.8, 0, 1.0), (0.5, 1.0, 0, 1.0), (0.2, 1.2, 16, 2.0), (0.99, 0.7, 0, 1.0)])
+def test_typical_sampling_inside_the_kernel_equals_the_torch_op_chain(mass, temp, top_k, pen):
+	"""TypicalLogitsWarper (unified_voice.py:47-75) inside ttk_sample_step_warped (round 3), where the reference's custom logits_processor runs -- after
+	the repetition penalty and suppress_tokens, before temperature / top-k: sampled ids, history and the generator stream equal the torch-op chain
+	(tortoise_tts_amd.sampling.LogitsPipeline + torch.multinomial), token by token with a growing history; the kept set is probed at its boundary."""
+	from tortoise_tts_amd import _lib
+	from tortoise_tts_amd.sampling import LogitsPipeline
+	lib = _lib.load()
+	B, V, stop, steps, off = 16, 8194, 8193, 8, 2
+	g = torch.Generator().manual_seed(int(mass * 100) + top_k)
+	logits = [(torch.randn((B, V), generator=g) * 3).to(DEV) for _ in range(steps)]
+	for lg in logits:
+		lg[:, :40] += 4.0
+	sup = [7, 8193]
+	pipe = LogitsPipeline(temperature=temp, top_k=top_k, repetition_penalty=pen, suppress_tokens=sup, typical_mass=mass, vocab=V, device=DEV)
+	torch.manual_seed(5); torch.cuda.manual_seed_all(5)
+	input_ids = torch.ones((B, off), dtype=torch.long, device=DEV)
+	input_ids[:, -1] = 8192
+	ref = []
+	for lg in logits:
+		nxt = torch.multinomial(torch.softmax(pipe(input_ids, lg), dim=-1), num_samples=1).squeeze(1)
+		input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
+		ref.append(nxt)
+	ref = torch.stack(ref, 1)
+	after_ref = torch.rand(4, device=DEV)
+	torch.manual_seed(5); torch.cuda.manual_seed_all(5)
+	unf = torch.ones(B, dtype=torch.long, device=DEV)
+	tok = torch.empty(B, dtype=torch.long, device=DEV)
+	ids = torch.full((B, steps), -1, dtype=torch.long, device=DEV)
+	col = torch.zeros(B, dtype=torch.long, device=DEV)
+	hist = torch.ones((B, off + steps), dtype=torch.long, device=DEV)
+	hist[:, off - 1] = 8192
+	mask = torch.zeros(V, dtype=torch.bool, device=DEV)
+	mask[sup] = True
+	q = torch.empty((B, V), device=DEV)
+	a = _lib.SampleArgs()
+	a.ld, a.B, a.V, a.q, a.ldq = V, B, V, q.data_ptr(), V
+	a.suppress, a.temperature, a.top_k, a.top_p, a.repetition_penalty, a.typical_mass = mask.data_ptr(), temp, top_k, 1.0, pen, mass
+	a.stop_token, a.unfinished, a.tok, a.ids, a.ids_ld, a.ids_cols, a.col = stop, unf.data_ptr(), tok.data_ptr(), ids.data_ptr(), steps, steps, col.data_ptr()
+	a.history, a.hist_ld, a.hist_off = hist.data_ptr(), hist.stride(0), off
+	for lg in logits:
+		q.exponential_(1)
+		a.scores = lg.data_ptr()
+		_lib.check(lib.ttk_sample_step_warped(_lib.C.byref(a), _lib.stream_ptr()), "ttk_sample_step_warped")
+	torch.cuda.synchronize()
+	after = torch.rand(4, device=DEV)
+	assert torch.equal(ids, ref), (ids != ref).sum().item()
+	assert torch.equal(hist[:, off:], ref) and torch.equal(after, after_ref)
+	# the kept set at its boundary, without history (penalty off): the least typical token torch keeps is kept, the most typical one it drops is dropped
+	if pen == 1.0 and top_k == 0:
+		lg = logits[0]
+		sc = LogitsPipeline(temperature=temp, suppress_tokens=sup, typical_mass=mass, vocab=V, device=DEV)(None, lg)
+		kept = torch.isfinite(sc)
+		lp = torch.log_softmax(torch.where(mask, -float("inf"), lg), dim=-1)
+		H = -(lp * lp.exp()).nansum(-1, keepdim=True)
+		dist = (-lp - H).abs()
+		far_kept = torch.where(kept, dist, torch.full_like(dist, -1.0)).argmax(dim=-1)
+		near_drop = torch.where(~kept & ~mask, dist, torch.full_like(dist, float("inf"))).argmin(dim=-1)
+
+		def probe(idx):
+			qq = torch.ones((B, V), device=DEV)
+			qq[torch.arange(B, device=DEV), idx] = 1e-30
+			a2 = _lib.SampleArgs()
+			u2, t2, i2, c2 = torch.ones(B, dtype=torch.long, device=DEV), torch.empty(B, dtype=torch.long, device=DEV), torch.full((B, 1), -1, dtype=torch.long, device=DEV), torch.zeros(B, dtype=torch.long, device=DEV)
+			a2.scores, a2.ld, a2.B, a2.V, a2.q, a2.ldq = lg.data_ptr(), V, B, V, qq.data_ptr(), V
+			a2.suppress, a2.temperature, a2.top_k, a2.top_p, a2.repetition_penalty, a2.typical_mass = mask.data_ptr(), temp, 0, 1.0, 1.0, mass
+			a2.stop_token, a2.unfinished, a2.tok, a2.ids, a2.ids_ld, a2.ids_cols, a2.col = V + 5, u2.data_ptr(), t2.data_ptr(), i2.data_ptr(), 1, 1, c2.data_ptr()
+			_lib.check(lib.ttk_sample_step_warped(_lib.C.byref(a2), _lib.stream_ptr()), "ttk_sample_step_warped")
+			torch.cuda.synchronize()
+			return t2 == idx
+		assert bool(probe(far_kept).all()) and not bool(probe(near_drop).any())

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header_sizes():
 	assert ctypes.sizeof(_lib.DiffConfigC) == 7 * 4
 	assert ctypes.sizeof(_lib.StepC) == 8 + 9 * 4 + 2 * 4 + 4      # int64 + 9 floats + 2 ints, padded to 8
 	assert ctypes.sizeof(_lib.WeightView) == 8 + 8 + 8 + 32
-	assert ctypes.sizeof(_lib.SampleArgs) == 160                    # ttk_sample_args (static_assert'ed in csrc/sample.hip)
+	assert ctypes.sizeof(_lib.SampleArgs) == 168                    # ttk_sample_args (static_assert'ed in csrc/sample.hip)
 	from tortoise_tts_amd.vocoder import VocConfigC
 	assert ctypes.sizeof(VocConfigC) == (2 + 8 + 8 + 2 + 4 + 12 + 2) * 4          # ttk_voc_config: 38 ints
 

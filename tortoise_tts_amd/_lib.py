@@ -54,7 +54,7 @@ class SampleArgs(C.Structure):
 				("suppress", C.c_void_p), ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float),
 				("repetition_penalty", C.c_float), ("stop_token", C.c_int64), ("unfinished", C.c_void_p), ("tok", C.c_void_p),
 				("ids", C.c_void_p), ("ids_ld", C.c_int64), ("ids_cols", C.c_int64), ("col", C.c_void_p), ("history", C.c_void_p),
-				("hist_ld", C.c_int64), ("hist_off", C.c_int64), ("live_rows", C.c_void_p), ("all_done", C.c_void_p)]
+				("hist_ld", C.c_int64), ("hist_off", C.c_int64), ("live_rows", C.c_void_p), ("all_done", C.c_void_p), ("typical_mass", C.c_float)]
 
 
 class ProfResult(C.Structure):

@@ -11,7 +11,7 @@ What runs where
     stream restated (csrc/ttk_rng.h), used only after a bitwise comparison with `exponential_` on this device and shape
     (else torch `exponential_` on the same stream) -- the generator stream is part of the reference's observable behaviour
     (seed 0 on every call) and is left where torch's draws would have left it; typical sampling (rare, off by default)
-    stays a torch op in front of the kernel (sampling.py).
+    runs inside the kernel too since round 3 (sampling.py keeps the torch-op forms for `hf_exact_top_p`).
   * the per-token loop .............................................. here; one HIP-graph replay per token.
 """
 from __future__ import annotations
@@ -217,16 +217,16 @@ class UnifiedVoice:
 		hf_generate_kwargs.pop("input_tokens", None)
 		hf_generate_kwargs.pop("kv_cache", None)
 		typical = bool(hf_generate_kwargs.get("typical_sampling", False))
-		if len(texts) == 1 or typical:      # one line, or typical sampling (torch ops in front of the kernel, built per call): the per-line calls
+		if len(texts) == 1 or (typical and self.hf_exact_top_p):      # one line, or HF's warpers as torch ops in front of the kernel (built per call): the per-line calls
 			out, self.last_generate_lines = [], []
 			for t in texts:
 				out.append(self.inference_speech(speech_conditioning_latent, t, num_return_sequences=num_return_sequences,
 												 max_generate_length=max_generate_length, **hf_generate_kwargs))
 				self.last_generate_lines.append(dict(self.last_generate, seed=hf_generate_kwargs.get("seed", 0)))
 			return out
-		hf_generate_kwargs.pop("typical_sampling", None)
-		hf_generate_kwargs.pop("typical_mass", None)
-		return self._generate_lines(speech_conditioning_latent, texts, num_return_sequences, max_generate_length, hf_generate_kwargs)
+		ts, tm = hf_generate_kwargs.pop("typical_sampling", False), hf_generate_kwargs.pop("typical_mass", .9)
+		typical_mass = tm if ts else None
+		return self._generate_lines(speech_conditioning_latent, texts, num_return_sequences, max_generate_length, hf_generate_kwargs, typical_mass)
 
 	def position_rng_after_line(self, g: int):
 		"""leave the torch generators as the reference's `generate` on line g alone leaves them (reseeded, advanced by that line's draws)"""
@@ -234,7 +234,7 @@ class UnifiedVoice:
 		setup_seed(info["seed"])
 		torch.cuda.default_generators[self.device.index or 0].set_offset(info["rng_start"] + info["steps"] * info["rng_step"])
 
-	def _generate_lines(self, cond, texts, C, max_generate_length, kw):
+	def _generate_lines(self, cond, texts, C, max_generate_length, kw, typical_mass=None):
 		c = self.cfg
 		G = len(texts)
 		B = G * C
@@ -245,7 +245,7 @@ class UnifiedVoice:
 		if Tmax + 4 + max_new > self.max_ctx or max_new + 2 > c.max_mel_seq_len:
 			raise _lib.TTKError(f"prefix {Tmax + 4} + {max_new} new tokens exceed max_ctx={self.max_ctx} or the mel position table ({c.max_mel_seq_len})")
 		suppress = tuple(kw.get("suppress_tokens") or ())
-		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 50), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0), suppress, None)
+		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 50), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0), suppress, typical_mass)
 		can_stop = c.stop_mel_token not in suppress
 		seed = kw.get("seed", 0)
 		with torch.cuda.device(self.device):
@@ -552,11 +552,11 @@ class _GenState:
 		self.history = None
 		if self.pipe.needs_history:
 			self.history = torch.ones((B, 2 + max_new), dtype=torch.long, device=dev)
-		# everything but typical sampling runs inside the fused kernel (V <= 9216: the row lives in registers); the typical warper, when
-		# asked for, runs as torch ops in front of it in HF's order (after the processors, before temperature), which means the
-		# processors then run as torch ops too and the kernel sees finished scores for that part
+		# every processor and warper runs inside the fused kernel (V <= 9216: the row lives in registers), the typical-sampling warper included
+		# (round 3).  With hf_exact_top_p the cumulative-mass warpers (top-p, typical) run as torch ops in front of it instead, in HF's order, which
+		# means the processors then run as torch ops too and the kernel sees finished scores for that part
 		p = self.pipe
-		self.in_kernel = p.typical_mass is None and c.number_mel_codes <= 9216 and not (model.hf_exact_top_p and p.top_p is not None)
+		self.in_kernel = c.number_mel_codes <= 9216 and not (model.hf_exact_top_p and (p.top_p is not None or p.typical_mass is not None))
 		self.graphable = self.in_kernel or not p.needs_history      # torch-op penalty: its history slice grows with the host's step count
 		a = _lib.SampleArgs()
 		a.ld, a.B, a.V = self.logits.stride(0), B, c.number_mel_codes
@@ -572,6 +572,7 @@ class _GenState:
 			a.suppress = _lib.ptr(p.suppress_mask)
 			a.temperature = p.temperature or 1.0
 			a.top_k, a.top_p, a.repetition_penalty = p.top_k or 0, p.top_p or 1.0, p.repetition_penalty or 1.0
+			a.typical_mass = float(p.typical_mass or 0.0)
 		else:
 			a.temperature, a.top_k, a.top_p, a.repetition_penalty = 1.0, 0, 1.0, 1.0
 		self.args = a

@@ -34,13 +34,14 @@ constexpr int SAMPLE_THREADS = 1024;
 constexpr int SAMPLE_NPT = 9;          // elements per thread held in registers on the fast path
 constexpr int SAMPLE_MAXV = SAMPLE_NPT * SAMPLE_THREADS;
 
-static_assert(sizeof(ttk_sample_args) == 160, "ttk_sample_args layout (tortoise_tts_amd/_lib.py: SampleArgs mirrors it)");
+static_assert(sizeof(ttk_sample_args) == 168, "ttk_sample_args layout (tortoise_tts_amd/_lib.py: SampleArgs mirrors it)");
 
 struct SampleParams {
 	const float* scores; int64_t ld; int V;
 	const float* q; int64_t ldq;
 	const unsigned char* suppress; float inv_t;
 	int top_k; float top_p; float penalty, inv_penalty;          // 0 / >= 1 / 1 = off
+	float typical_mass;                                           // TypicalLogitsWarper (unified_voice.py:47-75); 0 / >= 1 = off
 	int64_t stop_token;
 	int64_t *unfinished, *tok, *ids; int64_t ids_ld, ids_cols; int64_t* col;
 	int64_t* history; int64_t hist_ld, hist_off;
@@ -160,13 +161,83 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_step(SampleParams p) 
 				if (i < V && ((seen[i >> 5] >> (i & 31)) & 1)) v[j] = v[j] < 0.f ? v[j] * p.penalty : v[j] * p.inv_penalty;
 			}
 		}
-		// ---- SuppressTokensLogitsProcessor, TemperatureLogitsWarper
+		// ---- SuppressTokensLogitsProcessor
 #pragma unroll
 		for (int j = 0; j < SAMPLE_NPT; ++j) {
 			const int i = tid + j * SAMPLE_THREADS, ic = i < V ? i : V - 1;
-			float t = (p.suppress && p.suppress[ic]) ? -INFINITY : v[j];
-			t = scale ? t * p.inv_t : t;
+			const float t = (p.suppress && p.suppress[ic]) ? -INFINITY : v[j];
 			v[j] = i < V ? t : -INFINITY;
+		}
+		// ---- TypicalLogitsWarper (unified_voice.py:47-75; the reference passes it as a custom processor: after the processors above, before the
+		// warpers below): with logp = log_softmax(scores), H = -sum p logp, every token gets the distance |-logp - H|; tokens are taken in ascending
+		// distance until their probability mass reaches `mass`, the rest becomes -inf.  No sort: the same 4-pass radix descent as top-p, over the
+		// order-preserving key of the DISTANCE with exact fixed-point probability masses -- the first key at which the running mass reaches
+		// mass * total is the threshold, everything at or below it stays.  (As with top-p, a row whose running mass ties with the threshold within
+		// f32 rounding can keep one token more or less than torch's f32 cumsum does.)
+		if (p.typical_mass > 0.f && p.typical_mass < 1.0f) {
+			float m0 = -INFINITY;
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) m0 = fmaxf(m0, v[j]);
+			m0 = block_max(m0, red, tid);
+			float e[SAMPLE_NPT], sum = 0.f;
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) { e[j] = expf(v[j] - m0); sum += e[j]; }
+			sum = block_sum(sum, red, tid);
+			const float lse = m0 + logf(sum);
+			float d[SAMPLE_NPT], hpart = 0.f;
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) {
+				const float lp = v[j] - lse, pr = e[j] / sum;
+				d[j] = lp;                                        // log p (kept; becomes the distance below)
+				if (v[j] != -INFINITY) hpart -= pr * lp;          // nansum: removed tokens contribute (-inf * 0) = nan -> skipped
+			}
+			const float H = block_sum(hpart, red, tid);
+			unsigned long long w[SAMPLE_NPT], tot = 0;
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) {
+				w[j] = (unsigned long long)((e[j] / sum) * 1099511627776.0f); tot += w[j];
+				d[j] = v[j] != -INFINITY ? fabsf(-d[j] - H) : INFINITY;      // |-logp - H|; removed tokens sort last (inf), as abs(inf - H) does
+			}
+			if (tid < 256) hist64[tid] = 0;
+			__syncthreads();
+			atomicAdd(&hist64[0], tot);
+			__syncthreads();
+			const unsigned long long total = hist64[0];
+			// first position (ascending distance) whose cumulative mass is NOT < mass  <=>  running total >= ceil(mass * total)  <=>  > that - 1
+			unsigned long long target = (unsigned long long)((double)p.typical_mass * (double)total);
+			if (target >= total && total > 0) target = total - 1;
+			if (target > 0) target -= 1;
+			__syncthreads();
+			unsigned prefix = 0, mask = 0;
+			unsigned long long below = 0;
+			for (int pass = 3; pass >= 0; --pass) {
+				const int shift = 8 * pass;
+				if (tid < 256) hist64[tid] = 0;
+				__syncthreads();
+#pragma unroll
+				for (int j = 0; j < SAMPLE_NPT; ++j) {
+					const unsigned k = fkey(d[j]);
+					if (w[j] && (k & mask) == prefix) atomicAdd(&hist64[(k >> shift) & 255], w[j]);
+				}
+				__syncthreads();
+				if (tid < 64) {
+					int bin; unsigned long long before;
+					pick_bin<unsigned long long, false>(hist64, target - below, lane, bin, before);
+					if (tid == 0) { s_bin = bin; s_before = before; }
+				}
+				__syncthreads();
+				prefix |= (unsigned)s_bin << shift;
+				mask |= 0xffu << shift;
+				below += s_before;
+			}
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j)
+				if (fkey(d[j]) > prefix) v[j] = -INFINITY;        // sorted_scores > sorted_scores[last_ind]
+		}
+		// ---- TemperatureLogitsWarper
+		if (scale) {
+#pragma unroll
+			for (int j = 0; j < SAMPLE_NPT; ++j) v[j] = v[j] * p.inv_t;
 		}
 		// ---- TopKLogitsWarper: scores < (k-th largest) -> -inf
 		if (p.top_k > 0 && p.top_k < V) {
@@ -328,13 +399,15 @@ int launch_sample_step(const ttk_sample_args* a, const float* emb, const float* 
 	TTK_REQUIRE(a && a->scores && a->q && a->unfinished && a->tok && a->ids && a->col, TTK_E_ARG, "%s: null argument", who);
 	TTK_REQUIRE(a->B >= 1 && a->V >= 1 && a->ld >= a->V && a->ldq >= a->V, TTK_E_ARG, "%s: bad shape (B %d, V %d)", who, a->B, a->V);
 	TTK_REQUIRE(a->temperature > 0.f, TTK_E_ARG, "%s: temperature must be positive", who);
-	const bool warp = a->top_k > 0 || (a->top_p > 0.f && a->top_p < 1.0f) || (a->repetition_penalty > 0.f && a->repetition_penalty != 1.0f);
-	TTK_REQUIRE(!warp || a->V <= SAMPLE_MAXV, TTK_E_ARG, "%s: top-k / top-p / repetition penalty need V <= %d (V %d)", who, SAMPLE_MAXV, a->V);
+	const bool warp = a->top_k > 0 || (a->top_p > 0.f && a->top_p < 1.0f) || (a->repetition_penalty > 0.f && a->repetition_penalty != 1.0f) ||
+					  (a->typical_mass > 0.f && a->typical_mass < 1.0f);
+	TTK_REQUIRE(!warp || a->V <= SAMPLE_MAXV, TTK_E_ARG, "%s: top-k / top-p / typical sampling / repetition penalty need V <= %d (V %d)", who, SAMPLE_MAXV, a->V);
+	TTK_REQUIRE(a->typical_mass >= 0.f, TTK_E_ARG, "%s: negative typical_mass", who);
 	TTK_REQUIRE(a->top_p >= 0.f && a->repetition_penalty >= 0.f, TTK_E_ARG, "%s: negative top_p / repetition_penalty", who);
 	TTK_REQUIRE(!(a->repetition_penalty > 0.f && a->repetition_penalty != 1.0f) || a->history, TTK_E_ARG, "%s: the repetition penalty needs the history buffer", who);
 	SampleParams p = {};
 	p.scores = a->scores; p.ld = a->ld; p.V = a->V; p.q = a->q; p.ldq = a->ldq; p.suppress = a->suppress; p.inv_t = 1.0f / a->temperature;
-	p.top_k = a->top_k; p.top_p = a->top_p;
+	p.top_k = a->top_k; p.top_p = a->top_p; p.typical_mass = a->typical_mass;
 	p.penalty = a->repetition_penalty > 0.f ? a->repetition_penalty : 1.0f; p.inv_penalty = 1.0f / p.penalty;
 	p.stop_token = a->stop_token; p.unfinished = a->unfinished; p.tok = a->tok; p.ids = a->ids; p.ids_ld = a->ids_ld; p.ids_cols = a->ids_cols;
 	p.col = a->col; p.history = a->history; p.hist_ld = a->hist_ld; p.hist_off = a->hist_off; p.live_rows = a->live_rows; p.all_done = a->all_done;
