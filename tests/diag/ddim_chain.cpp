@@ -1,0 +1,188 @@
+// Diagnostic (not a test, not product code): the launches of one DiffusionLayer of the DDIM loop's body as libttk issues them at configs[1]'s
+// size (bf16, cond + cond-free batch of 2, T = 1088: M = 2176 rows, C = 1024) -- ResBlock {GroupNorm-apply, 1x1 GEMM, GroupNorm-apply, k=3 GEMM +
+// residual} + AttentionBlock {GroupNorm-apply, QKV GEMM, attention, proj GEMM + residual} -- chained over NL layers with distinct weights in ONE
+// captured graph: (a) microseconds per layer, and (b) in-kernel timestamps of EVERY wave of the eight kernels of one layer in the middle of the
+// chain: kernel boundaries, start spread, and the phases inside (GEMM: first requests issued, first tile landed, k-loop, epilogue, stores acknowledged).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTTK_STAMPS=2 -I tortoise_tts_amd/csrc tests/diag/ddim_chain.cpp -o tests/diag/ddim_chain.bin
+//   tests/diag/ddim_chain.bin [replays=10]          env: DC_LAYERS (20), DC_T (1088), DC_NB (2), DC_PF (1: GroupNorm-apply / attention touch the next GEMM's weights)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../../tortoise_tts_amd/csrc/gemm.hip"
+#include "../../tortoise_tts_amd/csrc/norm.hip"
+#include "../../tortoise_tts_amd/csrc/attn.hip"
+bool ttk::g_prof_on = false;
+void ttk::prof_start(int, double, hipStream_t) {}
+void ttk::prof_stop(hipStream_t) {}
+void ttk::prof_pair(int, double, hipEvent_t* a, hipEvent_t* b) { *a = nullptr; *b = nullptr; }
+using namespace ttk;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e), __LINE__); return 1; } } while (0)
+static int envi(const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; }
+
+constexpr int MAXWG = 1200;
+constexpr size_t SLOTS = (size_t)MAXWG * 16 * 8;
+
+static double q(std::vector<double> v, double f) {
+	if (v.empty()) return 0;
+	std::sort(v.begin(), v.end());
+	return v[std::min(v.size() - 1, (size_t)(f * (v.size() - 1) + 0.5))];
+}
+
+int main(int argc, char** argv) {
+	const int replays = argc > 1 ? atoi(argv[1]) : 10;
+	const int NL = envi("DC_LAYERS", 20), SL = NL / 2, T = envi("DC_T", 1088), nb = envi("DC_NB", 2), C = 1024, H = 16, M = nb * T, pf = envi("DC_PF", 1);
+	struct Layer { void *w1, *w3, *wqkv, *wproj; };
+	std::vector<Layer> L(NL);
+	for (int i = 0; i < NL; ++i) {
+		CK(hipMalloc(&L[i].w1, (size_t)C * C * 2)); CK(hipMalloc(&L[i].w3, (size_t)3 * C * C * 2)); CK(hipMalloc(&L[i].wqkv, (size_t)3 * C * C * 2)); CK(hipMalloc(&L[i].wproj, (size_t)C * C * 2));
+		CK(hipMemset(L[i].w1, 0, (size_t)C * C * 2)); CK(hipMemset(L[i].w3, 0, (size_t)3 * C * C * 2)); CK(hipMemset(L[i].wqkv, 0, (size_t)3 * C * C * 2)); CK(hipMemset(L[i].wproj, 0, (size_t)C * C * 2));
+	}
+	float *x, *hf, *ms, *gam, *bet, *bias, *relb; void *a, *qkv, *ao; unsigned long long* stamps;
+	const int nch = gn_num_chunks(T, C);
+	CK(hipMalloc(&x, (size_t)M * C * 4)); CK(hipMalloc(&hf, (size_t)M * C * 4)); CK(hipMalloc(&ms, (size_t)nb * 32 * nch * 3 * 4));
+	CK(hipMalloc(&gam, C * 4)); CK(hipMalloc(&bet, C * 4)); CK(hipMalloc(&bias, 3 * C * 4)); CK(hipMalloc(&relb, H * 129 * 4));
+	CK(hipMalloc(&a, (size_t)M * C * 2)); CK(hipMalloc(&qkv, (size_t)M * 3 * C * 2)); CK(hipMalloc(&ao, (size_t)M * C * 2));
+	CK(hipMalloc(&stamps, 8 * SLOTS * 8));
+	CK(hipMemset(x, 0, (size_t)M * C * 4)); CK(hipMemset(hf, 0, (size_t)M * C * 4)); CK(hipMemset(gam, 0, C * 4)); CK(hipMemset(bet, 0, C * 4)); CK(hipMemset(bias, 0, 3 * C * 4)); CK(hipMemset(relb, 0, H * 129 * 4));
+	CK(hipMemset(a, 0, (size_t)M * C * 2)); CK(hipMemset(qkv, 0, (size_t)M * 3 * C * 2)); CK(hipMemset(ao, 0, (size_t)M * C * 2));
+	{   // valid statistics: every chunk (64 rows x 32 channels) count 2048, mean 0, M2 2048
+		std::vector<float> h((size_t)nb * 32 * nch * 3);
+		for (size_t i = 0; i < h.size(); i += 3) { h[i] = 2048.f; h[i + 1] = 0.f; h[i + 2] = 2048.f; }
+		CK(hipMemcpy(ms, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+	}
+	hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+
+	auto gn = [&](const float* src, const void* next_w, int64_t next_bytes, int taps, unsigned long long* st) {
+		GnApplyParams p = {};
+		p.x = src; p.ms = ms; p.gamma = gam; p.beta = bet; p.nb = nb; p.T = T; p.Tout = T; p.C = C; p.nchunks = nch; p.act = ACT_SILU; p.out = a;
+		if (pf) { p.pf = next_w; p.pf_bytes = next_bytes; p.pf_taps = taps; }
+		p.stamps = st;
+		launch_gn_apply(DT_BF16, p, s);
+	};
+	auto layer = [&](int i, unsigned long long* st) {
+		auto S = [&](int k) { return st ? st + k * SLOTS : nullptr; };
+		// ResBlock
+		gn(x, L[i].w1, (int64_t)C * C * 2, 1, S(0));
+		GemmParams g = {};
+		g.nseg = 1; g.seg[0] = {a, C, 0, 0}; g.W = L[i].w1; g.ldw = C; g.M = M; g.N = C; g.K = C; g.bias = bias; g.C = hf; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; g.stamps = S(1);
+		launch_gemm(DT_BF16, g, s);
+		gn(hf, L[i].w3, (int64_t)C * C * 2, 3, S(2));
+		g = {};
+		g.nseg = 3; for (int j = 0; j < 3; ++j) g.seg[j] = {a, C, j - 1, (int64_t)j * C * C};
+		g.W = L[i].w3; g.ldw = C; g.M = M; g.N = C; g.K = C; g.rows_per_batch = T; g.bias = bias; g.residual = x; g.ldr = C; g.C = x; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; g.stamps = S(3);
+		launch_gemm(DT_BF16, g, s);
+		// AttentionBlock
+		gn(x, L[i].wqkv, (int64_t)3 * C * C * 2, 1, S(4));
+		g = {};
+		g.nseg = 1; g.seg[0] = {a, C, 0, 0}; g.W = L[i].wqkv; g.ldw = C; g.M = M; g.N = 3 * C; g.K = C; g.bias = bias; g.C = qkv; g.ldc = 3 * C; g.stamps = S(5);
+		launch_gemm(DT_BF16, g, s);
+		AttnParams at = {};
+		at.qkv = qkv; at.ld = 3 * C; at.q_off = 0; at.k_off = 64; at.v_off = 128; at.head_stride = 192; at.out = ao; at.ldo = C; at.nb = nb; at.T = T; at.H = H; at.bias = relb; at.scale = 0.125f;
+		if (pf) { at.pf = L[i].wproj; at.pf_bytes = (int64_t)C * C * 2; at.pf_taps = 1; }
+		at.stamps = S(6);
+		launch_attn_fwd(DT_BF16, at, s);
+		g = {};
+		g.nseg = 1; g.seg[0] = {ao, C, 0, 0}; g.W = L[i].wproj; g.ldw = C; g.M = M; g.N = C; g.K = C; g.bias = bias; g.residual = x; g.ldr = C; g.C = x; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; g.stamps = S(7);
+		launch_gemm(DT_BF16, g, s);
+	};
+	for (int i = 0; i < NL; ++i) layer(i, nullptr);
+	CK(hipStreamSynchronize(s));
+	hipGraph_t gr; hipGraphExec_t ge, ges;
+	CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+	for (int i = 0; i < NL; ++i) layer(i, nullptr);
+	CK(hipStreamEndCapture(s, &gr)); CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0)); CK(hipGraphDestroy(gr));
+	CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+	for (int i = 0; i < NL; ++i) layer(i, i == SL ? stamps : nullptr);
+	CK(hipStreamEndCapture(s, &gr)); CK(hipGraphInstantiate(&ges, gr, nullptr, nullptr, 0)); CK(hipGraphDestroy(gr));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	float best = 1e9f, best_eager = 1e9f;
+	for (int rep = 0; rep < 4; ++rep) {
+		CK(hipEventRecord(e0, s));
+		for (int r = 0; r < replays; ++r) CK(hipGraphLaunch(ge, s));
+		CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+		float msv; CK(hipEventElapsedTime(&msv, e0, e1));
+		if (rep >= 1) best = std::min(best, msv);
+	}
+	for (int rep = 0; rep < 3; ++rep) {
+		CK(hipEventRecord(e0, s));
+		for (int r = 0; r < replays; ++r) for (int i = 0; i < NL; ++i) layer(i, nullptr);
+		CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+		float msv; CK(hipEventElapsedTime(&msv, e0, e1));
+		if (rep >= 1) best_eager = std::min(best_eager, msv);
+	}
+	printf("ddim chain: T %d nb %d (M = %d), %d layers x %d replays, prefetch %d: graph %.2f us per layer (%.2f per launch), eager %.2f us per layer\n", T, nb, M, NL, replays, pf,
+		   best * 1e3 / (replays * NL), best * 1e3 / (replays * NL * 8), best_eager * 1e3 / (replays * NL));
+
+	const char* names[8] = {"gn_apply (res in)", "gemm 1x1", "gn_apply (res out)", "gemm k=3 + res", "gn_apply (attn)", "gemm qkv", "attention", "gemm proj + res"};
+	const bool is_gemm[8] = {false, true, false, true, false, true, false, true};
+	std::vector<unsigned long long> hs(8 * SLOTS);
+	std::vector<double> stat[8][10];
+	for (int rep = 0; rep < 9; ++rep) {
+		CK(hipMemsetAsync(stamps, 0, 8 * SLOTS * 8, s));
+		CK(hipGraphLaunch(ge, s)); CK(hipGraphLaunch(ges, s)); CK(hipGraphLaunch(ge, s));
+		CK(hipMemcpyAsync(hs.data(), stamps, 8 * SLOTS * 8, hipMemcpyDeviceToHost, s));
+		CK(hipStreamSynchronize(s));
+		if (rep < 2) continue;
+		double prev_end = 0;
+		for (int k = 0; k < 8; ++k) {
+			const unsigned long long* st = hs.data() + k * SLOTS;
+			double t0 = 1e30, t_ack = 0;
+			std::vector<double> starts, ph[5], wgd;
+			int nw = 0;
+			for (int w = 0; w < MAXWG; ++w) {
+				double ws = 1e30, we = 0;
+				for (int v = 0; v < 16; ++v) {
+					const unsigned long long* p = st + ((size_t)w * 16 + v) * 8;
+					if (!p[0]) continue;
+					++nw;
+					t0 = std::min(t0, (double)p[0]); ws = std::min(ws, (double)p[0]);
+					const double end = (double)(p[5] ? p[5] : p[4]);
+					we = std::max(we, end); t_ack = std::max(t_ack, end);
+				}
+				if (we > 0) wgd.push_back(we - ws);
+			}
+			for (int w = 0; w < MAXWG; ++w)
+				for (int v = 0; v < 16; ++v) {
+					const unsigned long long* p = st + ((size_t)w * 16 + v) * 8;
+					if (!p[0]) continue;
+					starts.push_back((double)p[0] - t0);
+					if (is_gemm[k]) {
+						if (p[1]) ph[0].push_back((double)p[1] - p[0]);
+						if (p[1] && p[2]) ph[1].push_back((double)p[2] - p[1]);
+						if (p[2] && p[3]) ph[2].push_back((double)p[3] - p[2]);
+						if (p[3] && p[4]) ph[3].push_back((double)p[4] - p[3]);
+						if (p[4] && p[5]) ph[4].push_back((double)p[5] - p[4]);
+					} else if (k == 6) {
+						if (p[4]) ph[2].push_back((double)p[4] - p[0]);
+						if (p[4] && p[5]) ph[4].push_back((double)p[5] - p[4]);
+					} else {
+						if (p[1]) ph[0].push_back((double)p[1] - p[0]);
+						if (p[1] && p[2]) ph[1].push_back((double)p[2] - p[1]);
+						if (p[2] && p[4]) ph[3].push_back((double)p[4] - p[2]);
+						if (p[4] && p[5]) ph[4].push_back((double)p[5] - p[4]);
+					}
+				}
+			auto push = [&](int i, double v) { stat[k][i].push_back(v * 0.01); };
+			push(0, k == 0 ? 0 : t0 - prev_end);
+			push(1, q(starts, 0.5)); push(2, q(starts, 1.0));
+			for (int i = 0; i < 5; ++i) push(3 + i, q(ph[i], 0.5));
+			push(8, q(wgd, 0.5)); push(9, t_ack - t0);
+			prev_end = t_ack;
+			if (rep == 2) stat[k][0].push_back(0), stat[k][0].pop_back();
+			(void)nw;
+		}
+	}
+	auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+	printf("%-20s | %8s | start p50 / max | issue   1st-tile  k-loop   epilogue  ack  (gn: loads, merge+barrier, -, apply+stores, ack) | WG dur p50 | first start..last ack\n", "kernel", "boundary");
+	double sum = 0;
+	for (int k = 0; k < 8; ++k) {
+		printf("%-20s | %8.2f | %6.2f %6.2f   | %5.2f   %5.2f    %6.2f   %5.2f    %5.2f | %8.2f   | %7.2f us\n", names[k], med(stat[k][0]), med(stat[k][1]), med(stat[k][2]),
+			   med(stat[k][3]), med(stat[k][4]), med(stat[k][5]), med(stat[k][6]), med(stat[k][7]), med(stat[k][8]), med(stat[k][9]));
+		sum += med(stat[k][0]) + med(stat[k][9]);
+	}
+	printf("sum of boundaries + spans of the stamped layer: %.2f us\n", sum);
+	return 0;
+}

@@ -74,8 +74,15 @@ template <> struct VT<float> {
 // NWV = waves per workgroup (4 or 8), each owning 16 * QT queries: 8 x 16 = 128-query blocks halve the K / V bytes a CU takes in per query (every
 // workgroup streams all keys of its head through LDS; at T = 1088 that is 590 KB per CU and launch with 64-query blocks, against ~60 GB/s a
 // CU can pull from L2) and still leave two waves per SIMD to overlap one wave's softmax VALU work with the other's MFMAs.
+// NWV = 9 = the BALANCED form (non-causal, QT = 1): gridDim.x workgroups per (batch, head) share its 16-query tiles as evenly as they divide -- a
+// workgroup gets `cnt` = 8 or 9 consecutive tiles, one per wave -- chosen by the launcher so that batch x heads x gridDim.x is exactly the number of
+// CUs.  At T = 1088 (68 tiles) with the conditioned + conditioning-free pair that is 8 workgroups per head, 256 in all, one per CU, where 64-query
+// blocks make 544 workgroups: 2.125 per CU, so 32 CUs run three at once and the launch lasts 27 us for a median workgroup of 21 (stamps of every
+// wave: tests/diag/ddim_chain.cpp).  Each tile's arithmetic is the QT = 1 form's, so the output is bit-identical.  K / V tiles are staged by the
+// first 512 threads.
 template <typename T, bool CAUSAL, bool BIAS, int QT, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnParams p) {
+	constexpr bool BAL = NWV == 9;
 	typedef typename Frag<T>::type FragT;
 	constexpr int ES = sizeof(T);
 	constexpr int ROWB = HD * ES;             // LDS row bytes (128 bf16 / 256 f32)
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	constexpr int SWM = NCH - 1;              // swizzle mask on the row index
 	constexpr int FCH = 8 * ES / 16;          // chunks per fragment
 	constexpr int TILE_CH = 64 * NCH;         // chunks per K (or V) tile
-	constexpr int NTH = 64 * NWV;
+	constexpr int NTH = BAL ? 512 : 64 * NWV; // threads that stage K / V tiles
 	constexpr int CPT = TILE_CH / NTH;        // chunks per thread (bf16 / f32: 2 / 4 with 4 waves, 1 / 2 with 8)
 	__shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
 	__shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
@@ -92,18 +99,25 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int h = blockIdx.y, b = blockIdx.z;
 	constexpr int QW = 16 * QT, QB = NWV * QW;        // queries per wave / per workgroup
-	const int q0 = blockIdx.x * QB + wave * QW;       // first query row of this wave
 	const int li = lane & 15, g = lane >> 4;
+	TTK_WSTAMP(p.stamps, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 0);
 	// ragged batch: sequence b holds TL valid rows in its slot of p.T rows.  Every bound below is the sequence's own (TL); p.T is only the stride.
 	const int TL = p.tlen ? p.tlen[b] : p.T;
-	if ((int)blockIdx.x * QB >= TL) return;           // a query block of padding rows (uniform for the workgroup: before any barrier)
+	int q0 = blockIdx.x * QB + wave * QW;             // first query row of this wave
+	int cnt = NWV;                                    // BAL: 16-query tiles (= working waves) of this workgroup
+	if (BAL) {
+		const int tiles = (TL + 15) / 16, G = gridDim.x, per = tiles / G, extra = tiles - per * G;
+		cnt = per + ((int)blockIdx.x < extra ? 1 : 0);
+		q0 = 16 * ((int)blockIdx.x * per + min((int)blockIdx.x, extra) + wave);
+		if (cnt == 0) return;
+	} else if ((int)blockIdx.x * QB >= TL) return;    // a query block of padding rows (uniform for the workgroup: before any barrier)
 	const T* base = (const T*)p.qkv + (int64_t)b * p.T * p.ld;
 	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
 
 	__shared__ unsigned pf_sink[64 * NWV];
 	if (p.pf) {   // the following projection's weights into L2; workgroups are numbered x-fastest over the (query block, head, batch) grid
 		const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-		l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (threadIdx.x >> 6) * 256), lin, gridDim.x * gridDim.y * gridDim.z, threadIdx.x, NTH);
+		l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (threadIdx.x >> 6) * 256), lin, gridDim.x * gridDim.y * gridDim.z, threadIdx.x, 64 * NWV);
 	}
 	if (BIAS) {
 		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid] * LOG2E;   // scores live in the log2 domain (exp2 = one v_exp_f32)
@@ -152,11 +166,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 		*(uint4*)(Vs + off) = v;
 	};
 	auto load_kv = [&](int kt) {
+		if (BAL && tid >= NTH) return;
 		ld1(kt, 0, rk0, rv0);
 		if (CPT > 1) ld1(kt, 1, rk1, rv1);
 		if (CPT > 2) { ld1(kt, 2, rk2, rv2); ld1(kt, 3, rk3, rv3); }
 	};
 	auto store_kv = [&]() {
+		if (BAL && tid >= NTH) return;
 		st1(0, rk0, rv0);
 		if (CPT > 1) st1(1, rk1, rv1);
 		if (CPT > 2) { st1(2, rk2, rv2); st1(3, rk3, rv3); }
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 		load_kv(kt + 1 < nkt ? kt + 1 : kt);   // unconditional (the last tile is re-read): keeps the staging registers out of scratch
 
 		const int k0 = kt * 64;
-		const bool wave_active = !CAUSAL || k0 <= q0 + QW - 1;
+		const bool wave_active = (!CAUSAL || k0 <= q0 + QW - 1) && (!BAL || wave < cnt);
 		if (wave_active) {
 			// ---- S^T tile: 4 key sub-tiles x 2 query tiles
 			f32x4 s[QT][4];
@@ -289,7 +305,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 		l += __shfl_xor(l, 32);
 		const float inv = 1.0f / l;
 		const int qi = q0 + 16 * qt + li;
-		if (qi < TL) {
+		if (qi < TL && (!BAL || wave < cnt)) {
 			if (p.out_f8) {      // operand of an fp8 projection GEMM: four consecutive head dims = one 32-bit store
 				unsigned char* dst = (unsigned char*)p.out + ((int64_t)b * p.T + qi) * p.ldo + h * HD;
 #pragma unroll
@@ -304,6 +320,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 			}
 		}
 	}
+	TTK_WSTAMPD(p.stamps, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 4, o[0][0][0]);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	TTK_WSTAMP(p.stamps, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 5);
+#endif
 }
 
 template <typename T>
@@ -320,6 +341,17 @@ static void launch_attn_fwd_t(const AttnParams& p, hipStream_t s) {
 		if (p.bias) hipLaunchKernelGGL((k_attn_fwd<T, false, true, 1, 8>), grid, dim3(512), 0, s, p);
 		else hipLaunchKernelGGL((k_attn_fwd<T, false, false, 1, 8>), grid, dim3(512), 0, s, p);
 		return;
+	}
+	// balanced form: batch x heads x G workgroups == 256 (the CUs), each with 8..9 tiles
+	static const int bal = [] { const char* e = getenv("TTK_ATTN_BAL"); return e ? atoi(e) : 1; }();
+	if (bal && !force_qt && !p.causal && !p.tlen && p.nb * p.H <= 256 && 256 % (p.nb * p.H) == 0) {
+		const int G = 256 / (p.nb * p.H), tiles = (p.T + 15) / 16;
+		if ((tiles + G - 1) / G <= 9 && tiles / G >= 6) {
+			dim3 grid(G, p.H, p.nb);
+			if (p.bias) hipLaunchKernelGGL((k_attn_fwd<T, false, true, 1, 9>), grid, dim3(576), 0, s, p);
+			else hipLaunchKernelGGL((k_attn_fwd<T, false, false, 1, 9>), grid, dim3(576), 0, s, p);
+			return;
+		}
 	}
 	if (big) {
 		dim3 grid((p.T + 127) / 128, p.H, p.nb);

@@ -171,7 +171,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	typedef typename Frag<T>::type FragT;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 
+	// what the prologue and the first segment read, as one batch of scalar loads (the ~500-byte argument block was fetched in six dependent round trips:
+	// a wave's first DMA request left 1.8 us after its first instruction, 1.2 us with the batch -- tests/diag/ddim_chain.cpp; pinning the epilogue's
+	// fields as well costs more in SGPR pressure than it returns, profiles/r03 notes)
+	TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.N), TTK_S(p.K), TTK_S(p.nseg), TTK_S(p.W), TTK_S(p.ldw), TTK_S(p.rows_per_batch), TTK_S(p.m_major),
+				 TTK_S(p.seg[0].A), TTK_S(p.seg[0].lda), TTK_S(p.seg[0].shift), TTK_S(p.seg[0].w_off));
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef TTK_STAMPS
+	unsigned long long* const stamps_ = p.stamps;
+#endif
+	TTK_WSTAMP(stamps_, blockIdx.x, 0);
 	const int wm = wave / NWN, wn = wave % NWN;
 	const int tiles_m = (p.M + BM - 1) / BM;
 	// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give
@@ -336,9 +345,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 #pragma unroll
 	for (int st = 0; st < NSTAGE; ++st)
 		if (st < NTILES) issue(st);
+	TTK_WSTAMP(stamps_, blockIdx.x, 1);
 	wait_tiles(min(NSTAGE, NTILES) - 1);                       // tile 0 has landed
 	__builtin_amdgcn_s_barrier();
 	asm volatile("" ::: "memory");
+	TTK_WSTAMP(stamps_, blockIdx.x, 2);
 	Frags f0, f1;
 	read_frags(f0, 0);
 	int kt = 0;
@@ -348,12 +359,18 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	}
 	if (kt + 2 == NTILES) { step(kt, f0, f1); mfma_tile(f1); }
 	else mfma_tile(f0);
+	TTK_WSTAMPD(stamps_, blockIdx.x, 3, acc[0][0][0]);
 
 	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
 	const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
 	if (p.transpose_out) { if (full) epilogue<T, 2, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 2, true, MI, NI>(p, acc, row0, col0, lane); }
 	else if (p.out_f32) { if (full) epilogue<T, 1, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 1, true, MI, NI>(p, acc, row0, col0, lane); }
 	else { if (full) epilogue<T, 0, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 0, true, MI, NI>(p, acc, row0, col0, lane); }
+	TTK_WSTAMP(stamps_, blockIdx.x, 4);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	TTK_WSTAMP(stamps_, blockIdx.x, 5);
+#endif
 }
 
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
@@ -391,6 +408,16 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 	else {
 		tile = pick_tile(p.M, p.N);
 	}
+	// 128 x 128 tiles that need a second, partly filled round (257..511 of them: one 96 KiB workgroup per CU) while 256 x 128 tiles fit one round: the QKV
+	// GEMM of a DDIM step at T = 1088 (408 tiles -> 216).  In-kernel stamps inside the replayed chain (tests/diag/ddim_chain.cpp): the second round starts
+	// 11.2 us into a 21.1 us launch; 256 x 128 x 8 waves takes 18.5 us.  (2-stage ring, two workgroups per CU: 25.6; 128 x 64: 22.9.)  Same k order per
+	// output element, so the same bits.  TTK_GEMM_TILE_WIDE overrides (tuning).
+	static const int wide = [] { const char* e = getenv("TTK_GEMM_TILE_WIDE"); return e ? atoi(e) : -2; }();
+	if (g_force_tile < 100 && tile == 0 && !p.gn_part) {
+		const int t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128), t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+		if (wide >= 0) { if (p.N >= 3072) tile = wide; }
+		else if (wide == -2 && t128 > 256 && t128 < 512 && t256 <= 256 && sizeof(T) == 2) tile = 8;
+	}
 	if (tile == 0) launch_tile<T, 128, 128, 2, 4, 3>(p, s, ea, eb);       // 8 waves, wave block 64 x 32, two workgroups per CU
 	else if (tile == 1) launch_tile<T, 128, 64, 2, 2, 3>(p, s, ea, eb);   // 4 waves, wave block 64 x 32, two workgroups per CU
 	else if (tile == 3) launch_tile<T, 128, 128, 2, 4, 4>(p, s, ea, eb);  // as 0 with a 4-stage ring (128 KiB: one workgroup per CU)
@@ -398,6 +425,8 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 	else if (tile == 5) launch_tile<T, 128, 64, 4, 2, 3>(p, s, ea, eb);   // as 1 with 8 waves (wave block 32 x 32): twice the waves issuing the LDS-DMA pieces
 	else if (tile == 6) launch_tile<T, 128, 64, 2, 4, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 16
 	else if (tile == 7) launch_tile<T, 256, 64, 4, 2, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 32, 120 KiB: one workgroup per CU
+	else if (tile == 8) launch_tile<T, 256, 128, 4, 2, 3>(p, s, ea, eb);  // 8 waves, wave block 64 x 64, 144 KiB: one workgroup per CU
+	else if (tile == 9) launch_tile<T, 128, 128, 2, 4, 2>(p, s, ea, eb);  // as 0 with a 2-stage ring (64 KiB: two workgroups per CU)
 	else launch_tile<T, 64, 64, 2, 2, 3>(p, s, ea, eb);
 }
 

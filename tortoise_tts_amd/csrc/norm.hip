@@ -136,6 +136,7 @@ void launch_gn_stats(const float* x, int nb, int T, int C, float* part, hipStrea
 template <typename OT, int GN_PASSES>
 __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	__shared__ float s_mean[32], s_rstd[32];
+	TTK_WSTAMP(p.stamps, blockIdx.x, 0);
 	const int c4n = p.C / 4;                    // threads per row
 	const int rpp = 256 / c4n;                  // rows per pass (C <= 1024)
 	const int strip = rpp * GN_PASSES;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 		const int ti = to < p.Tout ? (p.row_idx ? p.row_idx[to] : to) : 0;
 		xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + ti) * p.C + c);
 	}
+	TTK_WSTAMP(p.stamps, blockIdx.x, 1);
 	__shared__ unsigned pf_sink[64 * 4];
 	if (p.pf)     // the next GEMM's weights into L2 (see GnApplyParams)
 		l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (threadIdx.x >> 6) * 256), blockIdx.x, gridDim.x, threadIdx.x, 256);
@@ -180,6 +182,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 		if (sub == 0) { s_mean[g] = mean; s_rstd[g] = rsqrtf(m2 / nt + 1e-5f); }
 	}
 	__syncthreads();
+	TTK_WSTAMP(p.stamps, blockIdx.x, 2);
 	const int g = c / (p.C / 32);
 	const float mean = s_mean[g], rstd = s_rstd[g];
 	const float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
@@ -205,6 +208,100 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 			*(float4*)dst = make_float4(o0, o1, o2, o3);
 		}
 	}
+	TTK_WSTAMP(p.stamps, blockIdx.x, 4);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	TTK_WSTAMP(p.stamps, blockIdx.x, 5);
+#endif
+}
+
+// The DDIM loop's case of k_gn_apply -- C = 1024 (one thread = 4 channels of ONE row), no row gather -- with the shape decisions at compile time.
+// In-kernel stamps of every wave inside the replayed chain (tests/diag/ddim_chain.cpp, profiles/r03_ddim_chain_*.log) showed the generic kernel at
+// 5.5 us for a pass whose rows stream in ~1.5: 1.2 us between a wave's first instruction and its row requests (six run-time integer divisions -- c4n,
+// rows per pass, strips, the batch index, tid / c4n, tid % c4n -- and the arguments fetched in several dependent scalar round trips), and the
+// statistics merge waiting for the weight touches: those were issued between the row requests and the triples, vmcnt retires in order, so the triples
+// could not be used before the touched HBM lines had come back.  Here: grid (strips, batch) -- no division at all --, the arguments pinned into SGPRs
+// by one batch of scalar loads, every request (rows, affine parameters, triples) issued up front, and the touches on a FIFTH wave that does nothing
+// else and leaves before the barrier (a terminated wave does not take part in s_barrier), so nobody waits for them but the kernel's end -- which the
+// four working waves reach later anyway.  Same arithmetic in the same order as k_gn_apply: bit-identical output.
+template <typename OT, int GN_PASSES, bool GN_TOUCH_WAVE>
+__global__ __launch_bounds__(GN_TOUCH_WAVE ? 320 : 256) void k_gn_apply_c1024(GnApplyParams p) {
+	constexpr int C = 1024;
+	__shared__ unsigned pf_sink[64 * 4];
+	TTK_PIN_ARGS(TTK_S(p.x), TTK_S(p.ms), TTK_S(p.gamma), TTK_S(p.beta), TTK_S(p.scale), TTK_S(p.shift), TTK_S(p.ss_stride), TTK_S(p.T), TTK_S(p.nchunks),
+				 TTK_S(p.act), TTK_S(p.out), TTK_S(p.tlen), TTK_S(p.chunk_rows), TTK_S(p.pf), TTK_S(p.pf_bytes), TTK_S(p.pf_taps));
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 0);
+	const int tid = threadIdx.x;
+	if (GN_TOUCH_WAVE && tid >= 256) {      // the touch wave: the following GEMM's weights into L2 (see GnApplyParams), then gone
+		if (p.pf) l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink)), blockIdx.y * gridDim.x + blockIdx.x,
+									gridDim.x * gridDim.y, tid - 256, 64);
+		return;
+	}
+	const int b = blockIdx.y, t0 = blockIdx.x * GN_PASSES;
+	const int Tl = p.tlen ? p.tlen[b] : p.T;                                               // ragged batch: valid rows of this sequence
+	const int nch = p.tlen ? (Tl + p.chunk_rows - 1) / p.chunk_rows : p.nchunks;           // ... and the chunk triples that describe them
+	const int c = tid * 4;
+	float4 xv[GN_PASSES];
+#pragma unroll
+	for (int i = 0; i < GN_PASSES; ++i) {
+		const int to = t0 + i;
+		xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + (to < p.T ? to : 0)) * C + c);
+	}
+	const float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
+	float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+	if (p.scale) { sc = *(const float4*)(p.scale + (int64_t)b * p.ss_stride + c); sh = *(const float4*)(p.shift + (int64_t)b * p.ss_stride + c); }
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 1);
+	float mean, rstd;
+	{   // merge: 8 lanes per group, every chunk triple requested up front, DPP sums (k_gn_apply's arithmetic).  With 4 channels per thread the 8 lanes
+		// that merge group g are exactly the 8 threads whose channels lie in it (c >> 5 == tid >> 3), and the DPP sums leave the result in all 8: no LDS
+		// hand-over, no workgroup barrier.
+		const int g = tid >> 3, sub = tid & 7;
+		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
+		float cn[8], cm[8], c2[8];
+		float nt = 0.f, wsum = 0.f;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group
+			const int k = sub + 8 * i;
+			const bool ok = k < nch;
+			const int kk = ok ? k : 0;
+			const float a0 = part[3 * kk], a1 = part[3 * kk + 1], a2 = part[3 * kk + 2];
+			cn[i] = ok ? a0 : 0.f; cm[i] = ok ? a1 : 0.f; c2[i] = ok ? a2 : 0.f;
+			nt += cn[i]; wsum += cn[i] * cm[i];
+		}
+		nt = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(nt)));
+		wsum = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(wsum)));
+		mean = wsum / nt;
+		float m2 = 0.f;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) { const float d = cm[i] - mean; m2 += c2[i] + cn[i] * d * d; }
+		m2 = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(m2)));
+		rstd = rsqrtf(m2 / nt + 1e-5f);
+	}
+	TTK_WSTAMPD(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 2, rstd);
+	// (no fifth wave: the touches leave HERE -- every load this thread waits for has been consumed, nothing below waits on vmcnt, so they cost the
+	// workgroup only their issue slots and keep it alive until they land)
+	if (!GN_TOUCH_WAVE && p.pf) l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (tid >> 6) * 64), blockIdx.y * gridDim.x + blockIdx.x,
+												   gridDim.x * gridDim.y, tid, 256);
+	const float a0 = rstd * ga.x * (1.f + sc.x), a1 = rstd * ga.y * (1.f + sc.y), a2 = rstd * ga.z * (1.f + sc.z), a3 = rstd * ga.w * (1.f + sc.w);
+	const float d0 = (be.x - mean * rstd * ga.x) * (1.f + sc.x) + sh.x, d1 = (be.y - mean * rstd * ga.y) * (1.f + sc.y) + sh.y;
+	const float d2 = (be.z - mean * rstd * ga.z) * (1.f + sc.z) + sh.z, d3 = (be.w - mean * rstd * ga.w) * (1.f + sc.w) + sh.w;
+#pragma unroll
+	for (int i = 0; i < GN_PASSES; ++i) {
+		const int to = t0 + i;
+		if (to >= p.T) continue;
+		float o0 = xv[i].x * a0 + d0, o1 = xv[i].y * a1 + d1, o2 = xv[i].z * a2 + d2, o3 = xv[i].w * a3 + d3;
+		if (p.act == ACT_SILU) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+		if (to >= Tl) { o0 = 0.f; o1 = 0.f; o2 = 0.f; o3 = 0.f; }
+		OT* dst = (OT*)p.out + ((int64_t)b * p.T + to) * C + c;
+		if (sizeof(OT) == 1) *(unsigned*)dst = pack4_fp8(o0, o1, o2, o3);
+		else if (sizeof(OT) == 2) *(uint2*)dst = pack4_16<OT>(o0, o1, o2, o3);
+		else *(float4*)dst = make_float4(o0, o1, o2, o3);
+	}
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 4);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 5);
+#endif
 }
 
 template <int PASSES>
@@ -219,6 +316,20 @@ static void launch_gn_apply_p(int dt, const GnApplyParams& p, hipStream_t s) {
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
 	ProfScope prof(PROF_GN_APPLY, (double)p.nb * p.Tout * p.C * (4.0 + (p.out_f8 ? 1.0 : p.out_f32 ? 4.0 : dtype_size(dt))), s);
 	static const int passes = [] { const char* e = getenv("TTK_GN_PASSES"); return e ? atoi(e) : 2; }();
+	static const int fast = [] { const char* e = getenv("TTK_GN_FAST"); return e ? atoi(e) : 1; }();      // 0: the generic kernel everywhere
+	if (fast && p.C == 1024 && !p.row_idx && p.Tout == p.T && passes == 2 && p.nb <= 65535) {      // the DDIM loop's launches: k_gn_apply_c1024
+		const dim3 grid((p.T + 1) / 2, p.nb);
+		// the weight touches on a fifth wave (default) or, TTK_GN_TOUCH_WAVE=0, issued by the four working waves once their own loads are consumed:
+		// 122.8 - 123.0 against 123.5 - 123.7 us per layer in tests/diag/ddim_chain (both far ahead of touches issued between the row requests and the triples)
+		static const int tw = [] { const char* e = getenv("TTK_GN_TOUCH_WAVE"); return e ? atoi(e) : 1; }();
+#define GN_GO(OT) do { if (tw) hipLaunchKernelGGL((k_gn_apply_c1024<OT, 2, true>), grid, dim3(320), 0, s, p); else hipLaunchKernelGGL((k_gn_apply_c1024<OT, 2, false>), grid, dim3(256), 0, s, p); } while (0)
+		if (p.out_f8) GN_GO(f8);
+		else if (p.out_f32 || dt == DT_F32) GN_GO(float);
+		else if (dt == DT_F16) GN_GO(f16);
+		else GN_GO(bf16);
+#undef GN_GO
+		return;
+	}
 	// few rows in all (short clips, the latent conditioner): keep the strips small so the launch still spreads over the chip
 	const int rows = p.nb * p.Tout * (p.C / 4) / 256;
 	if (passes >= 8 && rows >= 8 * 256) launch_gn_apply_p<8>(dt, p, s);

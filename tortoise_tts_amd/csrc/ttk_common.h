@@ -141,6 +141,21 @@ __device__ __forceinline__ void l2_touch_for_next(const void* base, int64_t byte
 #define TTK_PIN_ARGS(...) asm volatile("" :: __VA_ARGS__)
 #define TTK_S(x) "s"(x)
 
+// Diagnostic builds only (-DTTK_STAMPS=2, tests/diag/*_chain.cpp): every wave records 100 MHz timestamps, [linear workgroup][wave (16 slots)][8]; slot 7 of
+// stamp 0 = XCC id.  The D form takes the stamp only once `dep` (a VGPR value) is really there -- the asm reads it, so the wave stalls on the MFMA /
+// load that produces it first; a bare s_memrealtime has no data dependency and floats above the arithmetic it is meant to follow.  Expand to nothing
+// in the product build.
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+#define TTK_WSTAMP(st, wg, i) do { if ((st) && (threadIdx.x & 63) == 0) { unsigned long long* st_ = (st) + ((size_t)(wg) * 16 + (threadIdx.x >> 6)) * 8; \
+	st_[(i)] = __builtin_amdgcn_s_memrealtime(); if ((i) == 0) st_[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); } } while (0)
+#define TTK_WSTAMPD(st, wg, i, dep) do { if (st) { unsigned tmp_; unsigned long long t_; \
+	asm volatile("s_nop 7\n\tv_readfirstlane_b32 %0, %2\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tmp_), "=s"(t_) : "v"(dep) : "memory"); \
+	if ((threadIdx.x & 63) == 0) (st)[((size_t)(wg) * 16 + (threadIdx.x >> 6)) * 8 + (i)] = t_; } } while (0)
+#else
+#define TTK_WSTAMP(st, wg, i) do {} while (0)
+#define TTK_WSTAMPD(st, wg, i, dep) do {} while (0)
+#endif
+
 __device__ __forceinline__ unsigned lds_byte_addr(const void* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
 
 }  // namespace ttk

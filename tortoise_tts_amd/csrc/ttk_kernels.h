@@ -65,6 +65,9 @@ struct GemmParams {
 	// optional fused GroupNorm32 statistics of the f32 output (see gemm_fuses_gn_stats): part[b][32][gn_T / 64][3]
 	float* gn_part; int gn_T;
 	int m_major;        // XCD-aware tile order: 0 = each XCD gets a few n-tiles x all m-tiles (its L2 keeps a weight slice), 1 = a few m-tiles x all n-tiles
+#ifdef TTK_STAMPS
+	unsigned long long* stamps;   // diagnostic build only
+#endif
 };
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s);
 // true when launch_gemm(M, N) picks a 128-row tile, i.e. each wave owns 64 rows x one or two whole 32-channel groups and can emit
@@ -163,6 +166,9 @@ struct GnApplyParams {
 	// blocks of `pf_bytes` each; block bytes are split into 8 equal slices, slice x = the n-range the GEMM's tile order gives XCD x, and
 	// the workgroups on XCD x (blockIdx % 8) touch one 128-byte line per thread of their share of slice x.
 	const void* pf; int64_t pf_bytes; int pf_taps;
+#ifdef TTK_STAMPS
+	unsigned long long* stamps;   // diagnostic build only
+#endif
 };
 void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s);
 
@@ -178,6 +184,9 @@ struct AttnParams {
 	const float* bias;                    // [H][129] relative-position bias (already scaled) or null
 	float scale;                          // multiplies q.k
 	const void* pf; int64_t pf_bytes; int pf_taps;   // optional L2 touch of the following GEMM's weights (see GnApplyParams)
+#ifdef TTK_STAMPS
+	unsigned long long* stamps;   // diagnostic build only
+#endif
 };
 void launch_attn_fwd(int dt, const AttnParams& p, hipStream_t s);
 
