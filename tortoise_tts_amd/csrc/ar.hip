@@ -317,13 +317,16 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	if (hipMemset(h->d_pos, 0, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
-	AR_TRY(h->arena.alloc(&h->attn_out, (size_t)round_up(cfg->max_batch, 16) * d * h->es));
-	if (hipMemset(h->attn_out, 0, (size_t)round_up(cfg->max_batch, 16) * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
-	// 16-row tiles: the decode path keeps the MLP activations in fragment order, whose padding rows must exist and hold zeros
-	AR_TRY(h->arena.alloc(&h->hbuf, (size_t)round_up(cfg->max_batch, 16) * 4 * d * h->es));
-	if (hipMemset(h->hbuf, 0, (size_t)round_up(cfg->max_batch, 16) * 4 * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
-	AR_TRY(h->arena.alloc(&h->x_frag, (size_t)round_up(cfg->max_batch, 16) * d * h->es));
-	if (hipMemset(h->x_frag, 0, (size_t)round_up(cfg->max_batch, 16) * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
+	// Fragment-order operands of the decode launches, [m_tile][k-step][lane]: the kernels are instantiated for 1, 2 or 4 sixteen-row tiles (csrc/gemv.hip:
+	// gemv_mt) and request EVERY tile of their instantiation, so 33..48 rows read a fourth tile: it must exist (each buffer is its own allocation; a
+	// read past its end is a fault whenever the driver has not mapped anything behind it) and hold zeros, like the padding rows inside a tile.
+	const size_t frag_rows = cfg->max_batch <= 16 ? 16 : (cfg->max_batch <= 32 ? 32 : 64);
+	AR_TRY(h->arena.alloc(&h->attn_out, frag_rows * d * h->es));
+	if (hipMemset(h->attn_out, 0, frag_rows * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
+	AR_TRY(h->arena.alloc(&h->hbuf, frag_rows * 4 * d * h->es));
+	if (hipMemset(h->hbuf, 0, frag_rows * 4 * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
+	AR_TRY(h->arena.alloc(&h->x_frag, frag_rows * d * h->es));
+	if (hipMemset(h->x_frag, 0, frag_rows * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->slab, (size_t)4 * (d / 16) * 4 * 4 * 256 * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)4 * (d / 16) * sizeof(int)));
 	if (hipMemset(h->tickets, 0, (size_t)4 * (d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);

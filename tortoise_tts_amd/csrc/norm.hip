@@ -318,11 +318,15 @@ void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
 	static const int passes = [] { const char* e = getenv("TTK_GN_PASSES"); return e ? atoi(e) : 2; }();
 	static const int fast = [] { const char* e = getenv("TTK_GN_FAST"); return e ? atoi(e) : 1; }();      // 0: the generic kernel everywhere
 	if (fast && p.C == 1024 && !p.row_idx && p.Tout == p.T && passes == 2 && p.nb <= 65535) {      // the DDIM loop's launches: k_gn_apply_c1024
-		const dim3 grid((p.T + 1) / 2, p.nb);
+		// rows per thread: with 2 the 1088 five-wave workgroups of a DDIM step do not fit the chip at once (two waves of each land on one SIMD: 4 per CU, 1024 slots) and
+		// the last 64 start 3 us late; with 4 all 544 are resident within 0.5 us (tests/diag/ddim_chain: 4.5 / 5.1 / 5.2 -> 4.2 / 4.7 / 4.8 us per launch)
+		static const int cp = [] { const char* e = getenv("TTK_GN_C1024_PASSES"); return e && atoi(e) == 2 ? 2 : 4; }();
+		const dim3 grid((p.T + cp - 1) / cp, p.nb);
 		// the weight touches on a fifth wave (default) or, TTK_GN_TOUCH_WAVE=0, issued by the four working waves once their own loads are consumed:
 		// 122.8 - 123.0 against 123.5 - 123.7 us per layer in tests/diag/ddim_chain (both far ahead of touches issued between the row requests and the triples)
 		static const int tw = [] { const char* e = getenv("TTK_GN_TOUCH_WAVE"); return e ? atoi(e) : 1; }();
-#define GN_GO(OT) do { if (tw) hipLaunchKernelGGL((k_gn_apply_c1024<OT, 2, true>), grid, dim3(320), 0, s, p); else hipLaunchKernelGGL((k_gn_apply_c1024<OT, 2, false>), grid, dim3(256), 0, s, p); } while (0)
+#define GN_GO(OT) do { if (cp == 4) { if (tw) hipLaunchKernelGGL((k_gn_apply_c1024<OT, 4, true>), grid, dim3(320), 0, s, p); else hipLaunchKernelGGL((k_gn_apply_c1024<OT, 4, false>), grid, dim3(256), 0, s, p); } \
+	else if (tw) hipLaunchKernelGGL((k_gn_apply_c1024<OT, 2, true>), grid, dim3(320), 0, s, p); else hipLaunchKernelGGL((k_gn_apply_c1024<OT, 2, false>), grid, dim3(256), 0, s, p); } while (0)
 		if (p.out_f8) GN_GO(f8);
 		else if (p.out_f32 || dt == DT_F32) GN_GO(float);
 		else if (dt == DT_F16) GN_GO(f16);
