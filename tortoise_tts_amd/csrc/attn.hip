@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	__shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
 	__shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
 	__shared__ float bias_s[132];
+	__shared__ float band_s[BIAS ? 288 : 4];   // the bias as a function of key - query over [-144, 144), saturation included: band tiles index it without clamps
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int h = blockIdx.y, b = blockIdx.z;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	}
 	if (BIAS) {
 		if (tid < 129) bias_s[tid] = p.bias[h * 129 + tid] * LOG2E;   // scores live in the log2 domain (exp2 = one v_exp_f32)
+		for (int i = tid; i < 288; i += 64 * NWV) { const int rel = i - 144; band_s[i] = p.bias[h * 129 + (rel < -64 ? -64 : (rel > 64 ? 64 : rel)) + 64] * LOG2E; }
 	}
 
 	// Q fragments (B operand of S^T = K Q^T): lane holds Q[q][32ks + 8g .. +8], scaled.  Four named values (an indexed
@@ -222,7 +224,21 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 				const float cbias = BIAS ? (k0 > qa ? bias_s[128] : bias_s[0]) : 0.f;
 				const bool slow = edge || diag || near_band;
 				float tmax = NEG_BIG;
-				if (slow) {   // per-element bias lookup and masks; scores become log2-domain values in place
+				if (BIAS && near_band && !edge && !diag) {
+					// a tile inside the bias band with nothing to mask (3 - 4 of the 17 key tiles at T = 1088): the same values as the general path below --
+					// bias from the table, one fma -- without its per-element clamps and compares (~80 of its ~110 VALU instructions per tile; the SQ
+					// counters put this kernel's critical SIMD 60 % in VALU issue, profiles/r03_pmc_attn.txt): key - query indexes the saturated table
+					// directly, the 16 offsets of a lane are immediates
+					const float* bt = band_s + (k0 - qi + 4 * g + 144);
+#pragma unroll
+					for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							const float v = fmaf(s[qt][nt][r], LOG2E, bt[16 * nt + r]);
+							s[qt][nt][r] = v;
+							tmax = fmaxf(tmax, v);
+						}
+				} else if (slow) {   // per-element bias lookup and masks; scores become log2-domain values in place
 #pragma unroll
 					for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
