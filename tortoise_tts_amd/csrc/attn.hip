@@ -153,11 +153,24 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	// staging registers as named scalars (indexed arrays captured by the lambdas were placed in scratch memory)
 	uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
 	rk1 = rv1 = rk2 = rk3 = rv2 = rv3 = make_uint4(0, 0, 0, 0);
+	// a thread's chunk of a tile: its address inside tile 0 once (row * ld is a 64-bit multiply: three quarter-rate instructions), then one wave-uniform
+	// offset per tile; only a last, partly valid tile takes the per-row clamp
+	auto thr_ptr = [&](int i) -> const T* { const int id = tid + NTH * i; return base + (int64_t)(id / NCH) * p.ld + (id % NCH) * (16 / ES); };
+	const T* const sp0 = thr_ptr(0);
+	const T* const sp1 = thr_ptr(CPT > 1 ? 1 : 0);
+	const T* const sp2 = thr_ptr(CPT > 2 ? 2 : 0);
+	const T* const sp3 = thr_ptr(CPT > 2 ? 3 : 0);
+	const int64_t tile_step = (int64_t)64 * p.ld;
 	auto ld1 = [&](int kt, int i, uint4& k, uint4& v) {
-		const int id = tid + NTH * i, row = id / NCH, c = id % NCH;
-		int key = kt * 64 + row;
-		key = key < TL ? key : TL - 1;
-		const T* src = base + (int64_t)key * p.ld + c * (16 / ES);
+		const T* src;
+		if (kt * 64 + 64 <= TL) {
+			src = (i == 0 ? sp0 : (i == 1 ? sp1 : (i == 2 ? sp2 : sp3))) + kt * tile_step;
+		} else {
+			const int id = tid + NTH * i, row = id / NCH, c = id % NCH;
+			int key = kt * 64 + row;
+			key = key < TL ? key : TL - 1;
+			src = base + (int64_t)key * p.ld + c * (16 / ES);
+		}
 		k = *(const uint4*)(src + kc);
 		v = *(const uint4*)(src + vc);
 	};
@@ -258,8 +271,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 						for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s[qt][nt][r]);
 					tmax = fmaf(tmax, LOG2E, cbias);
 				}
-				tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-				tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+				tmax = fold32_max(fold16_max(tmax));      // (4 VALU instructions; two __shfl_xor cost 22 and two LDS round trips)
 				// deferred rescale (cdna_hip_programming.md T13): keep the running max unless this tile exceeds it by more than 2^8;
 				// P then stays <= 256, exact enough in bf16 (same relative precision) with f32 accumulation.  Everything at the old
 				// scale (O, l) is multiplied exactly once, before any P of this tile exists.
@@ -273,6 +285,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 				}
 				const float mq = m_run[qt];
 				float psum = 0.f;
+				// (v_pk_fma_f32 / v_pk_add_f32 for the arguments and the row sum -- 8 fewer VALU instructions per tile -- measured SLOWER, 25.1 against 24.2 us per
+				// launch on one box: packed f32 operations cost more than the two scalar ones they replace beside MFMAs, MI355X_MICROARCH.md constants table)
 				if (slow) {
 #pragma unroll
 					for (int nt = 0; nt < 4; ++nt)
@@ -317,8 +331,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 #pragma unroll
 	for (int qt = 0; qt < QT; ++qt) {
 		float l = l_run[qt];
-		l += __shfl_xor(l, 16);
-		l += __shfl_xor(l, 32);
+		l = fold32_add(fold16_add(l));
 		const float inv = 1.0f / l;
 		const int qi = q0 + 16 * qt + li;
 		if (qi < TL && (!BAL || wave < cnt)) {

@@ -328,8 +328,8 @@ __global__ __launch_bounds__(LN ? 512 : 1024) void k_skinny(SkinnyParams p) {
 	if (FOLD) {   // the four lanes of a row (k-groups) -> every one holds the wave's partial; lane group 0 publishes it
 #pragma unroll
 		for (int mt = 0; mt < MT; ++mt) {
-			fs1[mt] += __shfl_xor(fs1[mt], 16); fs2[mt] += __shfl_xor(fs2[mt], 16);
-			fs1[mt] += __shfl_xor(fs1[mt], 32); fs2[mt] += __shfl_xor(fs2[mt], 32);
+			fs1[mt] = fold16_add(fs1[mt]); fs2[mt] = fold16_add(fs2[mt]);
+			fs1[mt] = fold32_add(fs1[mt]); fs2[mt] = fold32_add(fs2[mt]);
 			if (lane < 16) *(float2*)(rstat + ((wave * MT + mt) * 16 + lane) * 2) = make_float2(fs1[mt], fs2[mt]);
 		}
 	}

@@ -93,6 +93,30 @@ __device__ __forceinline__ float wave_sum(float v) {
 	const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
 	return (r0 + r1) + (r2 + r3);
 }
+// Folds over lane bit 4 / bit 5 (pairs {lane, lane ^ 16} / {lane, lane ^ 32}) for commutative operations without ds_bpermute's address arithmetic (8 VALU
+// instructions per __shfl_xor) and LDS round trip: v_permlane16_swap / v_permlane32_swap (gfx950) of a register with a copy of itself leave the pair's two
+// values in two registers of every lane.  Same operands as `op(v, __shfl_xor(v, 16 | 32))`, so the same bits.
+__device__ __forceinline__ float fmax_raw(float a, float b) {   // v_max_f32 without fmaxf's canonicalising v_max x, x in front (operands here are never sNaN)
+	float r;
+	asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ float fold16_max(float v) {
+	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+	return fmax_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float fold32_max(float v) {
+	const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+	return fmax_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float fold16_add(float v) {
+	const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold32_add(float v) {
+	const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+	return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
