@@ -14,40 +14,55 @@ namespace ttk {
 
 // one wave per row; d <= 4096
 // frag != 0: `out` is written in the MFMA A-fragment order of the skinny decode GEMV ([m_tile][d/32][lane][8], skinny.hip) instead of row-major
-template <typename OT>
+// NI = float4 slots per lane (d <= 256 * NI).  NI = 4 (d <= 1024: the decode step's ln_f + final_norm launch, one per token): the affine parameters of BOTH
+// norms are requested together with the row -- loaded where they are used they were two more dependent round trips behind the reductions (7.3 us per
+// launch in the kernel trace for 16 rows); NI = 16 keeps them at their use (64 float4 of parameters per lane would not fit the register file).
+template <typename OT, int NI>
 __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
 							const float* g2, const float* b2, OT* out, int64_t ldo, int frag, float* out2, const int64_t* out2_idx, int64_t out2_stride) {
+	constexpr bool HOIST = NI <= 4;
 	const int lane = threadIdx.x & 63;
 	const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (row >= rows) return;
 	if (out2 && out2_idx) out2 += out2_idx[0] * out2_stride;      // slot of a ring the caller advances on the device (ttk_ar_set_hidden_ring)
 	const int nchunk = d / 4;
-	float4 v[16];
+	float4 v[NI];
+	float4 pg[HOIST ? 2 : 1][HOIST ? NI : 1], pb[HOIST ? 2 : 1][HOIST ? NI : 1];
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
+	for (int i = 0; i < NI; ++i) {
 		const int c = lane + 64 * i;
 		v[i] = c < nchunk ? *(const float4*)(x + (int64_t)row * ldx + 4 * c) : make_float4(0, 0, 0, 0);
 	}
-	for (int pass = 0; pass < (g2 ? 2 : 1); ++pass) {
+	if (HOIST) {
+#pragma unroll
+		for (int i = 0; i < (HOIST ? NI : 0); ++i) {
+			const int c = lane + 64 * i < nchunk ? lane + 64 * i : 0;
+			pg[0][i] = *(const float4*)(g1 + 4 * c); pb[0][i] = *(const float4*)(b1 + 4 * c);
+			if (g2) { pg[HOIST ? 1 : 0][i] = *(const float4*)(g2 + 4 * c); pb[HOIST ? 1 : 0][i] = *(const float4*)(b2 + 4 * c); }
+		}
+	}
+#pragma unroll
+	for (int pass = 0; pass < 2; ++pass) {
+		if (pass == 1 && !g2) break;
 		const float* g = pass ? g2 : g1;
 		const float* b = pass ? b2 : b1;
 		float sum = 0.f;
 #pragma unroll
-		for (int i = 0; i < 16; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
+		for (int i = 0; i < NI; ++i) sum += v[i].x + v[i].y + v[i].z + v[i].w;
 		const float mean = wave_sum(sum) / (float)d;
 		float sq = 0.f;
 #pragma unroll
-		for (int i = 0; i < 16; ++i)
+		for (int i = 0; i < NI; ++i)
 			if (lane + 64 * i < nchunk) {
 				const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
 				sq += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
 			}
 		const float rstd = rsqrtf(wave_sum(sq) / (float)d + 1e-5f);
 #pragma unroll
-		for (int i = 0; i < 16; ++i) {
+		for (int i = 0; i < NI; ++i) {
 			const int c = lane + 64 * i;
 			if (c < nchunk) {
-				const float4 gg = *(const float4*)(g + 4 * c), bb = *(const float4*)(b + 4 * c);
+				const float4 gg = HOIST ? pg[HOIST ? pass : 0][HOIST ? i : 0] : *(const float4*)(g + 4 * c), bb = HOIST ? pb[HOIST ? pass : 0][HOIST ? i : 0] : *(const float4*)(b + 4 * c);
 				v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
 				v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
 				v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
@@ -56,7 +71,7 @@ __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const 
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
+	for (int i = 0; i < NI; ++i) {
 		const int c = lane + 64 * i;
 		if (c < nchunk) {
 			const int n = 4 * c;
@@ -72,12 +87,11 @@ void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, cons
 					  const int64_t* out2_idx, int64_t out2_stride) {
 	ProfScope prof(PROF_LAYERNORM, (double)rows * d * (4.0 + (out_f32 ? 4.0 : dtype_size(dt))), s);
 	const int grid = (rows + 3) / 4;
-	if (out_f32 || dt == DT_F32)
-		hipLaunchKernelGGL((k_layernorm<float>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (float*)out, ldo, frag, out2, out2_idx, out2_stride);
-	else if (dt == DT_F16)
-		hipLaunchKernelGGL((k_layernorm<f16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (f16*)out, ldo, frag, out2, out2_idx, out2_stride);
-	else
-		hipLaunchKernelGGL((k_layernorm<bf16>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (bf16*)out, ldo, frag, out2, out2_idx, out2_stride);
+#define LN_GO(OT, NI) hipLaunchKernelGGL((k_layernorm<OT, NI>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (OT*)out, ldo, frag, out2, out2_idx, out2_stride)
+	if (out_f32 || dt == DT_F32) { if (d <= 1024) LN_GO(float, 4); else LN_GO(float, 16); }
+	else if (dt == DT_F16) { if (d <= 1024) LN_GO(f16, 4); else LN_GO(f16, 16); }
+	else { if (d <= 1024) LN_GO(bf16, 4); else LN_GO(bf16, 16); }
+#undef LN_GO
 }
 
 // ---------------------------------------------------------------- GroupNorm32
