@@ -43,8 +43,10 @@ struct ttk_diff {
 	Lane lane[2];
 	Lane* L = &lane[0];      // the lane the block helpers below enqueue into (host code is sequential: flipped around the side-stream work)
 	WsBuf cs, cs2, xs, h0, csT, xcl, outb, ecl, ms_ecl, temb, e1, e2, se, emb_all, lat_T;
+	WsBuf hf0, ms_hf0;      // in_layers of the FIRST integrator ResBlock applied to the staged embedding (+ the GroupNorm statistics of the result): the same in every step
 	hipStream_t side = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_int[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+	int hf0_valid = 0;      // hf0 / ms_hf0 hold the staged embedding's first half-block (TTK_DIFF_HOIST=0: recomputed in every step, as before round 3)
 	int pipe = 1;           // ttk_diff_sample_ddim overlaps step i+1's integrator with step i's body (TTK_DIFF_PIPE=0: sequential)
 	int cur_b = 0, cur_T = 0, staged = 0;
 	int fuse_stats = 1;
@@ -123,14 +125,18 @@ static void attn_block(ttk_diff* h, const AttnBlk& A, float* x, int nb, int T, h
 // x = x + conv3(SiLU(GN(conv1(SiLU(GN(x)))) * (1 + scale) + shift))        diffusion.py:1363-1376
 // x_in (with its precomputed GroupNorm statistics ms_in): the block reads its input there and writes x -- the first integrator block of a
 // sampler step reads the staged code embedding directly instead of a per-step copy of it
+// hf_pre / ms_hf_pre: in_layers(x_in) and its statistics computed beforehand (ttk_diff_begin: the timestep enters a ResBlock only behind them, as
+// the scale / shift of the second GroupNorm) -- the block then starts at its second half
 static void res_block(ttk_diff* h, const ResBlk& R, float* x, int nb, int T, const float* emb_all, int64_t emb_stride, hipStream_t s,
-					  const float* x_in = nullptr, const float* ms_in = nullptr) {
+					  const float* x_in = nullptr, const float* ms_in = nullptr, const float* hf_pre = nullptr, const float* ms_hf_pre = nullptr) {
 	const int C = h->cfg.model_channels, rows = nb * T;
 	const float* src = x_in ? x_in : x;
-	gn(h, src, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->L->a.p, 0, nullptr, T, s, &R.in, ms_in);
-	gemm1(h, h->L->a.p, C, R.in, rows, h->L->hf.p, C, 1, ACT_NONE, nullptr, s, T);
+	if (!hf_pre) {
+		gn(h, src, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->L->a.p, 0, nullptr, T, s, &R.in, ms_in);
+		gemm1(h, h->L->a.p, C, R.in, rows, h->L->hf.p, C, 1, ACT_NONE, nullptr, s, T);
+	}
 	const float* sc = emb_all + (int64_t)R.emb_slot * 2 * C;
-	gn(h, (const float*)h->L->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->L->a.p, 0, nullptr, T, s, &R.out3);
+	gn(h, hf_pre ? hf_pre : (const float*)h->L->hf.p, nb, T, R.gn2_g, R.gn2_b, sc, sc + C, emb_stride, ACT_SILU, h->L->a.p, 0, nullptr, T, s, &R.out3, ms_hf_pre);
 	gemm_conv3(h, h->L->a.p, C, R.out3, rows, T, x, C, 1, src, 0, s, T);
 }
 
@@ -172,7 +178,9 @@ static int time_path(ttk_diff* h, const int64_t* t_dev, const int64_t* t_host, i
 static void integrator(ttk_diff* h, int nb, int T, const float* emb_all, int64_t emb_stride, float* cs, hipStream_t s,
 					   const float* cs_in = nullptr, const float* ms_in = nullptr) {
 	for (int i = 0; i < 3; ++i) {
-		res_block(h, h->integrator[i].res, cs, nb, T, emb_all, emb_stride, s, i == 0 ? cs_in : nullptr, i == 0 ? ms_in : nullptr);
+		const bool pre = i == 0 && cs_in && h->hf0_valid;
+		res_block(h, h->integrator[i].res, cs, nb, T, emb_all, emb_stride, s, i == 0 ? cs_in : nullptr, i == 0 ? ms_in : nullptr,
+				  pre ? (const float*)h->hf0.p : nullptr, pre ? (const float*)h->ms_hf0.p : nullptr);
 		attn_block(h, h->integrator[i].attn, cs, nb, T, s);
 	}
 }
@@ -295,7 +303,7 @@ int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight
 int ttk_diff_destroy(ttk_diff* h) {
 	if (!h) return TTK_OK;
 	(void)hipDeviceSynchronize();
-	WsBuf* all[] = {&h->cs, &h->cs2, &h->xs, &h->h0, &h->csT, &h->xcl, &h->outb, &h->ecl, &h->temb, &h->e1, &h->e2, &h->se, &h->emb_all, &h->lat_T, &h->ms_ecl};
+	WsBuf* all[] = {&h->cs, &h->cs2, &h->xs, &h->h0, &h->csT, &h->xcl, &h->outb, &h->ecl, &h->temb, &h->e1, &h->e2, &h->se, &h->emb_all, &h->lat_T, &h->ms_ecl, &h->hf0, &h->ms_hf0};
 	for (WsBuf* b : all) b->release();
 	for (Lane& L : h->lane) { L.a.release(); L.hf.release(); L.qkv.release(); L.ao.release(); L.ms.release(); }
 	if (h->side) (void)hipStreamDestroy(h->side);
@@ -354,6 +362,26 @@ int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream) {
 	TTK_TRY(h->ms_ecl.reserve((size_t)2 * b * 32 * gn_num_chunks(T, C) * 3 * 4));
 	launch_gn_stats(ecl, 2 * b, T, C, (float*)h->ms_ecl.p, s, h->tlen);
 	h->cur_b = b; h->cur_T = T; h->staged = 1;
+	// ... and so is the first half of the first integrator ResBlock on it, conv1x1(SiLU(GN(ecl))), with the statistics its second GroupNorm needs: the
+	// same launches a step would run (so the same bits), once per utterance instead of once per step
+	static const int hoist = [] { const char* e = getenv("TTK_DIFF_HOIST"); return e ? atoi(e) : 1; }();
+	h->hf0_valid = 0;
+	if (hoist) {
+		const int nb = 2 * b, nch = gn_num_chunks(T, C);
+		const size_t ms_bytes = (size_t)nb * 32 * nch * 3 * 4;
+		TTK_TRY(h->hf0.reserve((size_t)nb * T * C * 4)); TTK_TRY(h->ms_hf0.reserve(ms_bytes));
+		const ResBlk& R = h->integrator[0].res;
+		gn(h, ecl, nb, T, R.gn1_g, R.gn1_b, nullptr, nullptr, 0, ACT_SILU, h->L->a.p, 0, nullptr, T, s, &R.in, (const float*)h->ms_ecl.p);
+		gemm1(h, h->L->a.p, C, R.in, nb * T, h->hf0.p, C, 1, ACT_NONE, nullptr, s, T);
+		if (h->L->ms_owner == (const void*)h->hf0.p) {      // statistics left by the GEMM's epilogue (gn() would take them from there) ...
+			TTK_HIP(hipMemcpyAsync(h->ms_hf0.p, h->L->ms.p, ms_bytes, hipMemcpyDeviceToDevice, s));
+			if (h->need) launch_gn_stats((const float*)h->hf0.p, nb, T, C, (float*)h->ms_hf0.p, s, h->tlen, h->need);   // ... except for the ragged sequences of a batch
+		} else {
+			launch_gn_stats((const float*)h->hf0.p, nb, T, C, (float*)h->ms_hf0.p, s, h->tlen);
+		}
+		h->L->ms_owner = nullptr;
+		h->hf0_valid = 1;
+	}
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }
