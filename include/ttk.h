@@ -103,8 +103,10 @@ int ttk_ar_health(ttk_ar* h, int* flags_out, void* stream);
  * also writes final_norm(ln_f(h)) [B, D] f32 of its new rows to base + index[0] * stride (elements), `index` a device int64 the sampling launch
  * advances (the `col` of ttk_sample_args: tokens sampled so far), so step n's rows land in slot n of a [slots, B, D] buffer although the
  * captured launch arguments never change -- what the streaming generator (unified_voice.py:670-679, stream_generator.py:1172) yields next to
- * token n.  Pass base = NULL to switch it off.  Needs the default decode form (TTK_AR_HEAD_SPLIT=1, TTK_AR_SPLIT=1).                       */
-int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t stride);
+ * token n.  The base is uploaded to a device word on `stream` and read from there by the launches, so a token step captured during one
+ * generation writes into the buffer of whichever generation replays it.  Pass base = NULL to switch it off.  Needs the default decode form
+ * (TTK_AR_HEAD_SPLIT=1, TTK_AR_SPLIT=1).                                                                                                 */
+int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t stride, void* stream);
 
 /* One sampled token per candidate, the body of HF `_sample` that stream_generator.py drives (warpers :56-101; HF:generation/
  * utils.py:2894-2937): probs = softmax(scores / temperature); next = multinomial(probs, 1) = argmax(probs / q) with q the caller's

@@ -145,6 +145,27 @@ def test_streaming_generator_is_the_sampling_loop_token_by_token(small_ar):
 	assert torch.equal(again, want)
 
 
+def test_streaming_generator_twice_on_one_model_keeps_both_latent_sets(small_ar):
+	"""two streamed generations of the same shape on one model: the second replays the token step captured by the first, and must write ITS latents into
+	ITS buffer -- the first call's yielded latents stay what they were (the base of the latent buffer reaches the captured launch through device memory,
+	not as an argument frozen at capture)"""
+	model, _ = small_ar
+	text = torch.randint(1, 255, (1, 9), generator=gen(60)).to(DEV)
+	kw = dict(temperature=0.9, top_k=0, do_sample=True, num_return_sequences=4)
+	runs = []
+	for seed in (61, 62, 62):
+		cond = torch.randn(1, 128, generator=gen(seed)).to(DEV)
+		ids = model.compute_embeddings(cond, text)
+		out = list(model.get_generator(inputs=ids, max_length=ids.shape[1] + 12, **kw))
+		torch.cuda.synchronize()
+		runs.append((out, torch.stack([l for _, l in out], 0).clone(), torch.stack([t for t, _ in out], 1).clone()))
+	(out_a, lat_a, _), (out_b, lat_b, tok_b), (out_c, lat_c, tok_c) = runs
+	assert torch.isfinite(lat_b).all() and torch.equal(tok_b, tok_c) and torch.equal(lat_b, lat_c)           # same call twice: same tokens, same latents
+	assert not torch.equal(lat_a, lat_b)                                                                   # (a different voice gives different latents)
+	assert torch.equal(torch.stack([l for _, l in out_a], 0), lat_a)                                       # the first call's views were not written by the later ones
+	assert torch.equal(torch.stack([l for _, l in out_b], 0), lat_b)
+
+
 @pytest.mark.parametrize("b,M,T", [(1, 1, 4), (2, 7, 30), (1, 40, 174), (3, 70, 129)])
 def test_diffusion_odd_lengths(small_diff, b, M, T):
 	"""Frame counts that straddle the 64-key attention tiles and the 128-row GEMM tiles; nearest-neighbour expansion M -> T."""

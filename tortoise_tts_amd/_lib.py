@@ -74,7 +74,7 @@ SYMBOLS = {
 	"ttk_ar_decode": (_I, [_P, _P, _P, _P, _P]),
 	"ttk_ar_decode_next": (_I, [_P, _P, _P, _P]),
 	"ttk_ar_last_hidden": (_I, [_P, _P, _P]),
-	"ttk_ar_set_hidden_ring": (_I, [_P, _P, _P, _L]),
+	"ttk_ar_set_hidden_ring": (_I, [_P, _P, _P, _L, _P]),
 	"ttk_ar_health": (_I, [_P, C.POINTER(C.c_int), _P]),
 	"ttk_ar_set_noise": (_I, [_P, _P, _P, _P]),
 	"ttk_ar_prefill_lines": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),

@@ -465,7 +465,7 @@ class UnifiedVoice:
 			try:
 				st.logits.copy_(self._prefill(cond, text, B))
 				_lib.check(self.lib.ttk_ar_last_hidden(self._h, hid[0].data_ptr(), _lib.stream_ptr()), "ttk_ar_last_hidden")
-				_lib.check(self.lib.ttk_ar_set_hidden_ring(self._h, hid.data_ptr(), st.col.data_ptr(), B * c.model_dim), "ttk_ar_set_hidden_ring")
+				_lib.check(self.lib.ttk_ar_set_hidden_ring(self._h, hid.data_ptr(), st.col.data_ptr(), B * c.model_dim, _lib.stream_ptr()), "ttk_ar_set_hidden_ring")
 				events, produced = [], 0
 				while True:
 					while produced < min(max_new, n_done + 1 + LAG):       # tokens n_done .. n_done + LAG sampled or in flight
@@ -507,7 +507,7 @@ class UnifiedVoice:
 					if n_done >= max_new or (end and end <= n_done):
 						return
 			finally:
-				_lib.check(self.lib.ttk_ar_set_hidden_ring(self._h, None, None, 0), "ttk_ar_set_hidden_ring")
+				_lib.check(self.lib.ttk_ar_set_hidden_ring(self._h, None, None, 0, _lib.stream_ptr()), "ttk_ar_set_hidden_ring")
 				if st.own_rng:
 					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
 					# the generator where the reference's loop leaves it: one draw per token it produced (steps sampled ahead of an early end drew nothing

@@ -96,6 +96,7 @@ struct ttk_ar {
 	const int64_t* rng_args = nullptr; const int64_t* rng_draws = nullptr; float* rng_q = nullptr;
 	int* d_health = nullptr;  // GemvParams.health of the folded launches (ttk_ar_health reads and clears it)
 	float* ring_base = nullptr; const int64_t* ring_idx = nullptr; int64_t ring_stride = 0;      // ttk_ar_set_hidden_ring
+	int64_t* d_ring = nullptr;                                                                 // device word holding ring_base: what the (possibly captured) launch reads
 	int head_split = 1;     // decode head as LayerNorm launch + plain GEMV (TTK_AR_HEAD_SPLIT=0: norms inside the GEMV)
 	int lnfold = 1;         // ln_1 + c_attn and ln_2 + c_fc of the decode step with the LayerNorm folded into the matrix (TTK_AR_LNFOLD=0: LN prologue)
 	int lean = 1;           // decode launches on the compile-time-specialised kernels of gemv.hip where one exists (TTK_AR_LEAN=0: k_skinny everywhere)
@@ -246,7 +247,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 	if (h->head_split && whole) {
 		// ln_f + final_norm ONCE (4 workgroups), the mel head as a plain 513-tile GEMV over the normalised rows in fragment order: with the
 		// norms inside the GEMV every one of the 513 workgroups normalised all 16 rows, two passes each -- 17 us for 16.8 MB of weights
-		if (h->ring_base && !hid) launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, h->ring_base, h->ring_idx, h->ring_stride);
+		if (h->ring_base && !hid) launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, nullptr, h->ring_idx, h->ring_stride, h->d_ring);
 		else launch_layernorm(dt, x, d, nrows, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b, h->attn_out, d, 0, s, 1, hid);
 		p.a = h->attn_out; p.lda = d; p.a_frag = 1;
 		GemvParams gh = {};
@@ -315,6 +316,8 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	h->d_rowinfo = (int2*)(h->d_pos + 4);
 	h->d_health = h->d_pos + 2;      // (words 2, 3 of the block are otherwise unused; zeroed with it below)
 	if (hipMemset(h->d_pos, 0, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
+	AR_TRY(h->arena.alloc((void**)&h->d_ring, sizeof(int64_t)));
+	if (hipMemset(h->d_ring, 0, sizeof(int64_t)) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
 	AR_TRY(h->arena.alloc((void**)&h->qbuf, (size_t)cfg->max_batch * d * sizeof(float)));
 	// Fragment-order operands of the decode launches, [m_tile][k-step][lane]: the kernels are instantiated for 1, 2 or 4 sixteen-row tiles (csrc/gemv.hip:
@@ -517,10 +520,14 @@ int ttk_ar_set_noise(ttk_ar* h, const int64_t* rng_args, const int64_t* draws, f
 	return TTK_OK;
 }
 
-int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t stride) {
+int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t stride, void* stream) {
 	TTK_REQUIRE(h, TTK_E_ARG, "ttk_ar_set_hidden_ring: null handle");
 	TTK_REQUIRE(!base || (index && stride >= 0), TTK_E_ARG, "ttk_ar_set_hidden_ring: a ring needs its device index and a stride");
 	h->ring_base = base; h->ring_idx = base ? index : nullptr; h->ring_stride = base ? stride : 0;
+	if (base) {      // the launches read the base from device memory (a captured step is replayed by later generations with their own buffers): stream-ordered upload
+		const int64_t v = (int64_t)(uintptr_t)base;
+		TTK_HIP(hipMemcpyAsync(h->d_ring, &v, sizeof(v), hipMemcpyHostToDevice, (hipStream_t)stream));
+	}
 	return TTK_OK;
 }
 

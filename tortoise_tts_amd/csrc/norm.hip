@@ -19,12 +19,15 @@ namespace ttk {
 // launch in the kernel trace for 16 rows); NI = 16 keeps them at their use (64 float4 of parameters per lane would not fit the register file).
 template <typename OT, int NI>
 __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
-							const float* g2, const float* b2, OT* out, int64_t ldo, int frag, float* out2, const int64_t* out2_idx, int64_t out2_stride) {
+							const float* g2, const float* b2, OT* out, int64_t ldo, int frag, float* out2, const int64_t* out2_idx, int64_t out2_stride, const int64_t* out2_base) {
 	constexpr bool HOIST = NI <= 4;
 	const int lane = threadIdx.x & 63;
 	const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (row >= rows) return;
-	if (out2 && out2_idx) out2 += out2_idx[0] * out2_stride;      // slot of a ring the caller advances on the device (ttk_ar_set_hidden_ring)
+	// slot of a ring the caller advances on the device (ttk_ar_set_hidden_ring); the ring's BASE comes through device memory as well: a captured launch
+	// must serve the buffer of whichever generation replays it, not the one it was captured in
+	if (out2_base) out2 = (float*)(uintptr_t)out2_base[0];
+	if (out2 && out2_idx) out2 += out2_idx[0] * out2_stride;
 	const int nchunk = d / 4;
 	float4 v[NI];
 	float4 pg[HOIST ? 2 : 1][HOIST ? NI : 1], pb[HOIST ? 2 : 1][HOIST ? NI : 1];
@@ -84,10 +87,10 @@ __global__ void k_layernorm(const float* x, int64_t ldx, int rows, int d, const 
 
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
 					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s, int frag, float* out2,
-					  const int64_t* out2_idx, int64_t out2_stride) {
+					  const int64_t* out2_idx, int64_t out2_stride, const int64_t* out2_base) {
 	ProfScope prof(PROF_LAYERNORM, (double)rows * d * (4.0 + (out_f32 ? 4.0 : dtype_size(dt))), s);
 	const int grid = (rows + 3) / 4;
-#define LN_GO(OT, NI) hipLaunchKernelGGL((k_layernorm<OT, NI>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (OT*)out, ldo, frag, out2, out2_idx, out2_stride)
+#define LN_GO(OT, NI) hipLaunchKernelGGL((k_layernorm<OT, NI>), dim3(grid), dim3(256), 0, s, x, ldx, rows, d, g1, b1, g2, b2, (OT*)out, ldo, frag, out2, out2_idx, out2_stride, out2_base)
 	if (out_f32 || dt == DT_F32) { if (d <= 1024) LN_GO(float, 4); else LN_GO(float, 16); }
 	else if (dt == DT_F16) { if (d <= 1024) LN_GO(f16, 4); else LN_GO(f16, 16); }
 	else { if (d <= 1024) LN_GO(bf16, 4); else LN_GO(bf16, 16); }

@@ -145,7 +145,8 @@ bool launch_gemv(int dt, int role, const GemvParams& p, hipStream_t s);
 // y = LN2?(LN1(x)) per row; out is T or f32; frag: out in the skinny GEMV's A-fragment order instead of row-major; out2 (optional): also f32 [rows][d]
 void launch_layernorm(int dt, const float* x, int64_t ldx, int rows, int d, const float* g1, const float* b1,
 					  const float* g2, const float* b2, void* out, int64_t ldo, int out_f32, hipStream_t s, int frag = 0, float* out2 = nullptr,
-					  const int64_t* out2_idx = nullptr, int64_t out2_stride = 0);      // out2_idx: out2 += out2_idx[0] * out2_stride on the device
+					  const int64_t* out2_idx = nullptr, int64_t out2_stride = 0, const int64_t* out2_base = nullptr);
+// out2_idx: out2 += out2_idx[0] * out2_stride on the device; out2_base: out2 itself is read from that device word first
 // GroupNorm32 over channels-last x f32 [nb][T][C], 32 groups: per-chunk statistics part[nb][32][nchunks][3] = (count, mean, M2)
 int gn_num_chunks(int T, int C);
 int gn_rows_per_chunk(int C);
