@@ -1,0 +1,89 @@
+"""Handles reused across calls of different shape give what a fresh handle gives (state that outlives a call -- captured token steps, generation
+states, grow-only work buffers, per-utterance precomputations, the hidden ring -- must never leak from one call into the next).
+
+The reference builds nothing per call that survives it (HF `generate` and the diffusion loops are stateless apart from the module weights), so the
+product's caches have no counterpart there; every case compares a long-lived handle with freshly built ones BIT FOR BIT.  GPU only; calls go
+through the C ABI."""
+import pytest
+import torch
+
+from tortoise_tts_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def gen(seed):
+	return torch.Generator().manual_seed(seed)
+
+
+def new_ar(dtype="f32", max_batch=8):
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	return UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_SMALL), 31), W.AR_SMALL, dtype=dtype, device=DEV, max_batch=max_batch, max_ctx=160)
+
+
+def new_diff(dtype="f32"):
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	return DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(W.DIFF_SMALL), 32), W.DIFF_SMALL, dtype=dtype, device=DEV)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_sampling_calls_of_changing_shape_on_one_model(dtype):
+	"""text lengths, candidate counts, lengths and warpers change from call to call (several generation states and captured steps alive at once,
+	the least recently used one evicted and rebuilt); a streamed generation in between; every result equals a fresh model's"""
+	calls = [
+		dict(Tt=9, B=4, M=20, kw=dict(temperature=0.8, top_k=0)),
+		dict(Tt=23, B=4, M=20, kw=dict(temperature=0.8, top_k=0)),                       # same state, longer prefix
+		dict(Tt=5, B=8, M=12, kw=dict(temperature=1.0, top_k=30, top_p=0.9)),
+		dict(Tt=9, B=2, M=33, kw=dict(temperature=0.7, top_k=0, repetition_penalty=2.0)),
+		dict(Tt=14, B=1, M=20, kw=dict(temperature=0.8, top_k=0)),
+		dict(Tt=9, B=3, M=16, kw=dict(temperature=0.9, top_k=0, suppress_tokens=[W.AR_SMALL.stop_mel_token])),
+		dict(Tt=9, B=4, M=20, kw=dict(temperature=0.8, top_k=0)),                       # the first state again, after four others
+	]
+	keep = new_ar(dtype)
+	for i, c in enumerate(calls):
+		text = torch.randint(1, 255, (1, c["Tt"]), generator=gen(100 + i)).to(DEV)
+		cond = torch.randn(1, 128, generator=gen(200 + i)).to(DEV)
+		args = dict(do_sample=True, num_return_sequences=c["B"], max_generate_length=c["M"], **c["kw"])
+		with torch.inference_mode():
+			got = keep.inference_speech(cond, text, **args)
+			off_keep = torch.cuda.default_generators[0].get_offset()
+			want = new_ar(dtype).inference_speech(cond, text, **args)
+			off_new = torch.cuda.default_generators[0].get_offset()
+		assert torch.equal(got, want) and off_keep == off_new, (i, c)
+		if i == 2:      # a streamed generation on the long-lived model between two ordinary ones
+			ids = keep.compute_embeddings(cond, text)
+			out = list(keep.get_generator(inputs=ids, max_length=ids.shape[1] + 10, do_sample=True, num_return_sequences=4, temperature=0.8, top_k=0))
+			fresh = new_ar(dtype)
+			ids2 = fresh.compute_embeddings(cond, text)
+			ref = list(fresh.get_generator(inputs=ids2, max_length=ids2.shape[1] + 10, do_sample=True, num_return_sequences=4, temperature=0.8, top_k=0))
+			assert len(out) == len(ref)
+			for (t, l), (rt, rl) in zip(out, ref):
+				assert torch.equal(t, rt) and torch.equal(l, rl)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_diffusion_loops_of_changing_length_on_one_handle(dtype):
+	"""frame counts go up and down (grow-only buffers keep the larger capacity, the per-utterance precomputation of ttk_diff_begin is redone), a ragged
+	batch of two lines in between, both samplers: every result equals a fresh handle's"""
+	from tortoise_tts_amd.diffusion import get_diffuser
+	keep = new_diff(dtype)
+	C = W.DIFF_SMALL.model_channels
+	plan = [("ddim", 64), ("ddim", 200), ("p", 40), ("ddim", 64), ("lines", (128, 70)), ("ddim", 129), ("ddim", 200)]
+	for i, (kind, T) in enumerate(plan):
+		with torch.inference_mode():
+			if kind == "lines":
+				noises = [torch.randn((1, 100, t), generator=gen(300 + i + j)).to(DEV) for j, t in enumerate(T)]
+				Es = [torch.randn((1, C, t), generator=gen(400 + i + j)).to(DEV) for j, t in enumerate(T)]
+				got = get_diffuser(steps=5, cond_free=True).sample_loop_lines(keep, noises, Es)
+				want = get_diffuser(steps=5, cond_free=True).sample_loop_lines(new_diff(dtype), noises, Es)
+				for a, b in zip(got, want):
+					assert torch.equal(a, b), (i, kind, T)
+				continue
+			noise = torch.randn((1, 100, T), generator=gen(300 + i)).to(DEV)
+			E = torch.randn((1, C, T), generator=gen(400 + i)).to(DEV)
+			run = lambda m: (torch.manual_seed(7), torch.cuda.manual_seed_all(7),
+							 get_diffuser(steps=5, cond_free=True).sample_loop(m, (1, 100, T), sampler=kind, noise=noise, model_kwargs={"precomputed_aligned_embeddings": E}))[2]
+			got, want = run(keep), run(new_diff(dtype))
+		torch.cuda.synchronize()
+		assert torch.isfinite(got).all() and torch.equal(got, want), (i, kind, T, (got - want).abs().max().item())
