@@ -63,7 +63,9 @@ def test_full_size_line_batches_equal_the_single_runs(full_sd, dtype):
 	from tortoise_tts_amd.diffusion import DiffusionTTS
 	model = DiffusionTTS(full_sd, W.DIFF_FULL, dtype=dtype, device=DEV)
 	with torch.inference_mode():
-		for Ts in ([1088, 1000, 512, 70], [1088, 1088], [960, 1088, 1024]):
+		# (784 / 1152: the shortest / longest single runs that take the balanced attention form -- 6 and 9 sixteen-query tiles per workgroup; 1150 / 800: tile
+		# counts that do not divide by the workgroups per head, last key tile partly valid)
+		for Ts in ([1088, 1000, 512, 70], [1088, 1088], [960, 1088, 1024], [784, 1152], [1150, 800]):
 			single, batch, _, _ = run_both(model, Ts, 3, 900)
 			for i, (a, b) in enumerate(zip(single, batch)):
 				assert torch.isfinite(b).all() and torch.equal(a, b), (dtype, Ts, i, (a - b).abs().max().item())
