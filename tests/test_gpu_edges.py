@@ -145,6 +145,26 @@ def test_streaming_generator_is_the_sampling_loop_token_by_token(small_ar):
 	assert torch.equal(again, want)
 
 
+def test_a_second_generation_while_a_stream_is_open_is_refused(small_ar):
+	"""one generation at a time per handle (its KV cache / noise / latent ring belong to the open stream): refused by name, and fine again after close()"""
+	from tortoise_tts_amd import _lib
+	model, _ = small_ar
+	text = torch.randint(1, 255, (1, 9), generator=gen(70)).to(DEV)
+	cond = torch.randn(1, 128, generator=gen(71)).to(DEV)
+	kw = dict(temperature=0.9, top_k=0, do_sample=True, num_return_sequences=2)
+	ids = model.compute_embeddings(cond, text)
+	g1 = model.get_generator(inputs=ids, max_length=ids.shape[1] + 10, **kw)
+	g2 = model.get_generator(inputs=ids, max_length=ids.shape[1] + 10, **kw)        # creating a second generator is fine: nothing has run yet
+	first = next(g1)[0].clone()
+	with pytest.raises(_lib.TTKError, match="streamed generation is still open"):
+		model.inference_speech(cond, text, max_generate_length=10, **kw)
+	with pytest.raises(_lib.TTKError, match="streamed generation is still open"):
+		next(g2)
+	rest = [t.clone() for t, _ in g1]                                                 # the open stream is unharmed by the refused calls
+	want = model.inference_speech(cond, text, max_generate_length=10, **kw)
+	assert torch.equal(torch.stack([first] + rest, 1), want)
+
+
 def test_streaming_generator_twice_on_one_model_keeps_both_latent_sets(small_ar):
 	"""two streamed generations of the same shape on one model: the second replays the token step captured by the first, and must write ITS latents into
 	ITS buffer -- the first call's yielded latents stay what they were (the base of the latent buffer reaches the captured launch through device memory,

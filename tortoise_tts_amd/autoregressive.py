@@ -68,6 +68,7 @@ class UnifiedVoice:
 		del keep
 		self._states: Dict[tuple, "_GenState"] = {}
 		self._prefix = None
+		self._streaming = False          # a streamed generation is open on this handle (its KV cache, noise and latent ring belong to it)
 
 	def __del__(self):
 		h = getattr(self, "_h", None)
@@ -275,6 +276,12 @@ class UnifiedVoice:
 			self.last_generate = dict(self.last_generate_lines[-1])
 			return out
 
+	def _require_idle(self):
+		"""one generation at a time per handle: the KV cache, the noise arming and the latent ring of an open streamed generation are the handle's (the
+		reference's module is re-entrant because HF keeps all of that per call); starting another one would corrupt both silently, so it is refused"""
+		if self._streaming:
+			raise _lib.TTKError("a streamed generation is still open on this model: exhaust or close() its generator before starting another generation")
+
 	def compute_embeddings(self, cond_latents, text_inputs, kv_cache=True):
 		"""unified_voice.py:614-630: remembers the prefix, returns the fake id row [b, P+1]."""
 		self._prefix = (cond_latents, text_inputs)
@@ -296,6 +303,7 @@ class UnifiedVoice:
 	# ------------------------------------------------------------------ the token loop
 	def _generate(self, cond, text, num_return_sequences, max_generate_length, typical_mass, kw, stream, shard=None):
 		c = self.cfg
+		self._require_idle()
 		C = num_return_sequences * text.shape[0]          # candidates the noise is drawn for
 		lo, hi = (0, C) if shard is None else (int(shard[0]), int(shard[1]))
 		if not (0 <= lo < hi <= C):
@@ -451,6 +459,7 @@ class UnifiedVoice:
 		generation of the same shape on this model."""
 		c = self.cfg
 		LAG = 2
+		self._require_idle()            # (a generator body runs at its first next(): two generators may have been created, only one may run)
 		with torch.cuda.device(self.device):
 			st = self._gen_state(B, max_new, pipe_key, B, 0)
 			setup_seed(0)
@@ -462,6 +471,7 @@ class UnifiedVoice:
 			hid = torch.empty((max_new, B, c.model_dim), device=self.device, dtype=torch.float32)
 			fast = self.use_graph and st.graphable and st.own_rng        # captured step; else the same launches issued eagerly
 			n_done = 0
+			self._streaming = True
 			try:
 				st.logits.copy_(self._prefill(cond, text, B))
 				_lib.check(self.lib.ttk_ar_last_hidden(self._h, hid[0].data_ptr(), _lib.stream_ptr()), "ttk_ar_last_hidden")
@@ -507,6 +517,7 @@ class UnifiedVoice:
 					if n_done >= max_new or (end and end <= n_done):
 						return
 			finally:
+				self._streaming = False
 				_lib.check(self.lib.ttk_ar_set_hidden_ring(self._h, None, None, 0, _lib.stream_ptr()), "ttk_ar_set_hidden_ring")
 				if st.own_rng:
 					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
