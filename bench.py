@@ -19,7 +19,7 @@ same workload, rank 0, N = 1 only).
 
 --shard candidates   BASELINE configs[3] instead (not the headline line): ONE long-form utterance at a time, 2 lines x 256 text
          tokens, 32 candidates per GPU (256 at N = 8) x 500 mel tokens, 200 DDIM steps at T = 2176; candidates sharded over the ranks
-         (tortoise_tts_amd/dist.py: ids all-gathered over RCCL, scores all-gathered, the winner's owner diffuses, mel broadcast).
+         (tortoise_tts_amd/dist.py: ids all-gathered over RCCL, scores all-gathered, the lines' diffusions spread over the ranks, mels broadcast).
 """
 import argparse
 import json
@@ -134,6 +134,9 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 		for i in range(len(marks) - 1):
 			ms[marks[i + 1][0]] = ms.get(marks[i + 1][0], 0.0) + marks[i][1].elapsed_time(marks[i + 1][1])
 	L = len(marks_per_line)
+	# candidate shards with several lines: the lines' diffusions are spread over the ranks (dist.assign_diffusers), so THIS rank's "ddim" interval covers the
+	# lines it diffused (one ragged batch) -- possibly none; "_"-prefixed marks bracket time that belongs to no phase of the line that carries them
+	L_ddim = sum(1 for marks in marks_per_line if any(n == "ddim" for n, _ in marks))
 	e_w = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
 	e_kv = 4 if dtype_name == "f32" else 2
 	peak_f = 157.3e12 if dtype_name == "f32" else 2.5e15
@@ -151,23 +154,26 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 	lat_flop = L * (2.0 * blocks * S * n_cand + 2.0 * S * S * 1024 * 30 * n_cand)
 	T = n_mel * 4 * 24000 // 22050
 	F = 236 * 1024 ** 2 * T + 52 * 1024 * T * T + 1_843_200 * T
-	ddim_flop = L * n_ddim * 2.0 * F
+	ddim_flop = L_ddim * n_ddim * 2.0 * F
 	ar_floor = ar_bytes / 8.0e12 * 1e3 + prefill_flop / peak_f * 1e3
+	def phase(bound, work_key, work, name, peak, unit_key, unit_scale, **extra):
+		t = ms.get(name)
+		if not t or not work:           # the phase did not run on this rank (a candidate shard whose lines are all diffused elsewhere)
+			return {"bound": bound, work_key: work, "ms": t, "frac": None, "floor_ms": work / peak * 1e3, "note": "did not run on this rank", **extra}
+		return {"bound": bound, work_key: work, "ms": t, unit_key: work / (t * 1e-3) / unit_scale, "frac": work / (t * 1e-3) / peak, "floor_ms": work / peak * 1e3, **extra}
 	out = {
-		"ar_decode": {"bound": "hbm", "algorithmic_bytes": ar_bytes, "prefill_flop": prefill_flop, "ms": ms["ar_decode"],
-					  "achieved_GBps": ar_bytes / (ms["ar_decode"] * 1e-3) / 1e9, "frac": ar_bytes / (ms["ar_decode"] * 1e-3) / 8.0e12,
-					  "floor_ms": ar_floor, "note": f"prefill + {n_mel} sampled tokens; bytes = {n_mel - 1} KV-cached steps (weights once per step + KV read + logits)"},
-		"latent_pass": {"bound": "mfma", "flop": lat_flop, "ms": ms["latent_pass"], "achieved_TFLOPs": lat_flop / (ms["latent_pass"] * 1e-3) / 1e12,
-						"frac": lat_flop / (ms["latent_pass"] * 1e-3) / peak_f, "floor_ms": lat_flop / peak_f * 1e3},
-		"ddim": {"bound": "mfma", "flop": ddim_flop, "ms": ms["ddim"], "achieved_TFLOPs": ddim_flop / (ms["ddim"] * 1e-3) / 1e12,
-				 "frac": ddim_flop / (ms["ddim"] * 1e-3) / peak_ddim, "peak_TFLOPs": peak_ddim / 1e12, "floor_ms": ddim_flop / peak_ddim * 1e3,
-				 "note": f"timestep-independent conditioning + {n_ddim} steps x (cond + cond-free evaluation); flop = {2 * n_ddim} F(T)"},
+		"ar_decode": phase("hbm", "algorithmic_bytes", ar_bytes, "ar_decode", 8.0e12, "achieved_GBps", 1e9, prefill_flop=prefill_flop,
+						   note=f"prefill + {n_mel} sampled tokens; bytes = {n_mel - 1} KV-cached steps (weights once per step + KV read + logits)"),
+		"latent_pass": phase("mfma", "flop", lat_flop, "latent_pass", peak_f, "achieved_TFLOPs", 1e12),
+		"ddim": phase("mfma", "flop", ddim_flop, "ddim", peak_ddim, "achieved_TFLOPs", 1e12, peak_TFLOPs=peak_ddim / 1e12, lines_diffused_here=L_ddim,
+					  note=f"timestep-independent conditioning + {n_ddim} steps x (cond + cond-free evaluation); flop = {2 * n_ddim} F(T) per line diffused on this rank"),
 	}
+	out["ar_decode"]["floor_ms"] = ar_floor
 	if L > 1:
 		out["lines"] = L
 	out["whole_step_floor_ms"] = out["ar_decode"]["floor_ms"] + out["latent_pass"]["floor_ms"] + out["ddim"]["floor_ms"]
-	out["whole_step_ms"] = sum(ms.values())
-	out["whole_step_frac_of_floor"] = out["whole_step_floor_ms"] / out["whole_step_ms"]
+	out["whole_step_ms"] = sum(v for k, v in ms.items() if not k.startswith("_"))
+	out["whole_step_frac_of_floor"] = out["whole_step_floor_ms"] / out["whole_step_ms"] if out["whole_step_ms"] else None
 	return out
 
 
@@ -335,7 +341,7 @@ def main():
 		step(exchange=False, marks=marks)                  # one more step, run exactly as the timed ones, with events at the phase boundaries
 		torch.cuda.synchronize()
 		roof = profiling.dominant_kernel_roofline(lambda: step(exchange=False), ar, df)
-		if not a.small:
+		if not a.small and rank == 0:      # only rank 0 reports; a shard that diffused no line has no "ddim" interval (phase_roofline says so instead of raising)
 			roof["phases"] = phase_roofline(marks, a.dtype, n_text, n_cand, n_mel, n_ddim) if by_cand else phase_roofline([marks], a.dtype)
 	# informational, never `value`: the k = 1 variant SURVEY.md 8d row 2 asks to be reported beside the headline -- the candidate is chosen first and
 	# only its row goes through the dense latent pass (same bits out; the reference runs all 16, inference.py:370-379, and so does `value`)
@@ -372,6 +378,31 @@ def main():
 		piped = {"value": sum(r[1] for r in res) / dl, "unit": "audio-sec/wall-sec", "lines": n_lines, "text_tokens": lens, "ar_batch_lines": per_batch, "ms_per_line": 1e3 * dl / n_lines,
 				 "note": "stream of utterances: 4 lines sampled as one decode batch, diffusion pipelined under the next batch; not the headline metric"}
 		del tts4, ar4
+	# informational, never `value`: the loop real utterances run.  The headline suppresses the stop token (fixed length), so
+	# HF's stopping test is compiled out of its loop (`can_stop` False).  Here the stop token is NOT suppressed but unreachable -- mel_head.bias[stop] = -1e9 in
+	# a second handle's synthetic weights, so its probability is exactly 0, the length stays 250 and the ids must equal the headline's -- and the loop runs
+	# with the stopping test live: one event per token, the pinned flag read LAG tokens late (autoregressive.py `_token_loop`).
+	live = None
+	if rank == 0 and world == 1 and not a.no_roofline and not by_cand:
+		sd = W.synth_state_dict(W.ar_shapes(ar_cfg), 0)
+		sd["mel_head.bias"] = sd["mel_head.bias"].clone()
+		sd["mel_head.bias"][ar_cfg.stop_mel_token] = -1e9
+		ar_l = UnifiedVoice(sd, ar_cfg, dtype=a.dtype, device=dev, max_batch=n_cand, max_ctx=n_text + 4 + n_mel + 8)
+		del sd
+		tts_l = TTSHotPath(ar_l, df, vocoder=voc)
+		kwl = {k: v for k, v in kw.items() if k != "suppress_tokens"}
+		ref_codes = tts.inference(text, ar_lat, df_lat, **kw)[2]["codes"]
+		got_codes = tts_l.inference(text, ar_lat, df_lat, **kwl)[2]["codes"]      # (also the warm-up: captures this handle's token step)
+		torch.cuda.synchronize()
+		n_live = max(2, min(a.steps, 5))
+		t1 = time.perf_counter()
+		sec = sum(tts_l.inference(text, ar_lat, df_lat, **kwl)[1] for _ in range(n_live))
+		torch.cuda.synchronize()
+		dl = time.perf_counter() - t1
+		live = {"value": sec / dl, "unit": "audio-sec/wall-sec", "ms_per_step": 1e3 * dl / n_live, "steps": n_live,
+				"ids_equal_headline": bool(got_codes.shape == ref_codes.shape and torch.equal(got_codes, ref_codes)), "mel_tokens": int(got_codes.shape[1]),
+				"note": "stop token live (not suppressed, unreachable through mel_head.bias[stop] = -1e9): HF's per-token stopping test runs as the lagged pinned flag; not the headline metric"}
+		del tts_l, ar_l
 	log("roofline pass done; cpu baseline")
 	cpu = None
 	if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.small:
@@ -393,8 +424,8 @@ def main():
 			cfg_line["ar_handle_dtype"] = "fp8w"
 		if by_cand:
 			cfg_line = {"workload": f"configs[3]: one long-form utterance = 2 lines x 256 text tokens, {n_cand * world} AR candidates ({n_cand} per GPU) x 500 mel "
-									"tokens, latent pass + candidate choice on every shard, 200 DDIM steps with cond-free guidance at T=2176 (23.2 s audio per line) "
-									"on the winner's GPU; ids / scores all-gathered and the mel broadcast over RCCL",
+									"tokens, latent pass + candidate choice on every shard, 200 DDIM steps with cond-free guidance at T=2176 (23.2 s audio per line), "
+									"the lines' diffusions spread over the GPUs (latents + start noise broadcast from the winner's GPU); ids / scores all-gathered and the mels broadcast over RCCL",
 						"text_tokens": n_text, "candidates": n_cand * world, "mel_tokens": n_mel, "ddim_steps": n_ddim, "lines": n_lines,
 						"mel_frames": n_mel * 4 * 24000 // 22050, "parallelism": f"candidates x{world}", "small_models": bool(a.small)}
 		line = {
@@ -405,7 +436,7 @@ def main():
 			"ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": a.dtype, "data": "synthetic",
 			"config": cfg_line,
-			"roofline": roof, "cpu_baseline": cpu, "latent_k1_variant": k1, "pipelined_lines": piped,
+			"roofline": roof, "cpu_baseline": cpu, "latent_k1_variant": k1, "pipelined_lines": piped, "stop_live": live,
 		}
 		print(json.dumps(line), flush=True)
 	if dist.is_initialized():

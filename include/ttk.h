@@ -92,6 +92,14 @@ int ttk_ar_decode(ttk_ar* h, const int64_t* tok, float* logits_out, float* hidde
  * from the same forward's logits (stream_generator.py:1172) -- for the first token that is the prefill's row.                     */
 int ttk_ar_last_hidden(ttk_ar* h, float* hidden_out, void* stream);
 
+/* Host-only (no GPU call; usable before any handle exists): the geometry the decode launches of a handle created with (dtype, max_batch) run with when
+ * `rows` candidates are decoded -- out[0] = rows ttk_ar_create allocates and zeroes for each fragment-order operand (attention output, MLP
+ * activations, the T-typed residual copy), out[1] = sixteen-row tiles of the kernel instantiation the launch selects, out[2] = rows that
+ * instantiation requests (every tile of it, whatever `rows` is), out[3] = candidate slices of the KV cache.  out[2] <= out[0] for every
+ * rows <= max_batch is what ttk_ar_create asserts and every decode entry re-checks; tests/test_host_logic.py enumerates it.  No reference
+ * counterpart (the reference's tensors are sized by the call that makes them).                                                              */
+int ttk_ar_decode_geometry(int dtype, int max_batch, int rows, int32_t out[4]);
+
 /* What the decode step's folded LayerNorm (ln_1 + c_attn, ln_2 + c_fc as one matrix over the UN-normalised rows, T-typed) could not represent
  * well since the last call: bit 0 = a row of the residual stream had |mean| > 8 std (more than 3 of the operand's significand bits went to the
  * common offset the norm removes: results drift from the reference's LayerNorm-then-matmul; TTK_AR_LNFOLD=0 selects the form that normalises

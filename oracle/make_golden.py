@@ -14,6 +14,9 @@ Fixtures
   diff_small.npz  DiffusionTTS(128 ch, 2 layers, 2 heads): timestep_independent, forward cond/uncond,
                   DDIM 4 steps, p-sampler 4 steps                            (diffusion.py:1487-1574, :500-810)
   diff_full.npz   full-size DiffusionTTS(): one forward (cond + uncond) at T=26
+  diff_cfg1.npz   full-size DiffusionTTS() at configs[1]'s T = 1088: E, one evaluation pair, the last 8 of the 80 DDIM steps
+  diff_cfg1_loop.npz  the same model's WHOLE 80-step DDIM loop from seeded noise, x at 8 / 16 / 40 / 72 steps + final mel
+  e2e_cfg1.npz    one configs[1] utterance end to end in f32: the reference's sample_stream codes -> latents -> E -> 80 DDIM steps -> mel
   cond_small.npz  UnifiedVoice.get_conditioning / DiffusionTTS.get_conditioning, small widths, 2 clips   (unified_voice.py:535-542,
   cond_full.npz   diffusion.py:1477-1485); full-size encoders at short clips
   stft_ref.npz    STFT(1024, 256, 1024).transform magnitudes on seeded audio (arch_utils.py:560-623)
@@ -143,6 +146,95 @@ def diff_cfg1_case(d_mod):
 			xm = diffuser.ddim_sample(m, xm, torch.tensor([i]), clip_denoised=True, model_kwargs={"precomputed_aligned_embeddings": E}, eta=0.0)["sample"]
 	return dict(T=np.int64(T), M=np.int64(M), stride=np.int64(8), E_sub=E[:, :, ::8].numpy(), y_cond_sub=yc[:, :, ::8].numpy(),
 				y_uncond_sub=yu[:, :, ::8].numpy(), mel=xm.numpy())
+
+
+LOOP_CHECKPOINTS = (8, 16, 40, 72, 80)    # x after this many of the 80 DDIM steps is stored
+
+
+def _ddim_loop_with_checkpoints(d_mod, m, noise, E, steps=80):
+	"""The reference's whole DDIM loop (`sample_loop(sampler="ddim")` -> ddim_sample_loop :734-763 -> ddim_sample_loop_progressive :765-810, the
+	generator driven here so the intermediate samples can be kept), conditioning-free guidance on with its ramp as `get_diffuser` builds it."""
+	diffuser = d_mod.get_diffuser(steps=steps, cond_free=True)
+	keep, done = {}, 0
+	torch.manual_seed(0)                       # ddim_sample draws (and, with eta = 0, ignores) one randn_like per step
+	t0 = time.time()
+	for out in diffuser.ddim_sample_loop_progressive(m, tuple(noise.shape), noise=noise, clip_denoised=True,
+													 model_kwargs={"precomputed_aligned_embeddings": E}, device="cpu", progress=False, eta=0.0):
+		done += 1
+		if done in LOOP_CHECKPOINTS:
+			keep[done] = out["sample"].clone()
+			print(f"  step {done}/{steps}: {time.time() - t0:.0f}s, |x|max {float(keep[done].abs().max()):.3f}", flush=True)
+	assert done == steps
+	return keep
+
+
+def diff_cfg1_loop_case(d_mod):
+	"""configs[1]'s WHOLE diffusion through the REFERENCE: diff_cfg1's model, latents and conditioning at T = 1088, the full
+	80-step DDIM loop from seeded start noise.  Stored: x after 8 / 16 / 40 / 72 steps on every 8th frame and the final mel whole.
+	tests/test_gpu_ddim_full.py regenerates the inputs from the same seeds and asserts the per-dtype bounds of DESIGN.md section 2 at every checkpoint."""
+	cfg = W.DIFF_FULL
+	sd = W.synth_state_dict(W.diffusion_shapes(cfg), 1)
+	m = d_mod.DiffusionTTS(model_channels=cfg.model_channels, num_layers=cfg.num_layers, in_channels=cfg.in_channels,
+						   in_latent_channels=cfg.in_latent_channels, out_channels=cfg.out_channels, num_heads=cfg.num_heads)
+	load_into(m, sd)
+	M, T = 250, 250 * 4 * 24000 // 22050
+	lat = torch.randn(1, M, 1024, generator=gen(11))
+	dcond = torch.randn(1, 2048, generator=gen(12))
+	noise = torch.randn(1, 100, T, generator=gen(14))
+	with torch.inference_mode():
+		E = m.timestep_independent(lat, dcond, T, False)
+		keep = _ddim_loop_with_checkpoints(d_mod, m, noise, E)
+	out = dict(T=np.int64(T), M=np.int64(M), stride=np.int64(8), steps=np.int64(80), checkpoints=np.array(LOOP_CHECKPOINTS, dtype=np.int64), mel=keep[80].numpy())
+	for n in LOOP_CHECKPOINTS[:-1]:
+		out[f"x_after_{n}_sub"] = keep[n][:, :, ::8].numpy()
+	return out
+
+
+def e2e_cfg1_case(d_mod, uv_mod):
+	"""One configs[1] utterance end to end through the REFERENCE's modules in f32, in the order of inference.py:334-413: full-size UnifiedVoice and
+	DiffusionTTS on the repo's seeded weights, SURVEY section 8d's inputs (64 text tokens seed 1234, conditioning latents seed 1235, start noise seed
+	1236); 250 mel tokens drawn by the reference's own `sample_stream` (one candidate, stop token suppressed, CPU generator) -> forward(return_latent=True)
+	-> timestep_independent -> the 80-step DDIM loop -> mel.  Stored: the codes, latents / E subsampled, x at the loop's checkpoints on every 8th frame, the final mel whole."""
+	import importlib
+	from transformers import GenerationConfig, LogitsProcessorList, SuppressTokensLogitsProcessor
+	sg = importlib.import_module("tortoise_tts.models.stream_generator")
+	acfg, dcfg = W.AR_FULL, W.DIFF_FULL
+	ar = uv_mod.UnifiedVoice(layers=acfg.layers, model_dim=acfg.model_dim, heads=acfg.heads, checkpointing=False)
+	load_into(ar, W.synth_state_dict(W.ar_shapes(acfg), 0))
+	text = torch.randint(1, 255, (1, 64), generator=gen(1234))
+	g = gen(1235)
+	cond = torch.randn(1, 1024, generator=g)
+	dcond = torch.randn(1, 2048, generator=g)
+	M = 250
+	t0 = time.time()
+	with torch.inference_mode():
+		ids = ar.compute_embeddings(cond, text)
+		im = ar.inference_model
+		procs = LogitsProcessorList([SuppressTokensLogitsProcessor([acfg.stop_mel_token])])
+		warpers = sg.NewGenerationMixin._get_logits_warper(im, GenerationConfig(do_sample=True, num_beams=1, temperature=0.8, top_k=0, top_p=1.0))
+		sg.setup_seed(0)
+		toks = [tok.clone() for tok, _ in sg.NewGenerationMixin.sample_stream(
+			im, ids, logits_processor=procs, logits_warper=warpers, stopping_criteria=_ScalarMaxLength(ids.shape[1] + M),
+			pad_token_id=acfg.stop_mel_token, eos_token_id=acfg.stop_mel_token, output_hidden_states=True, return_dict_in_generate=False,
+			use_cache=True, attention_mask=torch.ones_like(ids))]
+		codes = torch.stack(toks, 1)
+		assert codes.shape == (1, M) and int(codes.max()) < acfg.stop_mel_token
+		print(f"  sampled {M} codes in {time.time() - t0:.0f}s: {codes[0, :8].tolist()} ...", flush=True)
+		lat = ar.forward(cond, text, torch.tensor([64], dtype=torch.int32), codes, torch.tensor([M * acfg.mel_length_compression]),
+						 return_latent=True, clip_inputs=False)
+		del ar, im
+		df = d_mod.DiffusionTTS(model_channels=dcfg.model_channels, num_layers=dcfg.num_layers, in_channels=dcfg.in_channels,
+								in_latent_channels=dcfg.in_latent_channels, out_channels=dcfg.out_channels, num_heads=dcfg.num_heads)
+		load_into(df, W.synth_state_dict(W.diffusion_shapes(dcfg), 1))
+		T = lat.shape[1] * 4 * 24000 // 22050
+		E = df.timestep_independent(lat, dcond, T, False)
+		noise = torch.randn(1, 100, T, generator=gen(1236))
+		keep = _ddim_loop_with_checkpoints(d_mod, df, noise, E)
+	out = dict(T=np.int64(T), M=np.int64(M), stride=np.int64(8), codes=codes.numpy(), latents_sub=lat[:, :, ::8].numpy(), E_sub=E[:, :, ::8].numpy(),
+			   checkpoints=np.array(LOOP_CHECKPOINTS, dtype=np.int64), mel=keep[80].numpy())
+	for n in LOOP_CHECKPOINTS[:-1]:
+		out[f"x_after_{n}_sub"] = keep[n][:, :, ::8].numpy()
+	return out
 
 
 def schedule_case(d_mod):
@@ -307,14 +399,16 @@ def vocoder_case(cfg, seed, T):
 	import importlib
 	bv = importlib.import_module("tortoise_tts.models.bigvgan")
 	sd = W.synth_state_dict(W.vocoder_shapes(cfg), seed)
+	torch.manual_seed(seed + 3)        # the weight-norm test tensors below are the constructor's own initialisation: seeded, so the fixture regenerates bit for bit
 	m = bv.BigVGAN(data=cfg.as_json())
 	out = dict(seed=np.int64(seed), wn_keys=np.array(sorted(k for k in m.state_dict().keys() if "filter" not in k)),
 			   filter_up=m.activation_post.upsample.filter.reshape(-1).numpy().copy(),
 			   filter_down=m.activation_post.downsample.lowpass.filter.reshape(-1).numpy().copy())
 	# a weight-normed tensor pair for the ingest test (g, v and the weight they produce), before the norm is removed
 	with torch.no_grad():
-		m.conv_pre.weight_g.copy_(torch.rand_like(m.conv_pre.weight_g, generator=None) + 0.5)
-		m.ups[0][0].weight_g.copy_(torch.rand_like(m.ups[0][0].weight_g) + 0.5)
+		gw = gen(seed + 2)
+		m.conv_pre.weight_g.copy_(torch.rand(m.conv_pre.weight_g.shape, generator=gw) + 0.5)
+		m.ups[0][0].weight_g.copy_(torch.rand(m.ups[0][0].weight_g.shape, generator=gw) + 0.5)
 	out["wn_conv_pre_g"], out["wn_conv_pre_v"] = m.conv_pre.weight_g.detach().numpy().copy(), m.conv_pre.weight_v.detach().numpy().copy()
 	out["wn_conv_pre_w"] = m.conv_pre.weight.detach().numpy().copy() if hasattr(m.conv_pre, "weight") else None
 	out["wn_ups0_g"], out["wn_ups0_v"] = m.ups[0][0].weight_g.detach().numpy().copy(), m.ups[0][0].weight_v.detach().numpy().copy()
@@ -468,6 +562,8 @@ def main():
 		("ar_full", lambda: ar_case(uv_mod, W.AR_FULL, 12, B=1, Tt=8, n_dec=2, M=6, full=True)),
 		("diff_full", lambda: diff_case(d_mod, W.DIFF_FULL, 22, b=1, M=6, full=True)),
 		("diff_cfg1", lambda: diff_cfg1_case(d_mod)),
+		("diff_cfg1_loop", lambda: diff_cfg1_loop_case(d_mod)),
+		("e2e_cfg1", lambda: e2e_cfg1_case(d_mod, uv_mod)),
 		("lora_small", lambda: lora_case(uv_mod, W.AR_SMALL, 13, rank=4, alpha=8)),
 		("hf_sample_loop", hf_sample_loop_case),
 		("wrapper", lambda: wrapper_case(uv_mod)),

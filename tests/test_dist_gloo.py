@@ -151,6 +151,21 @@ def _body_sharded_lines(rank, world):
 	return dict(res=[dict(mel=m, ids=i, scores=s, best=b) for m, i, s, b in res], calls=[st.calls for st in sts], batches=batches)
 
 
+def _body_spread_lines(rank, world):
+	"""`world` lines of one text, no scorer (every line's winner is candidate 0 on rank 0): the diffusions must be spread one per rank, each item
+	(codes + latents here; latents + start noise on libttk) travelling from rank 0 to its diffuser, every mel broadcast from where it was made.
+	spread=False keeps the round-3 behaviour (everything on the owner) and must give the same results."""
+	out = {}
+	for spread in (True, False):
+		sts = [_FakeStages(False) for _ in range(world)]
+		batches = []
+		for st in sts:
+			st.run_diffusion = (lambda prepared, st=st: (batches.append(len(prepared)), [st.diffuse(c, l) for c, l in prepared])[1])
+		res = D.sharded_candidates_lines(sts, 7, spread=spread)
+		out[spread] = dict(res=[dict(mel=m, ids=i, scores=s, best=b) for m, i, s, b in res], calls=[st.calls for st in sts], batches=batches)
+	return out
+
+
 def _body_subgroups(rank, world):
 	"""a 4-rank world cut into two 2-rank sub-groups (2 utterances x 2-way candidate shards, as configs[2] x configs[3] would combine on 8 GPUs),
 	and a 2-rank sub-group of a 3-rank world: every collective of the sharded path must stay inside the group it was given"""
@@ -299,3 +314,34 @@ def test_sharded_lines_one_diffusion_per_owner_two_ranks():
 	dif = lambda r, k: [c for c in got[r]["calls"][k] if c[0] == "diffuse"]
 	assert dif(0, 2) == [("diffuse", 2), ("diffuse", 0)] and dif(0, 0) == [] and dif(0, 1) == []
 	assert dif(1, 1) == [("diffuse", 5)] and dif(1, 0) == [] and dif(1, 2) == []
+
+
+def test_assign_diffusers_is_deterministic_balanced_and_keeps_lines_at_home_when_it_can():
+	assert D.assign_diffusers([0, 0], 8) == [0, 1]                       # configs[3] without a scorer: both winners on rank 0 -> ranks 0 and 1 diffuse
+	assert D.assign_diffusers([0, 0, 0, 0], 4) == [0, 1, 2, 3]
+	assert D.assign_diffusers([0, 1, 0], 2) == [0, 1, 0]                 # already balanced: nothing travels
+	assert D.assign_diffusers([3, 3, 3], 4) == [3, 0, 1]                 # the nearest idle ranks after the owner
+	assert D.assign_diffusers([1, 1, 1, 1, 1], 2) == [1, 0, 1, 0, 1]
+	for owners, world in (([0] * 7, 3), ([2, 2, 0, 1, 2, 2], 3)):
+		a = D.assign_diffusers(owners, world)
+		load = [a.count(r) for r in range(world)]
+		assert max(load) - min(load) <= 1
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_lines_spread_their_diffusions_over_the_ranks(world):
+	"""`world` lines whose winners all live on rank 0 -- every rank diffuses exactly one line (its item arrives by broadcast from
+	rank 0), each line's result equals its own sharded_candidates result and the unspread run's"""
+	got = _run_ranks(_body_spread_lines, world=world)
+	Lmax = max(3 + (c * 5) % 4 for c in range(7))
+	want_ids = torch.stack([_FakeStages.row(c, Lmax) for c in range(7)])
+	want_mel = (want_ids[0].float().sum() * 1.5).view(1, 1, 1) + torch.arange(12.0).view(1, 3, 4)
+	for r in range(world):
+		for spread in (True, False):
+			for k in range(world):
+				res = got[r][spread]["res"][k]
+				assert torch.equal(res["ids"], want_ids) and res["best"] == 0 and res["scores"] is None and torch.equal(res["mel"], want_mel)
+		assert got[r][True]["batches"] == [1]                              # one line per rank ...
+		dif = [(k, c) for k in range(world) for c in got[r][True]["calls"][k] if c[0] == "diffuse"]
+		assert dif == [(r, ("diffuse", 0))]                                # ... line r on rank r, run through line r's stages
+		assert got[r][False]["batches"] == ([world] if r == 0 else [])     # unspread: rank 0 diffuses all of them as one batch

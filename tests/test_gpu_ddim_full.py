@@ -1,0 +1,167 @@
+"""The WHOLE configs[1] diffusion against the reference, in every arithmetic mode that is timed.
+
+  diff_cfg1_loop.npz  the reference's `sample_loop(sampler="ddim")` (diffusion.py:734-810) run in the build container: full-size DiffusionTTS, T = 1088
+                      frames, all 80 DDIM steps with the ramped conditioning-free guidance, from seeded start noise; x after 8 / 16 / 40 / 72 steps on
+                      every 8th frame and the final mel whole (oracle/make_golden.py: diff_cfg1_loop_case).
+  e2e_cfg1.npz        one configs[1] utterance through the reference's modules in f32, in inference.py:334-413's order: 250 codes drawn by the
+                      reference's own sample_stream -> forward(return_latent=True) -> timestep_independent -> the same 80-step loop -> mel
+                      (oracle/make_golden.py: e2e_cfg1_case).
+
+The product runs the loop through `ttk_diff_sample_ddim` in chunks that end at the stored checkpoints (a chunk of k steps is the whole-loop entry on
+k consecutive schedule entries: same launches, same two-stream pipeline), so the error is read where the reference's x was stored.  The bounds below
+are the stated tolerance of `north_star` for the diffused mel at the benchmarked size; DESIGN.md section 2 quotes the measured growth.  Measured values
+are also written to gpurun_out/ddim_full_errors.json.  GPU only; calls go through the C ABI."""
+import json
+import os
+
+import pytest
+import torch
+
+import tortoise_oracle as O
+from tortoise_tts_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECKPOINTS = (8, 16, 40, 72, 80)
+
+# Stated tolerances at every checkpoint (x after n of the 80 steps) and for the final mel (n = 80, values in [-1, 1]).
+# f32: absolute; 16-bit / fp8 modes: relative L2 against the reference's f32 x.
+LOOP_BOUNDS = {
+	"f32": dict(kind="abs", at={8: 2e-3, 16: 2e-3, 40: 4e-3, 72: 8e-3, 80: 1e-2}),
+	"f16": dict(kind="rel", at={8: 2e-3, 16: 3e-3, 40: 8e-3, 72: 2e-2, 80: 3e-2}),
+	"bf16": dict(kind="rel", at={8: 1e-2, 16: 2e-2, 40: 5e-2, 72: 1.2e-1, 80: 1.6e-1}),
+	"fp8w": dict(kind="rel", at={8: 2e-2, 16: 4e-2, 40: 1e-1, 72: 2.5e-1, 80: 3.5e-1}),
+	"fp8": dict(kind="rel", at={8: 3e-2, 16: 6e-2, 40: 1.5e-1, 72: 3.5e-1, 80: 5e-1}),
+}
+# the end-to-end chain adds the latent pass and timestep_independent in the same arithmetic in front of the loop
+E2E_BOUNDS = {
+	"f32": dict(kind="abs", lat=1e-3, E=2e-3, at={8: 2e-3, 16: 2e-3, 40: 4e-3, 72: 8e-3, 80: 1e-2}),
+	"bf16": dict(kind="rel", lat=3e-2, E=3e-2, at={8: 1e-2, 16: 2e-2, 40: 6e-2, 72: 1.5e-1, 80: 2e-1}),
+	"fp8": dict(kind="rel", lat=8e-2, E=8e-2, at={8: 3e-2, 16: 6e-2, 40: 1.5e-1, 72: 3.5e-1, 80: 5e-1}),
+}
+
+
+def gen(seed):
+	return torch.Generator().manual_seed(seed)
+
+
+def maxerr(a, b):
+	return (torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max().item()
+
+
+def relerr(a, b):
+	a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+	return ((a - b).norm() / b.norm()).item()
+
+
+def record(name, values):
+	path = os.path.join(ROOT, "gpurun_out", "ddim_full_errors.json")
+	try:
+		os.makedirs(os.path.dirname(path), exist_ok=True)
+		data = json.load(open(path)) if os.path.exists(path) else {}
+		data[name] = values
+		json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+	except OSError:
+		pass
+
+
+def loop_with_checkpoints(model, noise, E, T):
+	"""x after 8 / 16 / 40 / 72 / 80 steps of the 80-step schedule, the loop issued as five calls of the whole-loop entry"""
+	from tortoise_tts_amd import _lib
+	from tortoise_tts_amd.diffusion import get_diffuser
+	d = get_diffuser(steps=80, cond_free=True)
+	coefs = [d.step_coefs(i, "ddim") for i in range(80)]
+	x = noise.to(DEV).clone()
+	Ed = E.to(DEV, torch.float32).contiguous()
+	out, done = {}, 0
+	for n in CHECKPOINTS:
+		k, lo = n - done, 80 - n                     # schedule entries lo .. lo + k - 1, run from the highest down
+		steps = (_lib.StepC * k)(*coefs[lo:lo + k])
+		_lib.check(model.lib.ttk_diff_sample_ddim(model._h, x.data_ptr(), Ed.data_ptr(), 1, T, steps, k, _lib.stream_ptr()), "ttk_diff_sample_ddim")
+		torch.cuda.synchronize()
+		out[n] = x.clone()
+		done = n
+	return out
+
+
+def check_loop(got, g, bounds, tag):
+	st = int(g["stride"])
+	errs = {}
+	fn = maxerr if bounds["kind"] == "abs" else relerr
+	for n in CHECKPOINTS:
+		want = torch.from_numpy(g["mel"] if n == 80 else g[f"x_after_{n}_sub"])
+		have = got[n] if n == 80 else got[n][:, :, ::st]
+		errs[n] = fn(have, want)
+	record(tag, {"kind": bounds["kind"], **{str(n): errs[n] for n in CHECKPOINTS}})
+	for n in CHECKPOINTS:
+		assert errs[n] < bounds["at"][n], (tag, n, errs)
+	assert torch.isfinite(got[80]).all() and got[80].abs().max() <= 1.0 + 1e-5      # the last step returns the clamped x0
+	return errs
+
+
+@pytest.fixture(scope="module")
+def diff_sd():
+	return W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 1)
+
+
+@pytest.fixture(scope="module")
+def loop_case(golden, diff_sd):
+	g = golden("diff_cfg1_loop")
+	M, T = int(g["M"]), int(g["T"])
+	assert T == O.mel_frames_for(M) == 1088 and int(g["steps"]) == 80 and tuple(g["checkpoints"]) == CHECKPOINTS
+	lat = torch.randn(1, M, 1024, generator=gen(11))
+	dcond = torch.randn(1, 2048, generator=gen(12))
+	noise = torch.randn(1, 100, T, generator=gen(14))
+	with torch.inference_mode():      # every mode starts from the oracle's f32 E (equal to the reference's: test_gpu_bench_shapes.py), so the LOOP is what is compared
+		E = O.DiffusionOracle(diff_sd, W.DIFF_FULL).timestep_independent(lat, dcond, T)
+	return g, noise, E, T
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16", "fp8w", "fp8"])
+def test_whole_80_step_ddim_loop_at_T1088_against_the_reference(diff_sd, loop_case, dtype):
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	g, noise, E, T = loop_case
+	model = DiffusionTTS(diff_sd, W.DIFF_FULL, dtype=dtype, device=DEV)
+	got = loop_with_checkpoints(model, noise, E, T)
+	check_loop(got, g, LOOP_BOUNDS[dtype], f"loop_{dtype}")
+
+
+def test_chunked_loop_equals_the_one_call_loop(diff_sd, loop_case):
+	"""the five chunk calls above ARE the 80-step loop: bit for bit the single `sample_loop` call the product path makes (bf16, the timed mode)"""
+	from tortoise_tts_amd.diffusion import DiffusionTTS, get_diffuser
+	g, noise, E, T = loop_case
+	model = DiffusionTTS(diff_sd, W.DIFF_FULL, dtype="bf16", device=DEV)
+	got = loop_with_checkpoints(model, noise, E, T)[80]
+	one = get_diffuser(steps=80, cond_free=True).sample_loop(model, (1, 100, T), sampler="ddim", noise=noise.to(DEV), model_kwargs={"precomputed_aligned_embeddings": E.to(DEV)})
+	assert torch.equal(got, one)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
+def test_end_to_end_chain_codes_to_mel_against_the_reference(golden, diff_sd, dtype):
+	"""the reference's codes teacher-forced: latent pass -> timestep_independent -> 80 DDIM steps, every stage in `dtype` feeding the next (no oracle
+	value is substituted in between), against the reference's f32 chain"""
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	g = golden("e2e_cfg1")
+	M, T, st = int(g["M"]), int(g["T"]), int(g["stride"])
+	assert (M, T) == (250, 1088)
+	text = torch.randint(1, 255, (1, 64), generator=gen(1234))
+	gg = gen(1235)
+	cond = torch.randn(1, 1024, generator=gg)
+	dcond = torch.randn(1, 2048, generator=gg)
+	noise = torch.randn(1, 100, T, generator=gen(1236))
+	codes = torch.from_numpy(g["codes"])
+	b = E2E_BOUNDS[dtype]
+	fn = maxerr if b["kind"] == "abs" else relerr
+	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtype=dtype, device=DEV, max_batch=1, max_ctx=64 + 4 + M + 8)
+	with torch.inference_mode():
+		lat = ar.forward(cond.to(DEV), text.to(DEV), torch.tensor([64], dtype=torch.int32), codes.to(DEV), torch.tensor([M * 1024]), return_latent=True, clip_inputs=False)
+		del ar
+		df = DiffusionTTS(diff_sd, W.DIFF_FULL, dtype=dtype, device=DEV)
+		E = df.timestep_independent(lat, dcond.to(DEV), T, False)
+		e_lat, e_E = fn(lat[:, :, ::st], g["latents_sub"]), fn(E[:, :, ::st], g["E_sub"])
+		record(f"e2e_{dtype}_front", {"kind": b["kind"], "latents": e_lat, "E": e_E})
+		assert e_lat < b["lat"] and e_E < b["E"], (e_lat, e_E)
+		got = loop_with_checkpoints(df, noise, E, T)
+	check_loop(got, g, b, f"e2e_{dtype}")

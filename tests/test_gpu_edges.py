@@ -160,6 +160,8 @@ def test_a_second_generation_while_a_stream_is_open_is_refused(small_ar):
 		model.inference_speech(cond, text, max_generate_length=10, **kw)
 	with pytest.raises(_lib.TTKError, match="streamed generation is still open"):
 		next(g2)
+	with pytest.raises(_lib.TTKError, match="streamed generation is still open"):      # a line batch would overwrite the open stream's cache and latent ring
+		model.inference_speech_lines(cond, [text, text[:, :5]], max_generate_length=10, **kw)
 	rest = [t.clone() for t, _ in g1]                                                 # the open stream is unharmed by the refused calls
 	want = model.inference_speech(cond, text, max_generate_length=10, **kw)
 	assert torch.equal(torch.stack([first] + rest, 1), want)
@@ -184,6 +186,26 @@ def test_streaming_generator_twice_on_one_model_keeps_both_latent_sets(small_ar)
 	assert not torch.equal(lat_a, lat_b)                                                                   # (a different voice gives different latents)
 	assert torch.equal(torch.stack([l for _, l in out_a], 0), lat_a)                                       # the first call's views were not written by the later ones
 	assert torch.equal(torch.stack([l for _, l in out_b], 0), lat_b)
+
+
+def test_streamed_tokens_outlive_later_generations_of_the_same_shape(small_ar):
+	"""the yielded tokens are the caller's, as the reference's fresh tensors are (stream_generator.py:1172) -- a consumer that collects the
+	yielded tensors and stacks them AFTER another generation of the same shape (streamed or not; both share the cached state's id buffer) must
+	still see its own tokens"""
+	model, _ = small_ar
+	text = torch.randint(1, 255, (1, 9), generator=gen(80)).to(DEV)
+	kw = dict(temperature=0.9, top_k=0, do_sample=True, num_return_sequences=4)
+	cond_a, cond_b = (torch.randn(1, 128, generator=gen(s)).to(DEV) for s in (81, 82))
+	ids = model.compute_embeddings(cond_a, text)
+	held = [t for t, _ in model.get_generator(inputs=ids, max_length=ids.shape[1] + 12, **kw)]          # not cloned: kept as yielded
+	torch.cuda.synchronize()
+	want = torch.stack(held, 1).clone()
+	other = model.inference_speech(cond_b, text, max_generate_length=12, **kw)                            # same (B, max_new, warpers) state, non-streamed
+	ids_b = model.compute_embeddings(cond_b, text)
+	list(model.get_generator(inputs=ids_b, max_length=ids_b.shape[1] + 12, **kw))                         # and streamed
+	torch.cuda.synchronize()
+	assert not torch.equal(other[:, :want.shape[1]], want[:, :other.shape[1]])                            # the later runs really produced other tokens
+	assert torch.equal(torch.stack(held, 1), want)
 
 
 @pytest.mark.parametrize("b,M,T", [(1, 1, 4), (2, 7, 30), (1, 40, 174), (3, 70, 129)])

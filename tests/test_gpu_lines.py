@@ -105,3 +105,22 @@ def test_typical_sampling_in_line_batches_and_against_the_torch_op_form():
 		assert torch.equal(a, b) and torch.cuda.default_generators[0].get_offset() == off_a
 	with pytest.raises(NotImplementedError):
 		ar.inference_speech_lines(al, _texts([5, 8]), num_return_sequences=2, do_sample=True, input_tokens=torch.zeros(1, 2))
+
+
+@pytest.mark.parametrize("penalty,graph", [(1.0, True), (2.0, True), (2.0, False)])
+def test_hf_exact_top_p_line_batches_equal_the_per_line_calls(penalty, graph):
+	"""hf_exact_top_p=True with top_p < 1 sends a LINE BATCH through the torch-op warper chain in front of the kernel (in_kernel=False, lines > 1):
+	graphable without a repetition penalty (no growing history slice), eager with one.  Each line must still equal its own call, generator position included,
+	and -- away from f32 cumsum ties -- the in-kernel cut of a default model"""
+	cfg = W.AR_SMALL
+	exact = _model(cfg, "f32", max_batch=12, max_ctx=128, hf_exact_top_p=True, use_graph=graph)
+	al = torch.randn(1, cfg.model_dim, generator=torch.Generator().manual_seed(13)).to(DEV)
+	kw = dict(do_sample=True, temperature=0.8, top_k=24, top_p=0.85, repetition_penalty=penalty, max_generate_length=30)
+	texts = _texts([11, 4, 26], seed=14)
+	want = _check(exact, al, texts, 4, kw)
+	st = next(reversed(exact._states.values()))
+	assert st.lines == 3 and not st.in_kernel and st.graphable == (penalty == 1.0)
+	plain = _model(cfg, "f32", max_batch=12, max_ctx=128, use_graph=graph)
+	with torch.inference_mode():
+		got = plain.inference_speech_lines(al, texts, num_return_sequences=4, **kw)
+	assert all(torch.equal(a, b) for a, b in zip(got, want))

@@ -99,6 +99,7 @@ SYMBOLS = {
 	"ttk_gemm_nt": (_I, [_I, _P, _P, _I, _I, _I, C.c_float, _P, _P, _P]),
 	"ttk_fp8_round_weights": (_I, [_P, _L, C.POINTER(C.c_float), _P]),
 	"ttk_sample_step": (_I, [_P, _L, _I, _I, _P, _L, _P, C.c_float, _L, _P, _P, _P, _L, _L, _P, _P, _L, _L, _P, _P, _P]),
+	"ttk_ar_decode_geometry": (_I, [_I, _I, _I, C.POINTER(C.c_int32)]),
 	"ttk_diff_create": (_I, [C.POINTER(_P), C.POINTER(DiffConfigC), C.POINTER(WeightView), _I]),
 	"ttk_diff_destroy": (_I, [_P]),
 	"ttk_diff_precompute": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),

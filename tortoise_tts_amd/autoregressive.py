@@ -237,6 +237,7 @@ class UnifiedVoice:
 
 	def _generate_lines(self, cond, texts, C, max_generate_length, kw, typical_mass=None):
 		c = self.cfg
+		self._require_idle()            # a line batch rewrites the KV cache, the noise arming and (through the ring) an open stream's latent buffer
 		G = len(texts)
 		B = G * C
 		if B > self.max_batch:
@@ -455,8 +456,8 @@ class UnifiedVoice:
 		the step's LayerNorm launch fills directly (ttk_ar_set_hidden_ring: the slot index is the device-side token counter, so the captured launch
 		serves every step).  The host runs LAG steps ahead of the consumer; HF's `unfinished_sequences.max() == 0` test (a host round trip per
 		token) is the pinned word the sampling kernel leaves -- the token count at which the last row finished -- read after the event of the
-		token about to be yielded.  The yielded tensors are views: the latents stay valid after the generator ends, the tokens until the next
-		generation of the same shape on this model."""
+		token about to be yielded.  The yielded tensors are slots of two per-call buffers (tokens [max_new, B], latents [max_new, B, d]): like the
+		reference's fresh tensors they stay valid whatever runs on the model afterwards."""
 		c = self.cfg
 		LAG = 2
 		self._require_idle()            # (a generator body runs at its first next(): two generators may have been created, only one may run)
@@ -469,6 +470,9 @@ class UnifiedVoice:
 			if st.own_rng:
 				st.arm_noise(gen, 0)
 			hid = torch.empty((max_new, B, c.model_dim), device=self.device, dtype=torch.float32)
+			# the yielded tokens get this call's lifetime too, as the reference's fresh tensors have (stream_generator.py:1172): `st.ids` belongs to the
+			# cached generation state, which the next generation of the same shape -- streamed or not -- refills
+			toks = torch.empty((max_new, B), device=self.device, dtype=torch.long)
 			fast = self.use_graph and st.graphable and st.own_rng        # captured step; else the same launches issued eagerly
 			n_done = 0
 			self._streaming = True
@@ -511,7 +515,8 @@ class UnifiedVoice:
 						events.append(ev)
 						produced += 1
 					events[n_done].synchronize()                               # token n_done and its flag are there
-					yield st.ids[:, n_done], hid[n_done]
+					toks[n_done].copy_(st.ids[:, n_done])
+					yield toks[n_done], hid[n_done]
 					n_done += 1
 					end = int(st.done[0]) if can_stop else 0                   # tokens sampled when the last row finished (0: still running)
 					if n_done >= max_new or (end and end <= n_done):

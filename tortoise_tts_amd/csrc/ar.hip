@@ -90,6 +90,8 @@ struct ttk_ar {
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
 	void *attn_out, *hbuf;  // T [max_batch][d], [max_batch][4d]
 	void* x_frag = nullptr; // T copy of x in A-fragment order [m_tile][d/32][64][8]: operand of the folded-LayerNorm launches
+	int poison = 0;         // TTK_DEBUG_POISON=1: the dense passes' scratch (ws_*) is filled with 0xFF when a prefill / latent pass ends -- nothing may read it afterwards
+	int frag_rows = 0;      // rows attn_out / hbuf / x_frag were allocated (and zeroed) for: 16 * decode_row_tiles(max_batch)
 	int shared_rows = 0;    // leading cache rows that are identical for all candidates of the current generation (AttnDecodeParams.shared_rows)
 	int share_prefix = 1;   // TTK_AR_SHARE_PREFIX=0: every candidate reads its own copy
 	// multinomial noise drawn by the mel-head launch (ttk_ar_set_noise): device RngArgs, per-row draw counters, q rows of this handle's candidates
@@ -119,6 +121,15 @@ struct ttk_ar {
 	int B = 0, P = 0, k = 0, ready = 0;
 	int Pmax = 0;           // longest prefix of the batch (capacity checks); == P for one line
 };
+
+// Debug aid: per-call scratch must not outlive its call.  A captured token step that kept reading one of these buffers would see
+// NaN patterns from here on (tests/test_gpu_reuse.py runs the reuse scenarios under the flag).
+static int poison_scratch(ttk_ar* h, hipStream_t s) {
+	if (!h->poison) return TTK_OK;
+	for (WsBuf* w : {&h->ws_x, &h->ws_a, &h->ws_qkv, &h->ws_ao, &h->ws_h})
+		if (w->p) TTK_HIP(hipMemsetAsync(w->p, 0xFF, w->cap, s));
+	return TTK_OK;
+}
 
 static int dense_forward(ttk_ar* h, float* x, int B, int S, bool write_kv, hipStream_t s, int kv_row0 = 0, int kv_t0 = 0) {
 	const int d = h->cfg.model_dim, H = h->cfg.heads, dt = h->dt;
@@ -323,7 +334,10 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	// Fragment-order operands of the decode launches, [m_tile][k-step][lane]: the kernels are instantiated for 1, 2 or 4 sixteen-row tiles (csrc/gemv.hip:
 	// gemv_mt) and request EVERY tile of their instantiation, so 33..48 rows read a fourth tile: it must exist (each buffer is its own allocation; a
 	// read past its end is a fault whenever the driver has not mapped anything behind it) and hold zeros, like the padding rows inside a tile.
-	const size_t frag_rows = cfg->max_batch <= 16 ? 16 : (cfg->max_batch <= 32 ? 32 : 64);
+	const size_t frag_rows = (size_t)16 * decode_row_tiles(cfg->max_batch);      // the SAME function the launchers pick their instantiation with
+	h->frag_rows = (int)frag_rows;
+	for (int B = 1; B <= cfg->max_batch; ++B)      // every batch this handle accepts: the tiles its launches request exist
+		if (16 * decode_row_tiles(B) > h->frag_rows) { set_error("ttk_ar_create: %d rows would request %d fragment rows, %d allocated", B, 16 * decode_row_tiles(B), h->frag_rows); return fail(TTK_E_STATE); }
 	AR_TRY(h->arena.alloc(&h->attn_out, frag_rows * d * h->es));
 	if (hipMemset(h->attn_out, 0, frag_rows * d * h->es) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc(&h->hbuf, frag_rows * 4 * d * h->es));
@@ -334,6 +348,8 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	AR_TRY(h->arena.alloc((void**)&h->tickets, (size_t)4 * (d / 16) * sizeof(int)));
 	if (hipMemset(h->tickets, 0, (size_t)4 * (d / 16) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
 	{
+		const char* ep = getenv("TTK_DEBUG_POISON");
+		h->poison = ep && atoi(ep) != 0;
 		const char* en = getenv("TTK_AR_NARROW");
 		h->narrow = en ? atoi(en) : 4;                    // 0 = 16-column workgroups (+ split-K for mlp.c_proj), 2 / 4 = workgroups per tile
 		const char* ef = getenv("TTK_AR_HFRAG");
@@ -408,6 +424,7 @@ int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* t
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, S, s);
 	launch_set_int(h->d_pos + 1, shared ? S : 0, s);      // rows of the shared prefix (AttnDecodeParams.shared_rows): device-resident, like the cache length
+	TTK_TRY(poison_scratch(h, s));
 	h->B = B; h->P = h->Pmax = Tt + 3; h->k = 0; h->ready = 1; h->lines_mode = 0;
 	h->shared_rows = shared ? S : 0;
 	TTK_HIP(hipGetLastError());
@@ -451,6 +468,7 @@ int ttk_ar_prefill_lines(ttk_ar* h, const float* cond_latents, const int64_t* te
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, Smax, s);
 	launch_set_int(h->d_pos + 1, Smax, s);
+	TTK_TRY(poison_scratch(h, s));
 	h->B = B; h->P = h->Pmax = Smax - 1; h->k = 0; h->ready = 1; h->lines_mode = 1;
 	h->shared_rows = Smax;
 	TTK_HIP(hipGetLastError());
@@ -463,6 +481,8 @@ static int decode_impl(ttk_ar* h, const int64_t* tok, float* logits_out, float* 
 	const ttk_ar_config& c = h->cfg;
 	const int B = h->B, d = c.model_dim;
 	TTK_REQUIRE(h->Pmax + 1 + h->k + 1 <= c.max_ctx, TTK_E_STATE, "%s: KV cache full (max_ctx=%d)", who, c.max_ctx);
+	TTK_REQUIRE(B <= c.max_batch && 16 * decode_row_tiles(B) <= h->frag_rows, TTK_E_STATE, "%s: %d rows request %d fragment rows, the handle holds %d (max_batch=%d)", who, B,
+				16 * decode_row_tiles(B), h->frag_rows, c.max_batch);
 	TTK_REQUIRE((h->lnfold && h->nsplit == 1) || B <= 32, TTK_E_STATE, "%s: the LayerNorm-prologue decode kernels (TTK_AR_LNFOLD=0 / TTK_AR_SPLIT) hold at most 32 candidates' rows in LDS; B=%d", who, B);
 	TTK_REQUIRE(h->k + 2 < c.max_mel_seq_len, TTK_E_STATE, "%s: mel position table exhausted (%d rows)", who, c.max_mel_seq_len);
 	TTK_REQUIRE(!h->ring_base || (h->head_split && h->nsplit == 1), TTK_E_STATE, "%s: the hidden ring needs the default decode form (TTK_AR_HEAD_SPLIT=1, TTK_AR_SPLIT=1)", who);
@@ -531,6 +551,19 @@ int ttk_ar_set_hidden_ring(ttk_ar* h, float* base, const int64_t* index, int64_t
 	return TTK_OK;
 }
 
+int ttk_ar_decode_geometry(int dtype, int max_batch, int rows, int32_t out[4]) {
+	TTK_REQUIRE(out, TTK_E_ARG, "ttk_ar_decode_geometry: null argument");
+	TTK_REQUIRE(dtype == TTK_F32 || dtype == TTK_BF16 || dtype == TTK_F16 || dtype == TTK_FP8W || dtype == TTK_FP8, TTK_E_ARG, "ttk_ar_decode_geometry: bad dtype %d", dtype);
+	const int cap = dtype == TTK_F32 ? 32 : 64;
+	TTK_REQUIRE(max_batch >= 1 && max_batch <= cap, TTK_E_ARG, "ttk_ar_decode_geometry: max_batch %d out of range (1..%d)", max_batch, cap);
+	TTK_REQUIRE(rows >= 1 && rows <= max_batch, TTK_E_ARG, "ttk_ar_decode_geometry: rows %d outside 1..max_batch=%d", rows, max_batch);
+	out[0] = 16 * decode_row_tiles(max_batch);      // rows ttk_ar_create allocates (and zeroes) per fragment-order operand
+	out[1] = decode_row_tiles(rows);                // sixteen-row tiles of the instantiation a launch over `rows` rows runs
+	out[2] = 16 * out[1];                           // rows that launch requests
+	out[3] = max_batch;                             // candidate slices of the KV cache
+	return TTK_OK;
+}
+
 int ttk_ar_health(ttk_ar* h, int* flags_out, void* stream) {
 	TTK_REQUIRE(h && flags_out, TTK_E_ARG, "ttk_ar_health: null argument");
 	hipStream_t s = (hipStream_t)stream;
@@ -568,6 +601,7 @@ int ttk_ar_latents(ttk_ar* h, const float* cond, const int64_t* text, int Tt, co
 	for (int b = 0; b < B; ++b)
 		launch_layernorm(h->dt, x + ((size_t)b * S + Tt + 3) * d, d, M, d, h->lnf_g, h->lnf_b, h->fn_g, h->fn_b,
 						 latents_out + (size_t)b * M * d, d, 1, s);
+	TTK_TRY(poison_scratch(h, s));
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
 }

@@ -302,9 +302,10 @@ static void gemv_go(const GemvParams& p, hipStream_t s, hipEvent_t ea, hipEvent_
 
 template <typename T, int ROLE, int NW, int KPW, bool W8>
 static void gemv_mt(const GemvParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-	if (p.M <= 16) gemv_go<T, 1, ROLE, NW, KPW, W8>(p, s, ea, eb);
-	else if (p.M <= 32) gemv_go<T, 2, ROLE, NW, KPW, W8>(p, s, ea, eb);
-	else if (sizeof(T) == 2) gemv_go<T, sizeof(T) == 2 ? 4 : 2, ROLE, NW, KPW, W8>(p, s, ea, eb);
+	const int mt = decode_row_tiles(p.M);
+	if (mt == 1) gemv_go<T, 1, ROLE, NW, KPW, W8>(p, s, ea, eb);
+	else if (mt == 2) gemv_go<T, 2, ROLE, NW, KPW, W8>(p, s, ea, eb);
+	else if (sizeof(T) == 2) gemv_go<T, sizeof(T) == 2 ? 4 : 2, ROLE, NW, KPW, W8>(p, s, ea, eb);      // (f32 batches end at 32 rows: gemv_supported)
 }
 
 // the (waves, k-steps per wave) the decode step uses per role and type: 16-bit 4 x 8 (K = 1024) / 8 x 16 (K = 4096); f32 batches are 4

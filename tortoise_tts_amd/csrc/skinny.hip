@@ -462,8 +462,9 @@ static void launch_skinny_mt(const SkinnyParams& p, int waves, hipStream_t s, hi
 
 template <typename T, bool W8>
 static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-	if (p.M <= 16) launch_skinny_mt<T, 1, W8>(p, waves, s, ea, eb);
-	else if (p.M <= 32) launch_skinny_mt<T, 2, W8>(p, waves, s, ea, eb);
+	const int mt = decode_row_tiles(p.M);
+	if (mt == 1) launch_skinny_mt<T, 1, W8>(p, waves, s, ea, eb);
+	else if (mt == 2) launch_skinny_mt<T, 2, W8>(p, waves, s, ea, eb);
 	else launch_skinny_mt<T, 4, W8>(p, waves, s, ea, eb);
 }
 

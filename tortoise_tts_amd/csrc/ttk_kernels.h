@@ -119,6 +119,11 @@ void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s);
 // folded), one compile-time specialisation per role; bit-identical to k_skinny on the same operands.  launch_gemv returns false (and launches
 // nothing) for a geometry it has no instantiation for: the caller then takes launch_skinny.
 enum GemvRole { GV_QKV = 0, GV_PROJ = 1, GV_FC = 2, GV_HEAD = 3 };
+// Sixteen-row tiles a decode launch is INSTANTIATED for when the batch has M rows (k_gemv / k_skinny: MT = 1, 2 or 4).  A launch requests EVERY tile of
+// its instantiation from the fragment-order operands, so the buffers behind them must hold 16 * decode_row_tiles(max_batch) rows: ttk_ar_create sizes
+// them with this function and every decode entry re-checks it (round 3's fault was a create-time size derived from max_batch alone).
+inline int decode_row_tiles(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
+
 struct GemvParams {
 	const void* Wp;             // weights in fragment order [n_tile][K/32][lane][8] (GV_QKV / GV_FC: gamma o W)
 	const void* a;              // rows in A-fragment order [m_tile][K/32][lane][8], T-typed, rows >= M zero (GV_QKV / GV_FC: un-normalised)

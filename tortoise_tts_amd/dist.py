@@ -118,6 +118,58 @@ class ShardStages:
 		"""mels of the prepared items, as one batch where the implementation can; default: one `diffuse` per item"""
 		return [self.diffuse(c, l) for c, l in prepared]
 
+	# a prepared item travels when its diffusion is assigned to another rank than the winner's owner (assign_diffusers)
+	def pack_prepared(self, prepared) -> List[torch.Tensor]:
+		"""the tensors of a prepared item, in an order `unpack_prepared` understands"""
+		return list(prepared)
+
+	def unpack_prepared(self, tensors: List[torch.Tensor]):
+		return tuple(tensors)
+
+
+def assign_diffusers(owners: List[int], world: int) -> List[int]:
+	"""Which rank diffuses which line.  A text's lines are independent DDIM loops (utterances / lines shard naturally), so they are
+	spread over the ranks instead of piling up on the winners' owners (without a scorer every line's winner is candidate 0 = rank 0, and the other
+	ranks idled through more than half of a configs[3] step).  Greedy in line order, a pure function of (owners, world) so every rank computes the same
+	answer without talking: a line stays on its owner while the owner is among the least loaded ranks (nothing travels), else it goes to the least
+	loaded rank, the nearest one after the owner first.  Lines that land on one rank still run as one ragged batch there."""
+	load = [0] * world
+	out = []
+	for o in owners:
+		m = min(load)
+		r = o if load[o] == m else min((q for q in range(world) if load[q] == m), key=lambda q: (q - o) % world)
+		load[r] += 1
+		out.append(r)
+	return out
+
+
+_DTYPES = (torch.float32, torch.int64, torch.int32, torch.float64, torch.bfloat16, torch.float16)
+
+
+def _move_item(tensors: Optional[List[torch.Tensor]], src: int, dev, group=None) -> List[torch.Tensor]:
+	"""a prepared item from group rank `src` to every rank of the group (the receiver that needs it keeps it): one header broadcast (count, dtype,
+	shape) + one broadcast per tensor, on the communicator the mel broadcast uses anyway.  <= 2 MB per line (latents [1, L, d] + start noise [1, 100, T])."""
+	rank = dist.get_rank(group)
+	gsrc = dist.get_global_rank(group, src) if group is not None else src
+	head = torch.zeros(1 + 8 * 6, dtype=torch.long, device=dev)
+	if rank == src:
+		assert len(tensors) <= 8 and all(t.dim() <= 4 for t in tensors)
+		head[0] = len(tensors)
+		for i, t in enumerate(tensors):
+			head[1 + 6 * i] = _DTYPES.index(t.dtype)
+			head[2 + 6 * i] = t.dim()
+			for j, n in enumerate(t.shape):
+				head[3 + 6 * i + j] = n
+	dist.broadcast(head, src=gsrc, group=group)
+	h = head.tolist()
+	out = []
+	for i in range(h[0]):
+		shape = h[3 + 6 * i: 3 + 6 * i + h[2 + 6 * i]]
+		t = tensors[i].to(dev).contiguous() if rank == src else torch.empty(shape, dtype=_DTYPES[h[1 + 6 * i]], device=dev)
+		dist.broadcast(t, src=gsrc, group=group)
+		out.append(t)
+	return out
+
 
 def sharded_candidates(stages: ShardStages, n_candidates: int, group=None):
 	"""One utterance, candidates sharded over the ranks of `group` (weights replicated, no data-path collective):
@@ -154,11 +206,14 @@ def sharded_candidates(stages: ShardStages, n_candidates: int, group=None):
 	return mel, ids, scores, best
 
 
-def sharded_candidates_lines(stages_list, n_candidates: int, group=None):
+def sharded_candidates_lines(stages_list, n_candidates: int, group=None, spread: bool = True):
 	"""`sharded_candidates` for the lines of one text: per line the same exchange (shard sampling, id all-gather, RNG alignment, latent pass and
 	scores on every shard, first maximum wins), with the winner's owner making that line's random draws at once (`prepare_diffusion`: the next
-	line's `generate` reseeds) -- and then ONE diffusion per owner over all the lines it owns (`run_diffusion`: a ragged batch on libttk), the
-	mels broadcast line by line.  Returns [(mel, ids, scores, best)] per line, each equal to that line's own `sharded_candidates` result."""
+	line's `generate` reseeds, so the start noise is drawn where the single-GPU run draws it and TRAVELS with the item) -- then the lines'
+	diffusions are spread over the ranks (`assign_diffusers`; spread=False keeps every line on its winner's owner): a line assigned to another rank
+	than its owner has its prepared item (latents + start noise, <= 2 MB) broadcast inside the group, every rank runs ONE diffusion over the lines
+	assigned to it (`run_diffusion`: a ragged batch on libttk), and the mels are broadcast line by line from where they were made.
+	Returns [(mel, ids, scores, best)] per line, each equal to that line's own `sharded_candidates` result."""
 	world = dist.get_world_size(group)
 	rank = dist.get_rank(group)
 	picked = []
@@ -178,17 +233,24 @@ def sharded_candidates_lines(stages_list, n_candidates: int, group=None):
 			best = candidate_shard(n_candidates, owner, world)[0] + idx
 		prep = st.prepare_diffusion(codes[idx:idx + 1], lat[idx:idx + 1]) if rank == owner else None
 		picked.append(dict(owner=owner, ids=ids, scores=scores, best=best, prep=prep))
-	mine = [k for k, p in enumerate(picked) if p["owner"] == rank]
+	owners = [p["owner"] for p in picked]
+	diffusers = assign_diffusers(owners, world) if spread else owners
+	for k, (p, st) in enumerate(zip(picked, stages_list)):
+		p["diffuser"] = diffusers[k]
+		if diffusers[k] != p["owner"]:      # every rank takes part in the broadcast; only the assigned rank keeps the item
+			moved = _move_item(st.pack_prepared(p["prep"]) if rank == p["owner"] else None, p["owner"], p["ids"].device, group)
+			p["prep"] = st.unpack_prepared(moved) if rank == diffusers[k] else None
+	mine = [k for k, p in enumerate(picked) if p["diffuser"] == rank]
 	mels = {}
 	if mine:
-		# (the LAST owned line's stages run the batch: their phase marks then end with the shared diffusion, right behind that line's own stages)
+		# (the LAST assigned line's stages run the batch: their phase marks then end with the shared diffusion, right behind that line's own stages)
 		for k, m in zip(mine, stages_list[mine[-1]].run_diffusion([picked[k]["prep"] for k in mine])):
 			mels[k] = m.to(torch.float32).contiguous()
 	out = []
 	for k, p in enumerate(picked):
 		dev = p["ids"].device
 		shape = torch.tensor(mels[k].shape, dtype=torch.long, device=dev) if k in mels else torch.zeros(3, dtype=torch.long, device=dev)
-		src = dist.get_global_rank(group, p["owner"]) if group is not None else p["owner"]
+		src = dist.get_global_rank(group, p["diffuser"]) if group is not None else p["diffuser"]
 		dist.broadcast(shape, src=src, group=group)
 		mel = mels[k] if k in mels else torch.empty([int(v) for v in shape], dtype=torch.float32, device=dev)
 		dist.broadcast(mel, src=src, group=group)

@@ -103,9 +103,18 @@ class HotPathStages:
 				torch.randn_like(noise)
 		return latents, noise, T
 
+	def pack_prepared(self, prepared):
+		latents, noise, _ = prepared
+		return [latents.to(torch.float32), noise.to(torch.float32)]
+
+	def unpack_prepared(self, tensors):
+		latents, noise = tensors
+		return latents, noise, int(noise.shape[-1])
+
 	def run_diffusion(self, prepared):
 		"""mels [1, 100, T_i] of the prepared lines: one ragged DDIM batch (SpacedDiffusion.sample_loop_lines) when there are several and the
 		sampler is ddim with conditioning-free guidance, else one loop per line; each mel bit for bit its own loop's either way"""
+		self._mark("_before_ddim")          # what lies between this line's latent pass and the shared diffusion (later lines' sampling, item moves) is not "ddim"
 		Es = [self.diff.timestep_independent(latents, self.dl, T, False) for latents, _, T in prepared]
 		if len(prepared) > 1 and self.sampler == "ddim" and self.diffuser.conditioning_free:
 			mels = self.diffuser.sample_loop_lines(self.diff, [n for _, n, _ in prepared], Es)
@@ -146,7 +155,8 @@ class TTSHotPath:
 		ranks as there, line by line (sample, id gather, latent pass, scores, winner), and the winners are then DIFFUSED TOGETHER -- the lines a rank
 		owns as one ragged DDIM batch (dist.sharded_candidates_lines) -- before the mels are broadcast.  Each line's result equals its own
 		`inference_sharded` call.  phase_marks (measurement only): a list that receives one list of (name, event) per line; the shared
-		diffusion's end is the "ddim" mark of every line it served.  Returns a list of (mels, seconds[, aux])."""
+		diffusion's end is the "ddim" mark of every line it served.  The lines' diffusions are spread over the ranks (dist.assign_diffusers): a line
+		whose winner lives on a busier rank has its latents + start noise sent to an idle one.  Returns a list of (mels, seconds[, aux])."""
 		from . import dist as D
 		stages = []
 		for text in lines:
