@@ -240,6 +240,7 @@ extern "C" {
 
 int ttk_diff_create(ttk_diff** out, const ttk_diff_config* cfg, const ttk_weight_view* w, int n_w) {
 	TTK_REQUIRE(out && cfg && w, TTK_E_ARG, "ttk_diff_create: null argument");
+	gemm_roles_refresh();
 	TTK_REQUIRE(cfg->model_channels % 64 == 0 && cfg->num_heads * 64 == cfg->model_channels, TTK_E_ARG,
 				"ttk_diff_create: head_dim must be 64 (channels %d, heads %d)", cfg->model_channels, cfg->num_heads);
 	TTK_REQUIRE(cfg->in_latent_channels % 64 == 0, TTK_E_ARG, "ttk_diff_create: in_latent_channels %% 64 != 0");

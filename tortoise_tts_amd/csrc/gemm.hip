@@ -153,9 +153,100 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ role-specialised form (GemmRole, ttk_kernels.h)
+// What the stamps of tests/diag/ddim_chain.cpp showed for the generic kernel inside the DDIM layer chain: 1.16-1.52 us from a wave's first instruction to its
+// first DMA request and 1.64-2.44 us of epilogue per launch -- 44 % of the four GEMMs' time outside their k-loops.  The first is ~350 instructions of run-time
+// shape arithmetic issued by one wave per SIMD (integer divisions by the m-tile count and by rows_per_batch, 64-bit address products, the segment table);
+// a role turns all of it into constants, shifts and three f32-reciprocal divisions, and reads a dozen argument words instead of the segment table.
+template <int ROLE> struct GRole { static constexpr bool on = false, RES = false, GN = false, CONV = false; static constexpr int N = 0, NSEG = 1, MODE = 0; };
+template <> struct GRole<GR_IN1x1> { static constexpr bool on = true, RES = false, GN = true, CONV = false; static constexpr int N = 1024, NSEG = 1, MODE = 1; };
+template <> struct GRole<GR_CONV3_RES> { static constexpr bool on = true, RES = true, GN = true, CONV = true; static constexpr int N = 1024, NSEG = 3, MODE = 1; };
+template <> struct GRole<GR_QKV> { static constexpr bool on = true, RES = false, GN = false, CONV = false; static constexpr int N = 3072, NSEG = 1, MODE = 0; };
+template <> struct GRole<GR_PROJ_RES> { static constexpr bool on = true, RES = true, GN = true, CONV = false; static constexpr int N = 1024, NSEG = 1, MODE = 1; };
+constexpr int GR_K = 1024;      // K = lda = ldw of every role
+
+// floor(x / d) for 0 <= x < 2^23 with inv = 1.0f / d: the f32 product is off by less than one, so one correction step either way makes it exact
+__device__ __forceinline__ int div_recip(int x, int d, float inv) {
+	int q = (int)((float)x * inv);
+	const int r = x - q * d;
+	q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+	return q;
+}
+
+// The generic epilogue with the role's decisions taken at compile time: bias always, no activation, no scale; ldc = ldr = N; 32-bit element indices
+// (M * N < 2^30, checked by the dispatcher).  Same operations on every value in the same order: bit-identical results.
+template <typename T, int ROLE, bool GUARD, int MI, int NI>
+__device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[MI][NI], int row0, int col0, int lane) {
+	typedef GRole<ROLE> R;
+	typedef typename OutOf<T>::type OT;
+	constexpr int N = R::N;
+	const int lr = 4 * (lane >> 4), lc = lane & 15;
+	float bj[NI];
+#pragma unroll
+	for (int j = 0; j < NI; ++j) bj[j] = p.bias[col0 + 16 * j + lc];
+	float res[MI][4][NI];
+	if constexpr (R::RES) {      // all residual loads before the first store: C aliases the residual
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int r = 0; r < 4; ++r)
+#pragma unroll
+				for (int j = 0; j < NI; ++j) {
+					const int gm = row0 + 16 * i + lr + r;
+					res[i][r][j] = (!GUARD || gm < p.M) ? p.residual[(unsigned)(gm * N + col0 + 16 * j + lc)] : 0.f;
+				}
+	}
+#pragma unroll
+	for (int i = 0; i < MI; ++i)
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int gm = row0 + 16 * i + lr + r;
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				float v = acc[i][j][r] + bj[j];
+				if constexpr (R::RES) v += res[i][r][j];
+				acc[i][j][r] = v;
+				if (GUARD && gm >= p.M) continue;
+				const unsigned o = (unsigned)(gm * N + col0 + 16 * j + lc);
+				if constexpr (R::MODE == 1) ((float*)p.C)[o] = v;
+				else ((OT*)p.C)[o] = cvt<OT>(v);
+			}
+		}
+	if constexpr (R::GN) {       // fused GroupNorm32 statistics, as in the generic epilogue
+		if (MI == 4 && row0 < p.M) {
+			const int b = div_recip(row0, p.gn_T, p.inv_gn_T), chunk = (row0 - b * p.gn_T) >> 6, nch = p.gn_T >> 6;
+#pragma unroll
+			for (int gq = 0; gq < NI / 2; ++gq) {
+				float sum = 0.f;
+#pragma unroll
+				for (int i = 0; i < MI; ++i)
+#pragma unroll
+					for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) sum += acc[i][2 * gq + jj][r];
+				const float mean = wave_sum(sum) * (1.0f / 2048.0f);
+				float sq = 0.f;
+#pragma unroll
+				for (int i = 0; i < MI; ++i)
+#pragma unroll
+					for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) { const float d = acc[i][2 * gq + jj][r] - mean; sq += d * d; }
+				sq = wave_sum(sq);
+				if (lane == 0) {
+					float* o = p.gn_part + (unsigned)(((b * 32 + (col0 / 32 + gq)) * nch + chunk) * 3);
+					o[0] = 2048.0f; o[1] = mean; o[2] = sq;
+				}
+			}
+		}
+	}
+}
+
 // NWM x NWN waves per workgroup; 8 waves (2 per SIMD) let one wave's MFMAs run under another's LDS reads and DMA issue.
-template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
+	typedef GRole<ROLE> R;
+	static_assert(!R::on || (sizeof(T) == 2 && R::N % BN == 0), "roles are 16-bit, N a multiple of the tile width");
 	constexpr int ES = sizeof(T);
 	constexpr bool F8 = ES == 1;       // fp8 operands: a lane's 16-byte read feeds two 16x16x32 MFMAs (k order is free as long as A and W agree)
 	constexpr int BKE = 128 / ES;      // K elements per tile row
@@ -174,30 +265,41 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	// what the prologue and the first segment read, as one batch of scalar loads (the ~500-byte argument block was fetched in six dependent round trips:
 	// a wave's first DMA request left 1.8 us after its first instruction, 1.2 us with the batch -- tests/diag/ddim_chain.cpp; pinning the epilogue's
 	// fields as well costs more in SGPR pressure than it returns, profiles/r03 notes)
-	TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.N), TTK_S(p.K), TTK_S(p.nseg), TTK_S(p.W), TTK_S(p.ldw), TTK_S(p.rows_per_batch), TTK_S(p.m_major),
-				 TTK_S(p.seg[0].A), TTK_S(p.seg[0].lda), TTK_S(p.seg[0].shift), TTK_S(p.seg[0].w_off));
+	if constexpr (R::on) {
+		if constexpr (R::CONV) TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.tiles_m), TTK_S(p.inv_tiles_m), TTK_S(p.rows_per_batch), TTK_S(p.inv_rpb));
+		else TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.tiles_m), TTK_S(p.inv_tiles_m));
+	} else {
+		TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.N), TTK_S(p.K), TTK_S(p.nseg), TTK_S(p.W), TTK_S(p.ldw), TTK_S(p.rows_per_batch), TTK_S(p.m_major),
+					 TTK_S(p.seg[0].A), TTK_S(p.seg[0].lda), TTK_S(p.seg[0].shift), TTK_S(p.seg[0].w_off));
+	}
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef TTK_STAMPS
 	unsigned long long* const stamps_ = p.stamps;
 #endif
 	TTK_WSTAMP(stamps_, blockIdx.x, 0);
 	const int wm = wave / NWN, wn = wave % NWN;
-	const int tiles_m = (p.M + BM - 1) / BM;
+	const int tiles_m = R::on ? p.tiles_m : (p.M + BM - 1) / BM;
 	// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give
 	// each XCD label (blockIdx % 8) a CONTIGUOUS run of the n-major tile order = a few n-tiles x all m-tiles.  Its private 4 MiB
 	// L2 then holds that weight slice while the activations stream through once, instead of every XCD caching all of W.
 	int tile_id;
 	{
-		const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+		const int nwg = R::on ? tiles_m * (R::N / BN) : (int)gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
 		tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
 	}
 	// p.m_major: the XCD's run of tiles is a few m-tiles x ALL n-tiles instead -- its L2 then holds the whole weight matrix plus an eighth of
 	// the activations, which is the smaller working set when the matrix (N x K) is smaller than the activation panel (M x K)
-	const int tiles_n = (p.N + BN - 1) / BN;
-	const int m0 = p.m_major ? (tile_id / tiles_n) * BM : (tile_id % tiles_m) * BM;
-	const int n0 = p.m_major ? (tile_id % tiles_n) * BN : (tile_id / tiles_m) * BN;
-	const int KT = p.K / BKE;
-	const int NTILES = p.nseg * KT;
+	int m0, n0;
+	if constexpr (R::on) {      // n-major order, no integer division
+		const int tn = div_recip(tile_id, tiles_m, p.inv_tiles_m);
+		m0 = (tile_id - tn * tiles_m) * BM; n0 = tn * BN;
+	} else {
+		const int tiles_n = (p.N + BN - 1) / BN;
+		m0 = p.m_major ? (tile_id / tiles_n) * BM : (tile_id % tiles_m) * BM;
+		n0 = p.m_major ? (tile_id % tiles_n) * BN : (tile_id / tiles_m) * BN;
+	}
+	const int KT = R::on ? GR_K / BKE : p.K / BKE;
+	const int NTILES = R::on ? R::NSEG * KT : p.nseg * KT;
 
 	// Staging addresses.  Both operands go through buffer descriptors: the per-lane byte offset inside the matrix (row, swizzled
 	// chunk) is fixed for a whole segment, the k advance is the instruction's SCALAR offset, and a lane whose row is outside M or
@@ -209,7 +311,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 #pragma unroll
 	for (int i = 0; i < A_PC; ++i) {
 		a_gm[i] = m0 + 8 * (wave + NW * i) + prow;
-		a_t[i] = p.rows_per_batch > 0 ? a_gm[i] % p.rows_per_batch : 0;
+		if constexpr (R::on) a_t[i] = R::CONV ? a_gm[i] - div_recip(a_gm[i], p.rows_per_batch, p.inv_rpb) * p.rows_per_batch : 0;
+		else a_t[i] = p.rows_per_batch > 0 ? a_gm[i] % p.rows_per_batch : 0;
 	}
 	const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
 	constexpr unsigned OOR = 0x80000000u;   // beyond any descriptor's num_records (buffers are < 2 GiB)
@@ -218,13 +321,28 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	for (int i = 0; i < B_PC; ++i) {
 		const int row = 8 * (wave + NW * i) + prow;
 		const int c = pslot ^ (row & 7);                   // logical chunk landing in this lane's slot
-		vb[i] = (unsigned)(((int64_t)(n0 + row) * p.ldw + c * EPC) * ES);
+		if constexpr (R::on) vb[i] = (unsigned)((n0 + row) * (GR_K * ES) + c * 16);
+		else vb[i] = (unsigned)(((int64_t)(n0 + row) * p.ldw + c * EPC) * ES);
 	}
 	const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
 	__amdgpu_buffer_rsrc_t srdA = srdB;
 	unsigned b_seg_off = 0;
 	int seg_i = 0, kk_i = 0;
 	auto set_segment = [&](int sg) {
+		if constexpr (R::on) {      // one activation tensor; a convolution's taps are its rows shifted by -1 / 0 / +1 against consecutive [N][K] matrices
+			const int shift = R::CONV ? sg - 1 : 0;
+			if (sg == 0) srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].A, 0, (unsigned)p.M * (unsigned)(GR_K * ES), 0x00020000);
+			b_seg_off = (unsigned)sg * (unsigned)(R::N * GR_K * ES);
+#pragma unroll
+			for (int i = 0; i < A_PC; ++i) {
+				const int row = 8 * (wave + NW * i) + prow;
+				const int c = pslot ^ (row & 7);
+				const int t = a_t[i] + shift;
+				const bool ok = a_gm[i] < p.M && (!R::CONV || (t >= 0 && t < p.rows_per_batch));
+				va[i] = ok ? (unsigned)((a_gm[i] + shift) * (GR_K * ES) + c * 16) : OOR;
+			}
+			return;
+		}
 		const int64_t lda = p.seg[sg].lda;
 		const int shift = p.seg[sg].shift;
 		srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[sg].A, 0, (unsigned)((int64_t)p.M * lda * ES), 0x00020000);
@@ -362,6 +480,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	TTK_WSTAMPD(stamps_, blockIdx.x, 3, acc[0][0][0]);
 
 	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
+	if constexpr (R::on) {
+		if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI>(p, acc, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI>(p, acc, row0, col0, lane);
+		TTK_WSTAMP(stamps_, blockIdx.x, 4);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		TTK_WSTAMP(stamps_, blockIdx.x, 5);
+#endif
+		return;
+	}
 	const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
 	if (p.transpose_out) { if (full) epilogue<T, 2, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 2, true, MI, NI>(p, acc, row0, col0, lane); }
 	else if (p.out_f32) { if (full) epilogue<T, 1, false, MI, NI>(p, acc, row0, col0, lane); else epilogue<T, 1, true, MI, NI>(p, acc, row0, col0, lane); }
@@ -373,16 +500,54 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 #endif
 }
 
-template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
-static void launch_tile(const GemmParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
+static void launch_tile(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	constexpr int LDS = NSTAGE * (BM + BN) * 128;
 	static bool attr_set = false;
 	if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_set = true;
 	}
-	const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-	hipExtLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE>), dim3(grid), dim3(64 * NWM * NWN), (unsigned)LDS, s, ea, eb, 0, p);
+	GemmParams p = p_in;
+	p.tiles_m = (p.M + BM - 1) / BM;
+	p.inv_tiles_m = 1.0f / (float)p.tiles_m;
+	p.inv_rpb = p.rows_per_batch > 0 ? 1.0f / (float)p.rows_per_batch : 0.f;
+	p.inv_gn_T = p.gn_T > 0 ? 1.0f / (float)p.gn_T : 0.f;
+	const int grid = p.tiles_m * ((p.N + BN - 1) / BN);
+	hipExtLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE>), dim3(grid), dim3(64 * NWM * NWN), (unsigned)LDS, s, ea, eb, 0, p);
+}
+
+// The role of a launch, or GR_NONE: every field a role fixes at compile time must have exactly that value (TTK_GEMM_ROLE=0 switches the roles off: A/B runs and
+// the test that the specialised kernels give the generic kernel's bits; read again by gemm_roles_refresh at every handle creation).
+int g_gemm_roles = -1;
+void gemm_roles_refresh() { const char* e = getenv("TTK_GEMM_ROLE"); g_gemm_roles = e ? atoi(e) : 1; }
+static int gemm_role_of(const GemmParams& p, int es) {
+	if (g_gemm_roles < 0) gemm_roles_refresh();
+	if (!g_gemm_roles || es != 2 || p.K != GR_K || p.ldw != GR_K || !p.bias || p.act != ACT_NONE || p.out_scale != 0.f || p.transpose_out || p.m_major) return GR_NONE;
+	if (p.M < 1 || p.M > (1 << 19) || p.seg[0].lda != GR_K || p.seg[0].w_off != 0) return GR_NONE;      // 32-bit byte offsets and M * N < 2^30 element indices
+	if (p.nseg == 1 && p.seg[0].shift == 0) {
+		if (p.N == 3072 && !p.out_f32 && p.ldc == 3072 && !p.residual && !p.gn_part) return GR_QKV;
+		if (p.N == 1024 && p.out_f32 && p.ldc == 1024 && p.gn_part && p.gn_T > 0) return !p.residual ? GR_IN1x1 : (p.ldr == 1024 ? GR_PROJ_RES : GR_NONE);
+		return GR_NONE;
+	}
+	if (p.nseg == 3 && p.N == 1024 && p.out_f32 && p.ldc == 1024 && p.residual && p.ldr == 1024 && p.gn_part && p.gn_T > 0 && p.rows_per_batch > 0) {
+		for (int j = 0; j < 3; ++j)
+			if (p.seg[j].A != p.seg[0].A || p.seg[j].lda != GR_K || p.seg[j].shift != j - 1 || p.seg[j].w_off != (int64_t)j * 1024 * GR_K) return GR_NONE;
+		return GR_CONV3_RES;
+	}
+	return GR_NONE;
+}
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
+static void launch_tile_role(int role, const GemmParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+	if constexpr (sizeof(T) == 2) {
+		if constexpr (BN <= 128 && BM != 256) {      // the 1024-wide roles run 128 x 64 (one utterance) or 128 x 128 (line batches) tiles
+			if (role == GR_IN1x1) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_IN1x1>(p, s, ea, eb);
+			if (role == GR_CONV3_RES) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_CONV3_RES>(p, s, ea, eb);
+			if (role == GR_PROJ_RES) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_PROJ_RES>(p, s, ea, eb);
+		}
+		if (role == GR_QKV) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_QKV>(p, s, ea, eb);
+	}
+	launch_tile<T, BM, BN, NWM, NWN, NSTAGE>(p, s, ea, eb);
 }
 
 int g_force_tile = -1;   // TTK_GEMM_TILE=0|1|2 (tuning only)
@@ -418,14 +583,15 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 		if (wide >= 0) { if (p.N >= 3072) tile = wide; }
 		else if (wide == -2 && t128 > 256 && t128 < 512 && t256 <= 256 && sizeof(T) == 2) tile = 8;
 	}
-	if (tile == 0) launch_tile<T, 128, 128, 2, 4, 3>(p, s, ea, eb);       // 8 waves, wave block 64 x 32, two workgroups per CU
-	else if (tile == 1) launch_tile<T, 128, 64, 2, 2, 3>(p, s, ea, eb);   // 4 waves, wave block 64 x 32, two workgroups per CU
+	const int role = gemm_role_of(p, (int)sizeof(T));
+	if (tile == 0) launch_tile_role<T, 128, 128, 2, 4, 3>(role, p, s, ea, eb);       // 8 waves, wave block 64 x 32, two workgroups per CU
+	else if (tile == 1) launch_tile_role<T, 128, 64, 2, 2, 3>(role, p, s, ea, eb);   // 4 waves, wave block 64 x 32, two workgroups per CU
 	else if (tile == 3) launch_tile<T, 128, 128, 2, 4, 4>(p, s, ea, eb);  // as 0 with a 4-stage ring (128 KiB: one workgroup per CU)
 	else if (tile == 4) launch_tile<T, 128, 64, 2, 2, 5>(p, s, ea, eb);   // as 1 with a 5-stage ring (120 KiB: one workgroup per CU)
 	else if (tile == 5) launch_tile<T, 128, 64, 4, 2, 3>(p, s, ea, eb);   // as 1 with 8 waves (wave block 32 x 32): twice the waves issuing the LDS-DMA pieces
 	else if (tile == 6) launch_tile<T, 128, 64, 2, 4, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 16
 	else if (tile == 7) launch_tile<T, 256, 64, 4, 2, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 32, 120 KiB: one workgroup per CU
-	else if (tile == 8) launch_tile<T, 256, 128, 4, 2, 3>(p, s, ea, eb);  // 8 waves, wave block 64 x 64, 144 KiB: one workgroup per CU
+	else if (tile == 8) launch_tile_role<T, 256, 128, 4, 2, 3>(role == GR_QKV ? role : GR_NONE, p, s, ea, eb);  // 8 waves, wave block 64 x 64, 144 KiB: one workgroup per CU
 	else if (tile == 9) launch_tile<T, 128, 128, 2, 4, 2>(p, s, ea, eb);  // as 0 with a 2-stage ring (64 KiB: two workgroups per CU)
 	// (128 x 64 as TWO waves of 64 x 64 -- a third less fragment traffic out of LDS per flop -- 158.9 ms per DDIM loop against 138.9 for tile 1 everywhere; with a 4-stage ring 213.7: not kept)
 	else launch_tile<T, 64, 64, 2, 2, 3>(p, s, ea, eb);

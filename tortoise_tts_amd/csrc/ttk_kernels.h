@@ -47,29 +47,39 @@ struct GemmSeg {
 	int64_t w_off;      // element offset of this segment's [Npad][K] matrix inside W
 };
 struct GemmParams {
-	GemmSeg seg[12];    // up to 11 taps of a dilated convolution (BigVGAN AMP blocks), 3 for the diffusion convs, 2 for a concat
+	// (the fields every launch reads sit in the first cache lines of the argument block; the segment table comes last)
 	int nseg;
+	int M, N, K;        // K (per segment) % 64 == 0
 	const void* W;      // T, each segment matrix [Npad][ldw] row-major (first K columns used), Npad % 128 == 0
 	int64_t ldw;
-	int M, N, K;        // K (per segment) % 64 == 0
 	int rows_per_batch; // >0 when any shift != 0 or transpose_out
+	int act;            // ttk::Act
 	const float* bias;  // [N] or null
 	const float* residual;  // f32 [M][ldr] or null (may alias C when out_f32)
 	int64_t ldr;
 	void* C;
 	int64_t ldc;
-	int act;            // ttk::Act
 	float out_scale;    // 0 = none; else the accumulators are multiplied by it before the bias (the fp8 weights' power-of-two tensor scale)
 	int out_f32;        // C is f32 (else T; bf16 when the operands are fp8)
 	int transpose_out;  // C is f32 [M / rows_per_batch][N][rows_per_batch]
 	// optional fused GroupNorm32 statistics of the f32 output (see gemm_fuses_gn_stats): part[b][32][gn_T / 64][3]
-	float* gn_part; int gn_T;
+	int gn_T; float* gn_part;
 	int m_major;        // XCD-aware tile order: 0 = each XCD gets a few n-tiles x all m-tiles (its L2 keeps a weight slice), 1 = a few m-tiles x all n-tiles
+	// filled by launch_gemm for the role-specialised instantiations (GemmRole): reciprocals that replace the kernel's run-time integer divisions
+	// (x / d as an f32 product + one correction step, exact for x < 2^23) -- by the m-tile count, rows_per_batch and gn_T
+	int tiles_m; float inv_tiles_m, inv_rpb, inv_gn_T;
 #ifdef TTK_STAMPS
 	unsigned long long* stamps;   // diagnostic build only
 #endif
+	GemmSeg seg[12];    // up to 11 taps of a dilated convolution (BigVGAN AMP blocks), 3 for the diffusion convs, 2 for a concat
 };
+// Roles of the DDIM loop's four GEMMs at model_channels = 1024, 16-bit operands.  A role fixes at COMPILE time what the generic kernel reads
+// from its arguments and branches on: K = lda = ldw = 1024, N, the segment table (one segment, or the three row-shifted taps of a k = 3 convolution over one
+// activation tensor), the epilogue form (bias always, no activation, no scale; f32 or T-typed output; residual; GroupNorm statistics) and the tile order.
+// M and the frames per batch element stay run-time values.  launch_gemm picks the role from the parameters; anything else runs the generic kernel.
+enum GemmRole { GR_NONE = 0, GR_IN1x1 = 1, GR_CONV3_RES = 2, GR_QKV = 3, GR_PROJ_RES = 4 };
 void launch_gemm(int dt, const GemmParams& p, hipStream_t s);
+void gemm_roles_refresh();      // re-reads TTK_GEMM_ROLE (handle creation)
 // true when launch_gemm(M, N) picks a 128-row tile, i.e. each wave owns 64 rows x one or two whole 32-channel groups and can emit
 // the (count, mean, M2) triple of its block in the epilogue (needs N % 64 == 0, 32 channels per group, T % 64 == 0)
 bool gemm_fuses_gn_stats(int M, int N, int C, int T);
