@@ -41,6 +41,39 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Fused GroupNorm32 statistics of a wave's 64-row block (the values just written: the next op on this tensor is always a GroupNorm): NI/2 whole groups of 32
+// channels; exact two-pass (mean, then centred squares) in registers, two DPP wave reductions per group, one (count, mean, M2) triple per (batch, group,
+// 64-row chunk) for k_gn_apply to merge.  ONE function for the generic and the role epilogues, with the contraction written out (the squares accumulate
+// by fma, nothing else is fused): left to the compiler, two instantiations of the same source rounded M2 differently in the last bit -- found by
+// tests/diag/role_check.cpp -- and results must not depend on which instantiation a shape happens to select.
+template <int MI, int NI>
+__device__ __forceinline__ void gn_block_stats(const f32x4 (&acc)[MI][NI], float* part, int b, int group0, int nch, int chunk, int lane) {
+#pragma clang fp contract(off)
+#pragma unroll
+	for (int gq = 0; gq < NI / 2; ++gq) {
+		float sum = 0.f;
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) sum += acc[i][2 * gq + jj][r];
+		const float mean = wave_sum(sum) * (1.0f / 2048.0f);
+		float sq = 0.f;
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) { const float d = acc[i][2 * gq + jj][r] - mean; sq = __builtin_fmaf(d, d, sq); }
+		sq = wave_sum(sq);
+		if (lane == 0) {
+			float* o = part + (((int64_t)b * 32 + (group0 + gq)) * nch + chunk) * 3;
+			o[0] = 2048.0f; o[1] = mean; o[2] = sq;
+		}
+	}
+}
+
 // Accumulator (i, j) register r is row row0 + 16i + 4*(lane>>4) + r, column col0 + 16j + (lane&15).
 // MODE 0: T-typed C; 1: f32 C (+ f32 residual, which may alias C); 2: f32 C transposed to [batch][N][rows_per_batch].
 // All residual/bias loads are issued before the first store: with C aliasing the residual a load-store-load-store order would
@@ -122,34 +155,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][N
 			}
 		}
 	}
-	// Fused GroupNorm32 statistics of the values just written (the next op on this tensor is always a GroupNorm): the wave's
-	// block is 64 rows x NI/2 whole groups of 32 channels; exact two-pass (mean, then centred squares) in registers, two DPP wave
-	// reductions per group, one (count, mean, M2) triple per (batch, group, 64-row chunk) for k_gn_apply to merge.
 	if (MODE == 1 && p.gn_part && MI == 4 && row0 < p.M) {
 		const int b = row0 / p.gn_T, chunk = (row0 - b * p.gn_T) / 64, nch = p.gn_T / 64;
-#pragma unroll
-		for (int gq = 0; gq < NI / 2; ++gq) {
-			float sum = 0.f;
-#pragma unroll
-			for (int i = 0; i < MI; ++i)
-#pragma unroll
-				for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-					for (int r = 0; r < 4; ++r) sum += acc[i][2 * gq + jj][r];
-			const float mean = wave_sum(sum) * (1.0f / 2048.0f);
-			float sq = 0.f;
-#pragma unroll
-			for (int i = 0; i < MI; ++i)
-#pragma unroll
-				for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-					for (int r = 0; r < 4; ++r) { const float d = acc[i][2 * gq + jj][r] - mean; sq += d * d; }
-			sq = wave_sum(sq);
-			if (lane == 0) {
-				float* o = p.gn_part + (((int64_t)b * 32 + (col0 / 32 + gq)) * nch + chunk) * 3;
-				o[0] = 2048.0f; o[1] = mean; o[2] = sq;
-			}
-		}
+		gn_block_stats<MI, NI>(acc, p.gn_part, b, col0 / 32, nch, chunk, lane);
 	}
 }
 
@@ -212,32 +220,10 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 				else ((OT*)p.C)[o] = cvt<OT>(v);
 			}
 		}
-	if constexpr (R::GN) {       // fused GroupNorm32 statistics, as in the generic epilogue
+	if constexpr (R::GN) {
 		if (MI == 4 && row0 < p.M) {
 			const int b = div_recip(row0, p.gn_T, p.inv_gn_T), chunk = (row0 - b * p.gn_T) >> 6, nch = p.gn_T >> 6;
-#pragma unroll
-			for (int gq = 0; gq < NI / 2; ++gq) {
-				float sum = 0.f;
-#pragma unroll
-				for (int i = 0; i < MI; ++i)
-#pragma unroll
-					for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-						for (int r = 0; r < 4; ++r) sum += acc[i][2 * gq + jj][r];
-				const float mean = wave_sum(sum) * (1.0f / 2048.0f);
-				float sq = 0.f;
-#pragma unroll
-				for (int i = 0; i < MI; ++i)
-#pragma unroll
-					for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-						for (int r = 0; r < 4; ++r) { const float d = acc[i][2 * gq + jj][r] - mean; sq += d * d; }
-				sq = wave_sum(sq);
-				if (lane == 0) {
-					float* o = p.gn_part + (unsigned)(((b * 32 + (col0 / 32 + gq)) * nch + chunk) * 3);
-					o[0] = 2048.0f; o[1] = mean; o[2] = sq;
-				}
-			}
+			gn_block_stats<MI, NI>(acc, p.gn_part, b, col0 / 32, nch, chunk, lane);
 		}
 	}
 }
@@ -520,8 +506,13 @@ static void launch_tile(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hi
 // The role of a launch, or GR_NONE: every field a role fixes at compile time must have exactly that value (TTK_GEMM_ROLE=0 switches the roles off: A/B runs and
 // the test that the specialised kernels give the generic kernel's bits; read again by gemm_roles_refresh at every handle creation).
 int g_gemm_roles = -1;
-void gemm_roles_refresh() { const char* e = getenv("TTK_GEMM_ROLE"); g_gemm_roles = e ? atoi(e) : 1; }
+void gemm_roles_refresh() { const char* e = getenv("TTK_GEMM_ROLE"); g_gemm_roles = e ? (atoi(e) == 1 ? 0x1E : atoi(e)) : 0x1E; }      // 0 = off, 1 = all, else a bit mask of GemmRole values
+static int gemm_role_of_unmasked(const GemmParams& p, int es);
 static int gemm_role_of(const GemmParams& p, int es) {
+	const int r = gemm_role_of_unmasked(p, es);
+	return (g_gemm_roles >> r) & 1 ? r : GR_NONE;
+}
+static int gemm_role_of_unmasked(const GemmParams& p, int es) {
 	if (g_gemm_roles < 0) gemm_roles_refresh();
 	if (!g_gemm_roles || es != 2 || p.K != GR_K || p.ldw != GR_K || !p.bias || p.act != ACT_NONE || p.out_scale != 0.f || p.transpose_out || p.m_major) return GR_NONE;
 	if (p.M < 1 || p.M > (1 << 19) || p.seg[0].lda != GR_K || p.seg[0].w_off != 0) return GR_NONE;      // 32-bit byte offsets and M * N < 2^30 element indices
