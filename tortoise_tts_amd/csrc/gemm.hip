@@ -183,8 +183,25 @@ __device__ __forceinline__ int div_recip(int x, int d, float inv) {
 
 // The generic epilogue with the role's decisions taken at compile time: bias always, no activation, no scale; ldc = ldr = N; 32-bit element indices
 // (M * N < 2^30, checked by the dispatcher).  Same operations on every value in the same order: bit-identical results.
-template <typename T, int ROLE, bool GUARD, int MI, int NI>
-__device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[MI][NI], int row0, int col0, int lane) {
+// the residual values of a wave's block, one dword per accumulator register (rows beyond M read as zero)
+template <int ROLE, int MI, int NI, bool GUARD>
+__device__ __forceinline__ void load_residual_role(const GemmParams& p, float (&res)[MI][4][NI], int row0, int col0, int lane) {
+	constexpr int N = GRole<ROLE>::N;
+	const int lr = 4 * (lane >> 4), lc = lane & 15;
+#pragma unroll
+	for (int i = 0; i < MI; ++i)
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+#pragma unroll
+			for (int j = 0; j < NI; ++j) {
+				const int gm = row0 + 16 * i + lr + r;
+				res[i][r][j] = (!GUARD || gm < p.M) ? p.residual[(unsigned)(gm * N + col0 + 16 * j + lc)] : 0.f;
+			}
+}
+
+// PRE: `res` already holds the residual (requested under the last k-tiles, see the role kernels' tail)
+template <typename T, int ROLE, bool GUARD, int MI, int NI, bool PRE = false>
+__device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[MI][NI], float (&res)[MI][4][NI], int row0, int col0, int lane) {
 	typedef GRole<ROLE> R;
 	typedef typename OutOf<T>::type OT;
 	constexpr int N = R::N;
@@ -192,8 +209,7 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 	float bj[NI];
 #pragma unroll
 	for (int j = 0; j < NI; ++j) bj[j] = p.bias[col0 + 16 * j + lc];
-	float res[MI][4][NI];
-	if constexpr (R::RES) {      // all residual loads before the first store: C aliases the residual
+	if constexpr (R::RES && !PRE) {      // all residual loads before the first store: C aliases the residual
 #pragma unroll
 		for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -456,18 +472,51 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	TTK_WSTAMP(stamps_, blockIdx.x, 2);
 	Frags f0, f1;
 	read_frags(f0, 0);
-	int kt = 0;
-	for (; kt + 2 < NTILES; kt += 2) {      // both tiles of a round have a successor
-		step(kt, f0, f1);
-		step(kt + 1, f1, f0);
+	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
+	float res_pre[MI][4][NI];
+	// Roles with a residual (the k = 3 conv and proj_out of the DDIM loop, C aliasing the residual): its tile is requested UNDER the last two k-tiles instead of
+	// in the epilogue, where its round trip was the longest single item (1.9 us of epilogue against 1.0 without a residual, profiles/r04_ddim_chain_roles.log).
+	// The requests leave right behind the LAST DMA request, so they are younger than every piece of the ring: vmcnt retires in order, and the two counted waits
+	// that follow simply allow RESN more loads in flight.  (Round 3 requested the tile at the top of the kernel: 32 loads in front of the first DMA request cost more
+	// than the epilogue gained.)  Same values into the same additions: same bits.
+	constexpr int RESN = MI * 4 * NI;
+	constexpr bool PRE_RES = R::on && R::RES && NSTAGE == 3 && PER_TILE + RESN <= 63 && !F8;
+	if constexpr (PRE_RES) {
+		constexpr int NT = R::NSEG * (GR_K / BKE);
+		static_assert(!PRE_RES || (NT % 2 == 0 && NT >= 8), "the peeled tail assumes an even tile count");
+		auto tail_step = [&](auto wtag, int stage_next, const Frags& cur, Frags& nxt) {
+			wait_vmcnt<decltype(wtag)::value>();
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+			read_frags(nxt, stage_next);
+			mfma_tile(cur);
+		};
+		int kt = 0;
+		for (; kt < NT - 4; kt += 2) {      // every one of these steps requests a tile
+			step(kt, f0, f1);
+			step(kt + 1, f1, f0);
+		}
+		step(NT - 4, f0, f1);                // requests the last tile (NT - 1)
+		if (m0 + BM <= p.M) load_residual_role<ROLE, MI, NI, false>(p, res_pre, row0, col0, lane);      // (straight-line: 32 requests back to back)
+		else load_residual_role<ROLE, MI, NI, true>(p, res_pre, row0, col0, lane);
+		asm volatile("" ::: "memory");
+		tail_step(std::integral_constant<int, PER_TILE + RESN>{}, (NT - 2) % NSTAGE, f1, f0);      // tile NT-2 has landed; tile NT-1 and the residual may be in flight
+		tail_step(std::integral_constant<int, RESN>{}, (NT - 1) % NSTAGE, f0, f1);                 // tile NT-1 has landed
+		mfma_tile(f1);
+	} else {
+		int kt = 0;
+		for (; kt + 2 < NTILES; kt += 2) {      // both tiles of a round have a successor
+			step(kt, f0, f1);
+			step(kt + 1, f1, f0);
+		}
+		if (kt + 2 == NTILES) { step(kt, f0, f1); mfma_tile(f1); }
+		else mfma_tile(f0);
 	}
-	if (kt + 2 == NTILES) { step(kt, f0, f1); mfma_tile(f1); }
-	else mfma_tile(f0);
 	TTK_WSTAMPD(stamps_, blockIdx.x, 3, acc[0][0][0]);
 
-	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
 	if constexpr (R::on) {
-		if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI>(p, acc, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI>(p, acc, row0, col0, lane);
+		if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI, PRE_RES>(p, acc, res_pre, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI, PRE_RES>(p, acc, res_pre, row0, col0, lane);
 		TTK_WSTAMP(stamps_, blockIdx.x, 4);
 #if defined(TTK_STAMPS) && TTK_STAMPS == 2
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
