@@ -1,0 +1,28 @@
+"""`bench.py --gpus 2 --shard candidates` end to end with the roofline pass ON, two ranks on the one GPU of the test box (TTK_BENCH_REHEARSAL=1: gloo
+instead of RCCL, both ranks on cuda:0; not a scaling measurement).  ADVICE r03 (high): every rank >= 1 of this configuration used to die with KeyError
+'ddim' in the roofline block -- only the rank a line's diffusion runs on has that interval -- and torchrun then tore the job down without a result line.
+Round 4 also spreads the two lines' diffusions over the two ranks (dist.assign_diffusers), so rank 0 reports ONE diffused line.  GPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_candidate_sharded_bench_prints_one_line_with_phases():
+	env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+	env["TTK_BENCH_REHEARSAL"] = "1"
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "candidates", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+					   env=env, capture_output=True, text=True, timeout=900)
+	assert r.returncode == 0, r.stderr[-3000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+	assert len(lines) == 1, r.stdout[-2000:]
+	line = json.loads(lines[0])
+	assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["backend"] == "gloo" and line["config"]["lines"] == 2
+	ph = line["roofline"]["phases"]
+	assert ph["lines"] == 2 and ph["ddim"]["lines_diffused_here"] == 1 and ph["ddim"]["ms"] > 0 and 0 < ph["ddim"]["frac"] < 1
+	assert ph["ar_decode"]["ms"] > 0 and ph["latent_pass"]["ms"] > 0 and line["value"] > 0

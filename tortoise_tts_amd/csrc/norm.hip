@@ -178,25 +178,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	{   // merge: 8 lanes per group, every chunk triple requested up front (one L2 latency, not one per chunk), DPP sums
 		const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
 		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
-		float cn[8], cm[8], c2[8];
-		float nt = 0.f, wsum = 0.f;
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group
-			const int k = sub + 8 * i;
-			const bool ok = k < nch;
-			const int kk = ok ? k : 0;
-			const float a0 = part[3 * kk], a1 = part[3 * kk + 1], a2 = part[3 * kk + 2];
-			cn[i] = ok ? a0 : 0.f; cm[i] = ok ? a1 : 0.f; c2[i] = ok ? a2 : 0.f;
-			nt += cn[i]; wsum += cn[i] * cm[i];
-		}
-		nt = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(nt)));
-		wsum = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(wsum)));
-		const float mean = wsum / nt;
-		float m2 = 0.f;
-#pragma unroll
-		for (int i = 0; i < 8; ++i) { const float d = cm[i] - mean; m2 += c2[i] + cn[i] * d * d; }
-		m2 = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(m2)));
-		if (sub == 0) { s_mean[g] = mean; s_rstd[g] = rsqrtf(m2 / nt + 1e-5f); }
+		float mean, rstd;
+		gn_merge_triples(part, nch, sub, [](const float* q) { return *q; }, mean, rstd);
+		if (sub == 0) { s_mean[g] = mean; s_rstd[g] = rstd; }
 	}
 	__syncthreads();
 	TTK_WSTAMP(p.stamps, blockIdx.x, 2);
@@ -206,14 +190,14 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnApplyParams p) {
 	float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
 	if (p.scale) { sc = *(const float4*)(p.scale + (int64_t)b * p.ss_stride + c); sh = *(const float4*)(p.shift + (int64_t)b * p.ss_stride + c); }
 	// fold everything into y = x * a + d per channel
-	const float a0 = rstd * ga.x * (1.f + sc.x), a1 = rstd * ga.y * (1.f + sc.y), a2 = rstd * ga.z * (1.f + sc.z), a3 = rstd * ga.w * (1.f + sc.w);
-	const float d0 = (be.x - mean * rstd * ga.x) * (1.f + sc.x) + sh.x, d1 = (be.y - mean * rstd * ga.y) * (1.f + sc.y) + sh.y;
-	const float d2 = (be.z - mean * rstd * ga.z) * (1.f + sc.z) + sh.z, d3 = (be.w - mean * rstd * ga.w) * (1.f + sc.w) + sh.w;
+	float a0, a1, a2, a3, d0, d1, d2, d3;
+	gn_fold_coef(mean, rstd, ga.x, be.x, sc.x, sh.x, a0, d0); gn_fold_coef(mean, rstd, ga.y, be.y, sc.y, sh.y, a1, d1);
+	gn_fold_coef(mean, rstd, ga.z, be.z, sc.z, sh.z, a2, d2); gn_fold_coef(mean, rstd, ga.w, be.w, sc.w, sh.w, a3, d3);
 #pragma unroll
 	for (int i = 0; i < GN_PASSES; ++i) {
 		const int to = t0 + i * rpp + rr;
 		if (to >= p.Tout) continue;
-		float o0 = xv[i].x * a0 + d0, o1 = xv[i].y * a1 + d1, o2 = xv[i].z * a2 + d2, o3 = xv[i].w * a3 + d3;
+		float o0 = gn_fold_apply(xv[i].x, a0, d0), o1 = gn_fold_apply(xv[i].y, a1, d1), o2 = gn_fold_apply(xv[i].z, a2, d2), o3 = gn_fold_apply(xv[i].w, a3, d3);
 		if (p.act == ACT_SILU) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
 		if (to >= Tl) { o0 = 0.f; o1 = 0.f; o2 = 0.f; o3 = 0.f; }      // padding rows of a ragged batch: zeros, what a k = 3 conv reads beyond a sequence's end
 		OT* dst = (OT*)p.out + ((int64_t)b * p.Tout + to) * p.C + c;
@@ -274,39 +258,21 @@ __global__ __launch_bounds__(GN_TOUCH_WAVE ? 320 : 256) void k_gn_apply_c1024(Gn
 		// hand-over, no workgroup barrier.
 		const int g = tid >> 3, sub = tid & 7;
 		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
-		float cn[8], cm[8], c2[8];
-		float nt = 0.f, wsum = 0.f;
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group
-			const int k = sub + 8 * i;
-			const bool ok = k < nch;
-			const int kk = ok ? k : 0;
-			const float a0 = part[3 * kk], a1 = part[3 * kk + 1], a2 = part[3 * kk + 2];
-			cn[i] = ok ? a0 : 0.f; cm[i] = ok ? a1 : 0.f; c2[i] = ok ? a2 : 0.f;
-			nt += cn[i]; wsum += cn[i] * cm[i];
-		}
-		nt = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(nt)));
-		wsum = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(wsum)));
-		mean = wsum / nt;
-		float m2 = 0.f;
-#pragma unroll
-		for (int i = 0; i < 8; ++i) { const float d = cm[i] - mean; m2 += c2[i] + cn[i] * d * d; }
-		m2 = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(m2)));
-		rstd = rsqrtf(m2 / nt + 1e-5f);
+		gn_merge_triples(part, nch, sub, [](const float* q) { return *q; }, mean, rstd);
 	}
 	TTK_WSTAMPD(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 2, rstd);
 	// (no fifth wave: the touches leave HERE -- every load this thread waits for has been consumed, nothing below waits on vmcnt, so they cost the
 	// workgroup only their issue slots and keep it alive until they land)
 	if (!GN_TOUCH_WAVE && p.pf) l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink) + (tid >> 6) * 64), blockIdx.y * gridDim.x + blockIdx.x,
 												   gridDim.x * gridDim.y, tid, 256);
-	const float a0 = rstd * ga.x * (1.f + sc.x), a1 = rstd * ga.y * (1.f + sc.y), a2 = rstd * ga.z * (1.f + sc.z), a3 = rstd * ga.w * (1.f + sc.w);
-	const float d0 = (be.x - mean * rstd * ga.x) * (1.f + sc.x) + sh.x, d1 = (be.y - mean * rstd * ga.y) * (1.f + sc.y) + sh.y;
-	const float d2 = (be.z - mean * rstd * ga.z) * (1.f + sc.z) + sh.z, d3 = (be.w - mean * rstd * ga.w) * (1.f + sc.w) + sh.w;
+	float a0, a1, a2, a3, d0, d1, d2, d3;
+	gn_fold_coef(mean, rstd, ga.x, be.x, sc.x, sh.x, a0, d0); gn_fold_coef(mean, rstd, ga.y, be.y, sc.y, sh.y, a1, d1);
+	gn_fold_coef(mean, rstd, ga.z, be.z, sc.z, sh.z, a2, d2); gn_fold_coef(mean, rstd, ga.w, be.w, sc.w, sh.w, a3, d3);
 #pragma unroll
 	for (int i = 0; i < GN_PASSES; ++i) {
 		const int to = t0 + i;
 		if (to >= p.T) continue;
-		float o0 = xv[i].x * a0 + d0, o1 = xv[i].y * a1 + d1, o2 = xv[i].z * a2 + d2, o3 = xv[i].w * a3 + d3;
+		float o0 = gn_fold_apply(xv[i].x, a0, d0), o1 = gn_fold_apply(xv[i].y, a1, d1), o2 = gn_fold_apply(xv[i].z, a2, d2), o3 = gn_fold_apply(xv[i].w, a3, d3);
 		if (p.act == ACT_SILU) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
 		if (to >= Tl) { o0 = 0.f; o1 = 0.f; o2 = 0.f; o3 = 0.f; }
 		OT* dst = (OT*)p.out + ((int64_t)b * p.T + to) * C + c;

@@ -132,6 +132,43 @@ __device__ __forceinline__ float gelu_new_f(float x) {   // HF:activations.py:59
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_precise(float x) { return silu_f(x); }
 
+// GroupNorm32 "apply" arithmetic, ONE definition for every kernel that normalises (k_gn_apply, k_gn_apply_c1024 and the dense GEMM's fused form): the merge of
+// a group's chunk triples (count, mean, M2) by 8 lanes (Chan et al.; lane `sub` takes chunks sub, sub + 8, ...; DPP sums leave the result in all 8) and the
+// per-channel fold y = x * a + d.  Contraction is written out (fmaf where a product feeds a sum, nothing else fused): left to the compiler, two instantiations
+// of one source line have rounded differently in the last bit (tests/diag/role_check.cpp), and a sequence must come out the same whichever kernel serves it.
+// LOAD(ptr) fetches one float of the triples (plain load, or an agent-scope load where the triples were written by this very launch).
+template <typename LoadF>
+__device__ __forceinline__ void gn_merge_triples(const float* part, int nch, int sub, LoadF load, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+	float cn[8], cm[8], c2[8];
+	float nt = 0.f, wsum = 0.f;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group
+		const int k = sub + 8 * i;
+		const bool ok = k < nch;
+		const int kk = ok ? k : 0;
+		const float a0 = load(part + 3 * kk), a1 = load(part + 3 * kk + 1), a2 = load(part + 3 * kk + 2);
+		cn[i] = ok ? a0 : 0.f; cm[i] = ok ? a1 : 0.f; c2[i] = ok ? a2 : 0.f;
+		nt += cn[i]; wsum = __builtin_fmaf(cn[i], cm[i], wsum);
+	}
+	nt = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(nt)));
+	wsum = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(wsum)));
+	mean = wsum / nt;
+	float m2 = 0.f;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { const float d = cm[i] - mean; m2 += __builtin_fmaf(cn[i] * d, d, c2[i]); }
+	m2 = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(m2)));
+	rstd = rsqrtf(m2 / nt + 1e-5f);
+}
+// y = x * a + d with a = rstd * gamma * (1 + scale), d = (beta - mean * rstd * gamma) * (1 + scale) + shift
+__device__ __forceinline__ void gn_fold_coef(float mean, float rstd, float gamma, float beta, float scale, float shift, float& a, float& d) {
+#pragma clang fp contract(off)
+	const float s1 = 1.f + scale;
+	a = rstd * gamma * s1;
+	d = __builtin_fmaf(beta - mean * rstd * gamma, s1, shift);
+}
+__device__ __forceinline__ float gn_fold_apply(float x, float a, float d) { return __builtin_fmaf(x, a, d); }
+
 enum Act { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_SILU = 2 };
 __device__ __forceinline__ float apply_act(float v, int act) {
 	if (act == ACT_GELU_NEW) return gelu_new_f(v);
