@@ -26,3 +26,20 @@ def test_two_rank_candidate_sharded_bench_prints_one_line_with_phases():
 	ph = line["roofline"]["phases"]
 	assert ph["lines"] == 2 and ph["ddim"]["lines_diffused_here"] == 1 and ph["ddim"]["ms"] > 0 and 0 < ph["ddim"]["frac"] < 1
 	assert ph["ar_decode"]["ms"] > 0 and ph["latent_pass"]["ms"] > 0 and line["value"] > 0
+
+
+def test_two_rank_utterance_sharded_bench_prints_one_line():
+	"""the driver's N > 1 form (configs[2]: one utterance per rank, the candidate ids all-gathered), two ranks on one GPU over gloo: one result line from rank 0,
+	whole-job value = 2 utterances' audio over the slower rank's time"""
+	env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+	env["TTK_BENCH_REHEARSAL"] = "1"
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+					   env=env, capture_output=True, text=True, timeout=900)
+	assert r.returncode == 0, r.stderr[-3000:]
+	lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+	assert len(lines) == 1, r.stdout[-2000:]
+	line = json.loads(lines[0])
+	assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+	audio = 2 * 1088 * 256 / 24000
+	assert abs(line["value"] - audio / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+	assert line["roofline"]["phases"]["ddim"]["ms"] > 0 and line["cpu_baseline"] is None

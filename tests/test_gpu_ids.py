@@ -97,6 +97,27 @@ def first_divergence(a, b):
 	return torch.where(ne.any(dim=1), ne.float().argmax(dim=1), torch.full((a.shape[0],), a.shape[1])).tolist()
 
 
+def test_f32_ids_equal_the_oracles_own_loop_at_full_size():
+	"""the 16 x 250 record below is an induction over a restated draw unless TTK_TEST_FULL_ORACLE_LOOP=1 (200 s).  This one runs the ORACLE'S
+	OWN KV-cached sampling loop (`O.inference_speech`, the loop the small-model id tests pin against the reference's sample_stream) at full size in the default
+	run on a draw count it finishes in seconds -- 4 candidates x 96 tokens, 64 text tokens, temperature 0.8, seed 0 -- against the product's free-running f32
+	loop: equal bit for bit, no indirection."""
+	sd = W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0)
+	g = torch.Generator().manual_seed(1234)
+	text = torch.randint(1, 255, (1, TEXT), generator=g)
+	cond = torch.randn(1, 1024, generator=g)
+	n_c, n_t = 4, 96
+	with torch.inference_mode():
+		want = O.inference_speech(O.AROracle(sd, W.AR_FULL), cond, text, num_return_sequences=n_c, max_generate_length=n_t, temperature=TEMP, top_k=0,
+								  suppress_tokens=[STOP], sample_device="cuda")
+		from tortoise_tts_amd.autoregressive import UnifiedVoice
+		model = UnifiedVoice(sd, W.AR_FULL, dtype="f32", device=DEV, max_batch=n_c, max_ctx=TEXT + 4 + n_t + 8)
+		got = model.inference_speech(cond.to(DEV), text.to(DEV), do_sample=True, temperature=TEMP, top_k=0, num_return_sequences=n_c, max_generate_length=n_t,
+									 suppress_tokens=[STOP]).cpu()
+	assert got.shape == want.shape == (n_c, n_t)
+	assert torch.equal(got, want.cpu()), first_divergence(got, want.cpu())
+
+
 def test_f32_ids_equal_the_oracle_at_the_benchmarked_configuration(case):
 	sd, text, cond, ref_ids, ref_logits, induction = case
 	with torch.inference_mode():
