@@ -444,10 +444,14 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	// so they are dealt to the waves exactly as in a batch of its own -- and its shared prefix rows live in the slice of its line's first candidate
 	int start = 0, grp = 0;
 	if (ROWS) { const int2 ri = p.row_info[b]; start = ri.x; grp = ri.y; }
-	const int n = min(p.d_pos[0] + 1, p.max_ctx) - start;
-	// rows [0, shared) are read from the line's first candidate.  The count sits next to the cache length in device memory, not in the kernel
-	// arguments: a captured token step is replayed for later calls with other prefix lengths
-	const int sh0 = p.shared_rows ? p.d_pos[1] : 0;
+	// {valid cache rows, rows of the shared prefix} as ONE 8-byte request.  Written as two reads, the second under `p.shared_rows`, hipcc issued two DEPENDENT
+	// loads -- position, wait, prefix length, wait -- in front of every K / V address: 1.76 us from a wave's first instruction to its requests
+	// (profiles/r03_ar_chain_lean.log).  Both words sit in device memory, not in the kernel arguments: a captured token step is replayed for later
+	// calls with other prefix lengths.
+	const int2 dp = *(const int2*)p.d_pos;
+	const int n = min(dp.x + 1, p.max_ctx) - start;
+	// rows [0, shared) are read from the line's first candidate
+	const int sh0 = p.shared_rows ? dp.y : 0;
 	const int shared = sh0 > 0 ? sh0 - start : 0;
 	const T* Kc = (const T*)p.kcache + (((int64_t)b * p.H + h) * p.max_ctx + start) * HD;
 	const T* Vc = (const T*)p.vcache + (((int64_t)b * p.H + h) * p.max_ctx + start) * HD;
