@@ -81,6 +81,13 @@ int ttk_ar_destroy(ttk_ar* h);
 int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, int B,
 				   float* logits_out, void* stream);
 
+/* Prefill of a PROMPTED continuation (`inference_speech(..., input_tokens=)`, unified_voice.py:651-656: the mel tokens of `input_tokens` follow start_mel in the
+ * first forward, :203-211): prompt = device int64 [prompt_rows][n_prompt] mel codes, prompt_rows == 1 (one prompt for all candidates: it joins the shared
+ * prefix) or B.  Mel positions 1 .. n_prompt; the cache then holds P + 1 + n_prompt rows, the logits are those of the last prompt row, and the first
+ * decode step feeds its token at mel position n_prompt + 2 (the reference's attention_mask.shape[1] - mel_len).                                          */
+int ttk_ar_prefill_prompted(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, const int64_t* prompt, int prompt_rows, int n_prompt, int B,
+							float* logits_out, void* stream);
+
 /* One KV-cached decode step (unified_voice.py:212-214 + HF GPT2Model + lm_head): feeds back tok [B] int64, the k-th
  * generated token (k = 1, 2, ... counted by the handle), with mel position k + 1 (the reference's indexing).
  *   logits_out [B, number_mel_codes] f32;  hidden_out (optional, may be NULL) [B, D] f32 = final_norm(ln_f(h)) of the

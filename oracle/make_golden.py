@@ -328,6 +328,8 @@ SAMPLE_STREAM_CASES = (
 	("warpers", 11, 0.0, 2, 6, 12, dict(temperature=0.7, top_k=16, top_p=0.9, repetition_penalty=2.0, suppress_tokens=[8193])),
 	("stop_first", 11, 60.0, 2, 5, 8, dict(temperature=1.0)),
 	("all_stop", 11, 7.0, 3, 7, 80, dict(temperature=0.8)),
+	# a prompted continuation (inference_speech's input_tokens, unified_voice.py:651-656): 5 seeded mel tokens per row behind the fake prefix; "max new" counts them (:660)
+	("prompted", 11, 0.0, 3, 8, 14, dict(temperature=0.8, repetition_penalty=1.5, suppress_tokens=[8193], prompt_len=5)),
 )
 
 
@@ -366,8 +368,14 @@ def sample_stream_case(uv_mod):
 		load_into(m, sd)
 		text = torch.randint(1, 255, (1, Tt), generator=gen(wseed + 1))
 		cond = torch.randn(1, cfg.model_dim, generator=gen(wseed + 2))
+		prompt = None
+		if kw.get("prompt_len"):
+			prompt = torch.randint(0, 8192, (B, kw["prompt_len"]), generator=gen(wseed + 3))
 		with torch.inference_mode():
 			ids = m.compute_embeddings(cond, text).repeat(B, 1)
+			n_fake = ids.shape[1]
+			if prompt is not None:
+				ids = torch.cat([ids, prompt], dim=1)
 			im = m.inference_model
 			procs = LogitsProcessorList()
 			if kw.get("repetition_penalty", 1.0) != 1.0:
@@ -380,12 +388,14 @@ def sample_stream_case(uv_mod):
 			toks, lats = [], []
 			for tok, lat in sg.NewGenerationMixin.sample_stream(
 					im, ids, logits_processor=procs, logits_warper=warpers,
-					stopping_criteria=_ScalarMaxLength(ids.shape[1] + max_new), pad_token_id=cfg.stop_mel_token,
+					stopping_criteria=_ScalarMaxLength(n_fake + max_new), pad_token_id=cfg.stop_mel_token,
 					eos_token_id=cfg.stop_mel_token, output_hidden_states=True, return_dict_in_generate=False, use_cache=True,
 					attention_mask=torch.ones_like(ids)):
 				toks.append(tok.clone())
 				lats.append(lat.clone())
 		out[f"{name}::text"], out[f"{name}::cond"] = text.numpy(), cond.numpy()
+		if prompt is not None:
+			out[f"{name}::prompt"] = prompt.numpy()
 		out[f"{name}::ids"] = torch.stack(toks, 1).numpy()                      # [B, n]
 		out[f"{name}::latents"] = torch.stack(lats, 1).numpy()                  # [B, n, d]
 		out[f"{name}::meta"] = np.array(json.dumps(dict(weight_seed=wseed, stop_bias=stop_bias, B=B, Tt=Tt, max_new=max_new, kw=kw)))

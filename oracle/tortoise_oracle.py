@@ -130,13 +130,17 @@ class AROracle:
 		h = layer_norm(hidden, self.w["final_norm.weight"], self.w["final_norm.bias"])
 		return F.linear(h, self.w["mel_head.weight"], self.w["mel_head.bias"])
 
-	def prefill(self, prefix: Tensor, B: int):
-		"""unified_voice.py:203-211: cat[cached prefix (repeat_interleave to B), mel_emb(start)+mel_pos(0)]."""
+	def prefill(self, prefix: Tensor, B: int, prompt: Optional[Tensor] = None):
+		"""unified_voice.py:203-211: cat[cached prefix (repeat_interleave to B), mel_emb(start)+mel_pos(0)].
+		prompt [B, n] (prompted continuation, :651-656): the ids behind the fake prefix are [start_mel | prompt], embedded at mel positions 0 .. n (:205-206)."""
 		c = self.cfg
 		if prefix.shape[0] != B:
 			prefix = prefix.repeat_interleave(B // prefix.shape[0], 0)
 		start = self.w["mel_embedding.weight"][c.start_mel_token] + self.w["mel_pos_embedding.emb.weight"][0]
 		emb = torch.cat([prefix, start.view(1, 1, -1).expand(B, 1, -1)], dim=1)
+		if prompt is not None and prompt.shape[1]:
+			n = prompt.shape[1]
+			emb = torch.cat([emb, self.w["mel_embedding.weight"][prompt] + self.w["mel_pos_embedding.emb.weight"][1:n + 1]], dim=1)
 		hidden, past = gpt2_stack(self.w, c.layers, c.heads, emb)
 		return self.lm_head(hidden), past, hidden
 
@@ -238,9 +242,14 @@ def process_logits(input_ids: Tensor, logits: Tensor, *, temperature=1.0, top_k=
 
 def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return_sequences=1,
 					max_generate_length=None, temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0,
-					suppress_tokens=None, sample_device="cpu", seed=0, return_logits=False, forced_tokens=None):
+					suppress_tokens=None, sample_device="cpu", seed=0, return_logits=False, forced_tokens=None, input_tokens=None):
 	"""unified_voice.py:632-668 + stream_generator.py:213-639 (sample branch) + HF `_sample`
 	HF:generation/utils.py:2894-2937.
+
+	* `input_tokens` [R, n] (prompted continuation, :651-656; restated from source, `TTS.inference` never passes it): the reference tiles the fake prefix and the
+	  prompts to `num_return_sequences` rows (:653-655, needs num_return_sequences % R == 0) and THEN hands generate() `num_return_sequences` again, which
+	  expands every row that many times (HF `_expand_inputs_for_generation`: repeat_interleave) -- num_return_sequences ** 2 sequences come back, row
+	  i * nrs + j = the j-th sample of prompt row i % R.  The prompt tokens are part of the returned ids and count towards max_generate_length (:660, :668).
 
 	* RNG: `setup_seed(seed)` with seed=0 is unconditional (stream_generator.py:223,296).
 	* Keyword defaults are HF `GenerationConfig`'s, which is what an omitted `**hf_generate_kwargs` entry means in the reference
@@ -256,6 +265,11 @@ def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_ret
 	"""
 	c = ar.cfg
 	B = num_return_sequences * text.shape[0]
+	prompt = None
+	if input_tokens is not None:
+		assert text.shape[0] == 1 and num_return_sequences % input_tokens.shape[0] == 0, "The number of return sequences must be divisible by the number of input sequences"
+		prompt = input_tokens.repeat(num_return_sequences // input_tokens.shape[0], 1).repeat_interleave(num_return_sequences, 0)
+		B = prompt.shape[0]
 	prefix = ar.prefix_embeddings(cond_latent, text)
 	P = prefix.shape[1]
 	trunc_index = P + 1
@@ -265,11 +279,14 @@ def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_ret
 		torch.cuda.manual_seed_all(seed)
 	input_ids = torch.ones((B, trunc_index), dtype=torch.long)
 	input_ids[:, -1] = c.start_mel_token
+	if prompt is not None:
+		input_ids = torch.cat([input_ids, prompt], dim=1)
 	unfinished = torch.ones(B, dtype=torch.long)
-	logits, past, _ = ar.prefill(prefix, B)
+	logits, past, _ = ar.prefill(prefix, B) if prompt is None else ar.prefill(prefix, B, prompt)
 	logits = logits[:, -1]
 	all_logits = []
-	k = 0
+	k = 0 if prompt is None else prompt.shape[1]      # mel tokens behind start_mel so far: the fed-back token k sits at mel position k + 1
+	n_drawn = 0
 	while True:
 		logits = logits.float()
 		if return_logits:
@@ -278,8 +295,9 @@ def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_ret
 								repetition_penalty=repetition_penalty, suppress_tokens=suppress_tokens)
 		probs = F.softmax(scores.to(sample_device), dim=-1)
 		nxt = torch.multinomial(probs, num_samples=1).squeeze(1).cpu()
-		if forced_tokens is not None and k < forced_tokens.shape[1]:
-			nxt = forced_tokens[:, k]
+		if forced_tokens is not None and n_drawn < forced_tokens.shape[1]:
+			nxt = forced_tokens[:, n_drawn]
+		n_drawn += 1
 		nxt = nxt * unfinished + c.stop_mel_token * (1 - unfinished)
 		input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
 		k += 1
@@ -295,7 +313,7 @@ def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_ret
 
 
 def sample_stream(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return_sequences=1, max_generate_length=None,
-				  temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0, suppress_tokens=None, sample_device="cpu", seed=0):
+				  temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0, suppress_tokens=None, sample_device="cpu", seed=0, prompt=None):
 	"""a6: `NewGenerationMixin.sample_stream` (stream_generator.py:911-1190) as `get_generator` drives it (unified_voice.py:670-679),
 	a generator of (next_tokens [B], latent [B, d]).  Pinned by tests/golden/sample_stream.npz, which the REFERENCE's own loop produced
 	(oracle/make_golden.py: sample_stream_case).  What that pin fixes:
@@ -316,10 +334,12 @@ def sample_stream(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return
 		torch.cuda.manual_seed_all(seed)
 	input_ids = torch.ones((B, trunc_index), dtype=torch.long)
 	input_ids[:, -1] = c.start_mel_token
+	if prompt is not None:      # `inputs` with mel tokens behind the fake prefix (one row per sequence): a prompted continuation, pinned by the fixture's "prompted" case
+		input_ids = torch.cat([input_ids, prompt], dim=1)
 	unfinished = torch.ones(B, dtype=torch.long)
-	logits, past, hidden = ar.prefill(prefix, B)
+	logits, past, hidden = ar.prefill(prefix, B, prompt)
 	logits, hidden = logits[:, -1], hidden[:, -1]
-	k = 0
+	k = 0 if prompt is None else prompt.shape[1]
 	while True:
 		scores = process_logits(input_ids, logits, temperature=temperature, top_k=top_k, top_p=top_p,
 								repetition_penalty=repetition_penalty, suppress_tokens=suppress_tokens)

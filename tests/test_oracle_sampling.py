@@ -141,10 +141,27 @@ def test_sample_stream_equals_the_references_own_loop(golden):
 		text, cond = torch.from_numpy(g[f"{name}::text"]), torch.from_numpy(g[f"{name}::cond"])
 		kw = dict(meta["kw"])
 		kw.setdefault("top_k", 0)
+		want_ids, want_lat = torch.from_numpy(g[f"{name}::ids"]), torch.from_numpy(g[f"{name}::latents"])
+		if kw.pop("prompt_len", None):
+			# a prompted continuation: the reference's loop was given ids = [fake prefix | one prompt per row].  The oracle's loop takes the same rows;
+			# `inference_speech(input_tokens=)` builds its rows as the reference's wrapper does (tiled, then expanded by generate: nrs ** 2 of them) and must equal
+			# the oracle's loop on exactly those rows, prompt columns in front (unified_voice.py:651-668)
+			prompt = torch.from_numpy(g[f"{name}::prompt"])
+			with torch.inference_mode():
+				pairs = list(O.sample_stream(ar, cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], prompt=prompt, **kw))
+				nrs = prompt.shape[0]
+				ids = O.inference_speech(ar, cond, text, num_return_sequences=nrs, max_generate_length=meta["max_new"], input_tokens=prompt, **kw)
+				rows = prompt.repeat_interleave(nrs, 0)
+				again = list(O.sample_stream(ar, cond, text, num_return_sequences=nrs * nrs, max_generate_length=meta["max_new"], prompt=rows, **kw))
+			assert len(pairs) == want_ids.shape[1] == meta["max_new"] - prompt.shape[1], name       # "max new" counts the prompt tokens (:660)
+			assert torch.equal(torch.stack([t for t, _ in pairs], 1), want_ids), name
+			assert (torch.stack([l for _, l in pairs], 1) - want_lat).abs().max() < 2e-5, name
+			assert ids.shape == (nrs * nrs, meta["max_new"]) and torch.equal(ids[:, :prompt.shape[1]], rows), name
+			assert torch.equal(ids[:, prompt.shape[1]:], torch.stack([t for t, _ in again], 1)), name
+			continue
 		with torch.inference_mode():
 			pairs = list(O.sample_stream(ar, cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], **kw))
 			ids = O.inference_speech(ar, cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], **kw)
-		want_ids, want_lat = torch.from_numpy(g[f"{name}::ids"]), torch.from_numpy(g[f"{name}::latents"])
 		assert len(pairs) == want_ids.shape[1], name                                 # every token is yielded, the last one too
 		assert torch.equal(torch.stack([t for t, _ in pairs], 1), want_ids), name
 		assert (torch.stack([l for _, l in pairs], 1) - want_lat).abs().max() < 2e-5, name

@@ -71,6 +71,7 @@ SYMBOLS = {
 	"ttk_ar_create": (_I, [C.POINTER(_P), C.POINTER(ARConfigC), C.POINTER(WeightView), _I]),
 	"ttk_ar_destroy": (_I, [_P]),
 	"ttk_ar_prefill": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
+	"ttk_ar_prefill_prompted": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
 	"ttk_ar_decode": (_I, [_P, _P, _P, _P, _P]),
 	"ttk_ar_decode_next": (_I, [_P, _P, _P, _P]),
 	"ttk_ar_last_hidden": (_I, [_P, _P, _P]),

@@ -92,12 +92,19 @@ class UnifiedVoice:
 		if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= n):
 			raise IndexError(f"{what} ids must lie in [0, {n}); got [{int(ids.min())}, {int(ids.max())}]")
 
-	def _prefill(self, cond: torch.Tensor, text: torch.Tensor, B: int) -> torch.Tensor:
+	def _prefill(self, cond: torch.Tensor, text: torch.Tensor, B: int, prompt: Optional[torch.Tensor] = None) -> torch.Tensor:
+		"""prompt [1 or B, n] int64: the mel tokens of a prompted continuation, cached behind start_mel (include/ttk.h: ttk_ar_prefill_prompted)"""
 		cond = cond.to(self.device, torch.float32).contiguous()
 		text = text.to(self.device, torch.int64).contiguous().view(-1)
 		_lib.require_cuda(cond, text)
 		self._check_ids(text, self.cfg.number_text_tokens + 1, "text token")
 		logits = torch.empty((B, self.cfg.number_mel_codes), device=self.device, dtype=torch.float32)
+		if prompt is not None and prompt.shape[1]:
+			prompt = prompt.to(self.device, torch.int64).contiguous()
+			self._check_ids(prompt, self.cfg.number_mel_codes, "prompt mel code")
+			_lib.check(self.lib.ttk_ar_prefill_prompted(self._h, cond.data_ptr(), cond.shape[0], text.data_ptr(), text.numel(), prompt.data_ptr(), prompt.shape[0],
+														prompt.shape[1], B, logits.data_ptr(), _lib.stream_ptr()), "ttk_ar_prefill_prompted")
+			return logits
 		_lib.check(self.lib.ttk_ar_prefill(self._h, cond.data_ptr(), cond.shape[0], text.data_ptr(), text.numel(), B,
 										   logits.data_ptr(), _lib.stream_ptr()), "ttk_ar_prefill")
 		return logits
@@ -188,16 +195,28 @@ class UnifiedVoice:
 		candidates per token (the same Philox stream on every rank: `generate` reseeds to 0) and consumes its own rows, so the ids it
 		returns are bit for bit the rows lo..hi-1 of the unsharded call -- up to the length, which here ends with the shard's own last
 		row (the gather pads with the stop token, as the unsharded loop does for finished rows)."""
-		if input_tokens is not None:
-			raise NotImplementedError("input_tokens (prompted continuation) is not on the inference hot path")
 		if text_inputs.shape[0] != 1:
 			raise NotImplementedError("one text line per call, as inference.py:244-246 does")
+		prompt = None
+		if input_tokens is not None:
+			# Prompted continuation (unified_voice.py:651-656; `TTS.inference` never passes it).  The reference tiles the fake prefix and the prompts to
+			# num_return_sequences rows (:653-655) and then hands generate() num_return_sequences AGAIN, which expands every row that many times
+			# (HF _expand_inputs_for_generation: repeat_interleave): num_return_sequences ** 2 sequences come back, row i * nrs + j = sample j of prompt row
+			# i % R, the prompt tokens in front (:668 cuts at trunc_index only) and counted in max_generate_length (:660).  Restated from source; the loop on
+			# such rows is pinned by the reference's own sample_stream (tests/golden/sample_stream.npz, "prompted").
+			if candidate_shard is not None:
+				raise NotImplementedError("a prompted continuation is not sharded over ranks")
+			if input_tokens.dim() != 2 or input_tokens.shape[0] < 1 or num_return_sequences % input_tokens.shape[0] != 0:
+				raise ValueError("The number of return sequences must be divisible by the number of input sequences")
+			prompt = input_tokens.to(self.device, torch.int64).repeat(num_return_sequences // input_tokens.shape[0], 1).repeat_interleave(num_return_sequences, 0)
+			if bool((prompt == self.stop_mel_token).any()):
+				raise ValueError("input_tokens must not contain the stop token")
 		# omitted keywords mean HF GenerationConfig defaults in the reference (stream_generator.py:262-276): do_sample False (greedy
 		# search, not on the hot path: TTS.inference always samples, inference.py:336), top_k 50, temperature / top_p / penalty 1
 		if hf_generate_kwargs.get("num_beams", 1) not in (None, 1) or not hf_generate_kwargs.get("do_sample", False):
 			raise NotImplementedError("only the sampling branch (do_sample=True, num_beams=1) is implemented; pass do_sample=True")
-		gen, _ = self._generate(speech_conditioning_latent, text_inputs, num_return_sequences, max_generate_length,
-								typical_mass if typical_sampling else None, hf_generate_kwargs, stream=False, shard=candidate_shard)
+		gen, _ = self._generate(speech_conditioning_latent, text_inputs, num_return_sequences if prompt is None else prompt.shape[0], max_generate_length,
+								typical_mass if typical_sampling else None, hf_generate_kwargs, stream=False, shard=candidate_shard, prompt=prompt)
 		return gen
 
 	def inference_speech_lines(self, speech_conditioning_latent, texts, num_return_sequences=1, max_generate_length=None, **hf_generate_kwargs):
@@ -302,9 +321,12 @@ class UnifiedVoice:
 		return self._generate(cond, text, B, n_new, None, hf_generate_kwargs, stream=True)
 
 	# ------------------------------------------------------------------ the token loop
-	def _generate(self, cond, text, num_return_sequences, max_generate_length, typical_mass, kw, stream, shard=None):
+	def _generate(self, cond, text, num_return_sequences, max_generate_length, typical_mass, kw, stream, shard=None, prompt=None):
 		c = self.cfg
 		self._require_idle()
+		n_in = 0 if prompt is None else int(prompt.shape[1])
+		if stream and n_in:
+			raise NotImplementedError("the streaming generator takes no prompt tokens")
 		C = num_return_sequences * text.shape[0]          # candidates the noise is drawn for
 		lo, hi = (0, C) if shard is None else (int(shard[0]), int(shard[1]))
 		if not (0 <= lo < hi <= C):
@@ -320,6 +342,8 @@ class UnifiedVoice:
 		if trunc_index + max_new > self.max_ctx or max_new + 2 > c.max_mel_seq_len:
 			raise _lib.TTKError(f"prefix {trunc_index} + {max_new} new tokens exceed max_ctx={self.max_ctx} "
 								f"or the mel position table ({c.max_mel_seq_len})")
+		if n_in >= max_new:      # HF's stopping criterion is only looked at after a token has been appended: the reference would still sample one
+			raise ValueError(f"{n_in} prompt tokens leave no room below max_generate_length={max_new}")
 		suppress = tuple(kw.get("suppress_tokens") or ())
 		pipe_key = (kw.get("temperature", 1.0), kw.get("top_k", 50), kw.get("top_p", 1.0), kw.get("repetition_penalty", 1.0),
 					suppress, typical_mass)
@@ -331,25 +355,26 @@ class UnifiedVoice:
 			setup_seed(kw.get("seed", 0))
 			gen = torch.cuda.default_generators[self.device.index or 0]
 			off_start = gen.get_offset()
-			st.reset(c)
+			st.reset(c, prompt)
 			if st.own_rng:
-				st.arm_noise(gen, lo)
+				st.arm_noise(gen, lo, n_in)
 			try:
-				n = self._token_loop(st, gen, off_start, lambda: self._prefill(cond, text, B), max_new, can_stop)
+				n = self._token_loop(st, gen, off_start, lambda: self._prefill(cond, text, B, prompt), max_new, can_stop, n_in)
 			finally:
 				if st.own_rng:
 					_lib.check(self.lib.ttk_ar_set_noise(self._h, None, None, None), "ttk_ar_set_noise")
 			if st.own_rng:
-				gen.set_offset(off_start + n * st.noise_step)        # what n torch draws would have consumed
+				gen.set_offset(off_start + (n - n_in) * st.noise_step)        # what the n - n_in torch draws would have consumed
 			# what the sampling consumed from the generator: dist.py aligns a shard's stream with the unsharded run's from this
-			self.last_generate = dict(steps=n, rng_start=off_start, rng_step=(gen.get_offset() - off_start) // max(n, 1))
+			self.last_generate = dict(steps=n - n_in, rng_start=off_start, rng_step=(gen.get_offset() - off_start) // max(n - n_in, 1))
 			self._check_health()
 			return st.ids[:, :n].clone(), None
 
-	def _token_loop(self, st, gen, off_start, prefill, max_new, can_stop):
+	def _token_loop(self, st, gen, off_start, prefill, max_new, can_stop, n0=0):
+		"""n0: id columns that are filled already (the prompt tokens of a prompted continuation); returns the filled columns at the end"""
 		c = self.cfg
 		st.logits.copy_(prefill())
-		n = 0
+		n = n0
 		if not (self.use_graph and st.graphable):
 			while True:
 				st.sample(n)
@@ -367,10 +392,10 @@ class UnifiedVoice:
 			# always has work queued.  The <= LAG tokens generated past the true end are all padding; they are cut off below
 			# and the generator offset they consumed is handed back, so ids AND the RNG stream equal the reference's.
 			LAG = 2
-			st.sample(0)
+			st.sample(n0)
 			if st.rng_step is None:
 				st.rng_step = gen.get_offset() - off_start
-			n = 1
+			n = n0 + 1
 			events = []
 			stopped = can_stop and int(st.unfinished.max()) == 0
 			while n < max_new and not stopped:
@@ -424,7 +449,7 @@ class UnifiedVoice:
 				ids = st.ids[:, :n]
 				is_stop = ids == c.stop_mel_token
 				if bool(is_stop.any(dim=1).all()):
-					n_true = int(is_stop.float().argmax(dim=1).max()) + 1
+					n_true = max(int(is_stop.float().argmax(dim=1).max()) + 1, n0 + 1)
 					if n_true < n:
 						if not st.own_rng:
 							gen.set_offset(gen.get_offset() - (n - n_true) * st.rng_step)
@@ -628,15 +653,16 @@ class _GenState:
 		finally:
 			gen.set_state(keep)
 
-	def arm_noise(self, gen, lo):
-		"""point the mel-head launches of this call at q, starting from the generator's current state"""
+	def arm_noise(self, gen, lo, n0=0):
+		"""point the mel-head launches of this call at q, starting from the generator's current state.  n0: id columns filled before the first draw (prompt
+		tokens): the launches number their draws by the column counter, so the first offset is moved back by n0 draws"""
 		seed = gen.initial_seed()
 		seed = seed - (1 << 64) if seed >= (1 << 63) else seed
-		self.rng.copy_(torch.tensor([seed, gen.get_offset(), self.noise_threads, self.noise_step, lo, self.noise_rows if self.lines > 1 else 0], dtype=torch.long))
+		self.rng.copy_(torch.tensor([seed, gen.get_offset() - n0 * self.noise_step, self.noise_threads, self.noise_step, lo, self.noise_rows if self.lines > 1 else 0], dtype=torch.long))
 		m = self.model
 		_lib.check(m.lib.ttk_ar_set_noise(m._h, self.rng.data_ptr(), self.col.data_ptr(), self.q[lo].data_ptr()), "ttk_ar_set_noise")
 
-	def reset(self, c):
+	def reset(self, c, prompt=None):
 		self.ids.fill_(self.stop)
 		self.unfinished.fill_(1)
 		self.col.zero_()
@@ -645,6 +671,12 @@ class _GenState:
 		if self.history is not None:
 			self.history.fill_(1)
 			self.history[:, 1] = c.start_mel_token
+		if prompt is not None and prompt.shape[1]:      # a prompted continuation: the prompt tokens are the first id columns (and part of what the repetition penalty sees)
+			n0 = prompt.shape[1]
+			self.ids[:, :n0] = prompt
+			self.col.fill_(n0)
+			if self.history is not None:
+				self.history[:, 2:2 + n0] = prompt
 
 	def sample(self, n):
 		"""one token from self.logits: process / warp, sample, pad finished rows, record, and write the next step's input row

@@ -17,10 +17,12 @@ struct ARLayer {
 };
 
 // rows of the prefill input: [cond | start_text, text.., stop_text | start_mel]      (unified_voice.py:639-649, :203-211)
+// rows of the prefill: [cond | start_text, text.., stop_text | start_mel | prompt tokens (optional: prompted continuation, unified_voice.py:651-656)];
+// the mel rows sit at mel positions 0, 1, ..., n_in   (GPT2InferenceModel.forward's first branch, unified_voice.py:203-211)
 __global__ void k_build_prefill_emb(const float* cond, int Bc, const int64_t* text, int Tt, int B, int d,
 									const float* text_emb, const float* text_pos, const float* mel_emb, const float* mel_pos,
-									int start_text, int stop_text, int start_mel, float* out) {
-	const int S = Tt + 4;
+									int start_text, int stop_text, int start_mel, float* out, const int64_t* prompt = nullptr, int prompt_rows = 0, int n_in = 0) {
+	const int S = Tt + 4 + n_in;
 	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int d4 = d / 4;
 	if (idx >= (int64_t)B * S * d4) return;
@@ -30,8 +32,10 @@ __global__ void k_build_prefill_emb(const float* cond, int Bc, const int64_t* te
 	float4 v;
 	if (s == 0) {
 		v = *(const float4*)(cond + (int64_t)(Bc == 1 ? 0 : b) * d + c);
-	} else if (s == S - 1) {
-		const float4 e = *(const float4*)(mel_emb + (int64_t)start_mel * d + c), w = *(const float4*)(mel_pos + c);
+	} else if (s >= Tt + 3) {
+		const int j = s - (Tt + 3);   // mel position: 0 = start_mel, j >= 1 = prompt token j - 1
+		const int64_t tok = j == 0 ? start_mel : prompt[(int64_t)(prompt_rows == 1 ? 0 : b) * n_in + j - 1];
+		const float4 e = *(const float4*)(mel_emb + tok * d + c), w = *(const float4*)(mel_pos + (int64_t)j * d + c);
 		v = make_float4(e.x + w.x, e.y + w.y, e.z + w.z, e.w + w.w);
 	} else {
 		const int j = s - 1;   // position in [start, text.., stop]
@@ -400,35 +404,51 @@ int ttk_ar_destroy(ttk_ar* h) {
 	return TTK_OK;
 }
 
-int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, int B, float* logits_out, void* stream) {
-	TTK_REQUIRE(h && cond_latent && text && logits_out, TTK_E_ARG, "ttk_ar_prefill: null argument");
+static int prefill_impl(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, const int64_t* prompt, int prompt_rows, int n_in, int B, float* logits_out,
+						void* stream, const char* who) {
+	TTK_REQUIRE(h && cond_latent && text && logits_out, TTK_E_ARG, "%s: null argument", who);
 	const ttk_ar_config& c = h->cfg;
-	TTK_REQUIRE(B >= 1 && B <= c.max_batch, TTK_E_ARG, "ttk_ar_prefill: B=%d exceeds max_batch=%d", B, c.max_batch);
-	TTK_REQUIRE(Bc == 1 || Bc == B, TTK_E_ARG, "ttk_ar_prefill: cond batch %d must be 1 or B=%d", Bc, B);
-	TTK_REQUIRE(Tt >= 1 && Tt + 2 <= c.max_text_seq_len, TTK_E_ARG, "ttk_ar_prefill: %d text tokens exceed the position table (%d)", Tt, c.max_text_seq_len - 2);
-	const int S = Tt + 4, d = c.model_dim;
-	TTK_REQUIRE(S + 1 <= c.max_ctx, TTK_E_ARG, "ttk_ar_prefill: prefix of %d rows does not fit max_ctx=%d", S, c.max_ctx);
+	TTK_REQUIRE(B >= 1 && B <= c.max_batch, TTK_E_ARG, "%s: B=%d exceeds max_batch=%d", who, B, c.max_batch);
+	TTK_REQUIRE(Bc == 1 || Bc == B, TTK_E_ARG, "%s: cond batch %d must be 1 or B=%d", who, Bc, B);
+	TTK_REQUIRE(Tt >= 1 && Tt + 2 <= c.max_text_seq_len, TTK_E_ARG, "%s: %d text tokens exceed the position table (%d)", who, Tt, c.max_text_seq_len - 2);
+	TTK_REQUIRE(n_in == 0 || (prompt && (prompt_rows == 1 || prompt_rows == B)), TTK_E_ARG, "%s: %d prompt tokens need 1 or B=%d prompt rows (got %d)", who, n_in, B, prompt_rows);
+	TTK_REQUIRE(n_in >= 0 && n_in + 2 < c.max_mel_seq_len, TTK_E_ARG, "%s: %d prompt tokens exceed the mel position table (%d)", who, n_in, c.max_mel_seq_len);
+	const int S = Tt + 4 + n_in, d = c.model_dim;
+	TTK_REQUIRE(S + 1 <= c.max_ctx, TTK_E_ARG, "%s: prefix of %d rows does not fit max_ctx=%d", who, S, c.max_ctx);
 	hipStream_t s = (hipStream_t)stream;
 	// One conditioning latent and one text line for all B candidates (what inference_speech passes): the B prefixes are the same rows, so
 	// the prefix is run ONCE and its cache rows live in candidate 0's slice only -- the decode attention reads rows [0, S) there for every
-	// candidate (AttnDecodeParams.shared_rows) -- and the last row / the logits are replicated.
-	const bool shared = Bc == 1 && B > 1 && h->share_prefix && h->nsplit == 1;
+	// candidate (AttnDecodeParams.shared_rows) -- and the last row / the logits are replicated.  (A prompt shared by all candidates is part of that
+	// prefix; with one prompt per candidate every candidate's rows are run and cached on their own.)
+	const bool shared = Bc == 1 && B > 1 && h->share_prefix && h->nsplit == 1 && (n_in == 0 || prompt_rows == 1);
 	const int Bp = shared ? 1 : B;
 	TTK_TRY(h->ws_x.reserve((size_t)Bp * S * d * sizeof(float)));
 	float* x = (float*)h->ws_x.p;
 	const int64_t total = (int64_t)Bp * S * (d / 4);
 	hipLaunchKernelGGL(k_build_prefill_emb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cond_latent, Bc, text, Tt, Bp, d,
-					   h->text_emb, h->text_pos, h->mel_emb, h->mel_pos, c.start_text_token, c.stop_text_token, c.start_mel_token, x);
+					   h->text_emb, h->text_pos, h->mel_emb, h->mel_pos, c.start_text_token, c.stop_text_token, c.start_mel_token, x, prompt, prompt_rows, n_in);
 	TTK_TRY(dense_forward(h, x, Bp, S, true, s));
 	launch_copy_rows(x + (size_t)(S - 1) * d, shared ? 0 : (int64_t)S * d, h->x, d, B, d, s);      // source stride 0: one row to all candidates
 	head_launch(h, B, logits_out, nullptr, s);
 	launch_set_int(h->d_pos, S, s);
 	launch_set_int(h->d_pos + 1, shared ? S : 0, s);      // rows of the shared prefix (AttnDecodeParams.shared_rows): device-resident, like the cache length
 	TTK_TRY(poison_scratch(h, s));
-	h->B = B; h->P = h->Pmax = Tt + 3; h->k = 0; h->ready = 1; h->lines_mode = 0;
+	// k = mel tokens behind start_mel that are cached already: the decode step's capacity and position checks count from it (the position itself is taken
+	// from the cache length on the device: cached rows - P, the reference's attention_mask.shape[1] - mel_len)
+	h->B = B; h->P = h->Pmax = Tt + 3; h->k = n_in; h->ready = 1; h->lines_mode = 0;
 	h->shared_rows = shared ? S : 0;
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;
+}
+
+int ttk_ar_prefill(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, int B, float* logits_out, void* stream) {
+	return prefill_impl(h, cond_latent, Bc, text, Tt, nullptr, 0, 0, B, logits_out, stream, "ttk_ar_prefill");
+}
+
+int ttk_ar_prefill_prompted(ttk_ar* h, const float* cond_latent, int Bc, const int64_t* text, int Tt, const int64_t* prompt, int prompt_rows, int n_prompt, int B,
+							float* logits_out, void* stream) {
+	TTK_REQUIRE(n_prompt >= 1 && prompt, TTK_E_ARG, "ttk_ar_prefill_prompted: needs at least one prompt token");
+	return prefill_impl(h, cond_latent, Bc, text, Tt, prompt, prompt_rows, n_prompt, B, logits_out, stream, "ttk_ar_prefill_prompted");
 }
 
 // Several text lines as ONE decode batch (no reference counterpart: TTS.inference walks its lines one by one, inference.py:244-246, each with
