@@ -244,9 +244,9 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 	}
 }
 
-// NWM x NWN waves per workgroup; 8 waves (2 per SIMD) let one wave's MFMAs run under another's LDS reads and DMA issue.
-template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
-__global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
+// One output tile [m0, m0 + BM) x [n0, n0 + BN): operand staging, the k-loop and the epilogue.  `wave` = this wave's index among the NWM x NWN waves of the tile.
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, const int wave) {
 	typedef GRole<ROLE> R;
 	static_assert(!R::on || (sizeof(T) == 2 && R::N % BN == 0), "roles are 16-bit, N a multiple of the tile width");
 	constexpr int ES = sizeof(T);
@@ -263,43 +263,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	constexpr int STAGE = (BM + BN) * 128;
 	typedef typename Frag<T>::type FragT;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-
-	// what the prologue and the first segment read, as one batch of scalar loads (the ~500-byte argument block was fetched in six dependent round trips:
-	// a wave's first DMA request left 1.8 us after its first instruction, 1.2 us with the batch -- tests/diag/ddim_chain.cpp; pinning the epilogue's
-	// fields as well costs more in SGPR pressure than it returns, profiles/r03 notes)
-	if constexpr (R::on) {
-		if constexpr (R::CONV) TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.tiles_m), TTK_S(p.inv_tiles_m), TTK_S(p.rows_per_batch), TTK_S(p.inv_rpb));
-		else TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.tiles_m), TTK_S(p.inv_tiles_m));
-	} else {
-		TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.N), TTK_S(p.K), TTK_S(p.nseg), TTK_S(p.W), TTK_S(p.ldw), TTK_S(p.rows_per_batch), TTK_S(p.m_major),
-					 TTK_S(p.seg[0].A), TTK_S(p.seg[0].lda), TTK_S(p.seg[0].shift), TTK_S(p.seg[0].w_off));
-	}
-	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int tid = threadIdx.x, lane = tid & 63;
 #ifdef TTK_STAMPS
 	unsigned long long* const stamps_ = p.stamps;
 #endif
-	TTK_WSTAMP(stamps_, blockIdx.x, 0);
 	const int wm = wave / NWN, wn = wave % NWN;
-	const int tiles_m = R::on ? p.tiles_m : (p.M + BM - 1) / BM;
-	// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give
-	// each XCD label (blockIdx % 8) a CONTIGUOUS run of the n-major tile order = a few n-tiles x all m-tiles.  Its private 4 MiB
-	// L2 then holds that weight slice while the activations stream through once, instead of every XCD caching all of W.
-	int tile_id;
-	{
-		const int nwg = R::on ? tiles_m * (R::N / BN) : (int)gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-		tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-	}
-	// p.m_major: the XCD's run of tiles is a few m-tiles x ALL n-tiles instead -- its L2 then holds the whole weight matrix plus an eighth of
-	// the activations, which is the smaller working set when the matrix (N x K) is smaller than the activation panel (M x K)
-	int m0, n0;
-	if constexpr (R::on) {      // n-major order, no integer division
-		const int tn = div_recip(tile_id, tiles_m, p.inv_tiles_m);
-		m0 = (tile_id - tn * tiles_m) * BM; n0 = tn * BN;
-	} else {
-		const int tiles_n = (p.N + BN - 1) / BN;
-		m0 = p.m_major ? (tile_id / tiles_n) * BM : (tile_id % tiles_m) * BM;
-		n0 = p.m_major ? (tile_id % tiles_n) * BN : (tile_id / tiles_m) * BN;
-	}
 	const int KT = R::on ? GR_K / BKE : p.K / BKE;
 	const int NTILES = R::on ? R::NSEG * KT : p.nseg * KT;
 
@@ -535,6 +503,80 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 #endif
 }
 
+// NWM x NWN waves per workgroup; 8 waves (2 per SIMD) let one wave's MFMAs run under another's LDS reads and DMA issue.
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
+	typedef GRole<ROLE> R;
+
+	// what the prologue and the first segment read, as one batch of scalar loads (the ~500-byte argument block was fetched in six dependent round trips:
+	// a wave's first DMA request left 1.8 us after its first instruction, 1.2 us with the batch -- tests/diag/ddim_chain.cpp; pinning the epilogue's
+	// fields as well costs more in SGPR pressure than it returns, profiles/r03 notes)
+	if constexpr (R::on) {
+		if constexpr (R::CONV) TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.tiles_m), TTK_S(p.inv_tiles_m), TTK_S(p.rows_per_batch), TTK_S(p.inv_rpb));
+		else TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.tiles_m), TTK_S(p.inv_tiles_m));
+	} else {
+		TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.N), TTK_S(p.K), TTK_S(p.nseg), TTK_S(p.W), TTK_S(p.ldw), TTK_S(p.rows_per_batch), TTK_S(p.m_major),
+					 TTK_S(p.seg[0].A), TTK_S(p.seg[0].lda), TTK_S(p.seg[0].shift), TTK_S(p.seg[0].w_off));
+	}
+	const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef TTK_STAMPS
+	unsigned long long* const stamps_ = p.stamps;
+#endif
+	TTK_WSTAMP(stamps_, blockIdx.x, 0);
+	const int tiles_m = R::on ? p.tiles_m : (p.M + BM - 1) / BM;
+	// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give
+	// each XCD label (blockIdx % 8) a CONTIGUOUS run of the n-major tile order = a few n-tiles x all m-tiles.  Its private 4 MiB
+	// L2 then holds that weight slice while the activations stream through once, instead of every XCD caching all of W.
+	int tile_id;
+	{
+		const int nwg = R::on ? tiles_m * (R::N / BN) : (int)gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+		tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+	}
+	// p.m_major: the XCD's run of tiles is a few m-tiles x ALL n-tiles instead -- its L2 then holds the whole weight matrix plus an eighth of
+	// the activations, which is the smaller working set when the matrix (N x K) is smaller than the activation panel (M x K)
+	int m0, n0;
+	if constexpr (R::on) {      // n-major order, no integer division
+		const int tn = div_recip(tile_id, tiles_m, p.inv_tiles_m);
+		m0 = (tile_id - tn * tiles_m) * BM; n0 = tn * BN;
+	} else {
+		const int tiles_n = (p.N + BN - 1) / BN;
+		m0 = p.m_major ? (tile_id / tiles_n) * BM : (tile_id % tiles_m) * BM;
+		n0 = p.m_major ? (tile_id % tiles_n) * BN : (tile_id / tiles_m) * BN;
+	}
+	gemm_tile<T, BM, BN, NWM, NWN, NSTAGE, ROLE>(p, m0, n0, wave);
+}
+
+// Mixed grid for the statistics roles when the 128 x 64 tiling leaves a few tiles more than there are CUs (the DDIM step at T = 1088: 17 x 16 = 272 tiles on 256
+// CUs -- the 16 CUs that hold two finish 1.4 x later and set the length of three launches per layer: 25.9 us against 19.5 us for the same k = 3 conv at T = 1024,
+// profiles/r04_ddim_chain_T1024_vs_T1088.log).  The first `mix_full` workgroups are the full tiles of the first mix_fm tile rows, one per CU; the remaining rows are cut into
+// 64 x 64 tiles run by TWO waves each (the other two leave at once), so the surplus is spread over twice as many CUs in pieces half the size, and
+// every wave still owns a 64-row x 32-channel statistics chunk.  Same k order per output element as any other tiling: same bits.
+template <typename T, int ROLE>
+__global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmParams p) {
+	typedef GRole<ROLE> R;
+	static_assert(R::on && R::N == 1024, "mixed grids serve the 1024-wide roles");
+	if constexpr (R::CONV) TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.mix_full), TTK_S(p.mix_fm), TTK_S(p.inv_tiles_m), TTK_S(p.rows_per_batch), TTK_S(p.inv_rpb));
+	else TTK_PIN_ARGS(TTK_S(p.M), TTK_S(p.W), TTK_S(p.seg[0].A), TTK_S(p.mix_full), TTK_S(p.mix_fm), TTK_S(p.inv_tiles_m));
+	const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef TTK_STAMPS
+	unsigned long long* const stamps_ = p.stamps;
+#endif
+	TTK_WSTAMP(stamps_, blockIdx.x, 0);
+	const int b = blockIdx.x;
+	if (b < p.mix_full) {      // full tiles, XCD-aware n-major order over mix_fm x 16 tiles (p.inv_tiles_m = 1 / mix_fm)
+		const int nwg = p.mix_full, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+		const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+		const int tn = div_recip(tile_id, p.mix_fm, p.inv_tiles_m);
+		gemm_tile<T, 128, 64, 2, 2, 3, ROLE>(p, (tile_id - tn * p.mix_fm) * 128, tn * 64, wave);
+	} else {                   // half-height tiles of the remaining rows: j = row block * 16 + (n-tile & 1) * 8 + XCD, n-tile = 2 * XCD + (n-tile & 1) -- the XCD whose L2 holds that weight slice
+		// (64 x 32 tiles on ONE wave each, over 64 CUs, were tried as well: a lone wave's k-loop is slower than the full tile beside it -- 116.0 against 114.5 us per
+		// layer, 130.0 against 128.3 ms per loop; profiles/r04_ddim_chain_mixed_quarter.log)
+		if (wave >= 2) return;
+		const int j = b - p.mix_full;
+		gemm_tile<T, 64, 64, 1, 2, 3, ROLE>(p, p.mix_fm * 128 + (j >> 4) * 64, (2 * (j & 7) + ((j >> 3) & 1)) * 64, wave);
+	}
+}
+
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
 static void launch_tile(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	constexpr int LDS = NSTAGE * (BM + BN) * 128;
@@ -552,10 +594,33 @@ static void launch_tile(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hi
 	hipExtLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE>), dim3(grid), dim3(64 * NWM * NWN), (unsigned)LDS, s, ea, eb, 0, p);
 }
 
+// see k_gemm_mixed: tile rows [0, fm) as full 128 x 64 tiles (fm x 16 = 256 of them), the remaining M - 128 fm rows as 64 x 64 tiles
+static int g_mixed_mode = -1;      // TTK_GEMM_MIXED=0 switches the mixed grid off (A/B runs); read again at handle creation
+static bool mixed_grid_applies(const GemmParams& p) {
+	if (g_mixed_mode < 0) { const char* e = getenv("TTK_GEMM_MIXED"); g_mixed_mode = e ? atoi(e) : 1; }
+	if (!g_mixed_mode || p.N != 1024 || p.M % 64 != 0) return false;
+	const int tiles_m = (p.M + 127) / 128;
+	return tiles_m * 16 > 256 && tiles_m * 16 <= 320;      // 2048 < M <= 2560: at most 64 full tiles' worth of surplus rows
+}
+template <typename T, int ROLE>
+static void launch_mixed(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
+	constexpr int LDS = 3 * (128 + 64) * 128;
+	static bool attr_set = false;
+	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_mixed<T, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+	GemmParams p = p_in;
+	p.mix_fm = 16; p.mix_full = 256;
+	p.tiles_m = p.mix_fm;
+	p.inv_tiles_m = 1.0f / (float)p.mix_fm;
+	p.inv_rpb = p.rows_per_batch > 0 ? 1.0f / (float)p.rows_per_batch : 0.f;
+	p.inv_gn_T = p.gn_T > 0 ? 1.0f / (float)p.gn_T : 0.f;
+	const int blocks64 = (p.M - 128 * p.mix_fm) / 64;
+	hipExtLaunchKernelGGL((k_gemm_mixed<T, ROLE>), dim3(p.mix_full + blocks64 * 16), dim3(256), (unsigned)LDS, s, ea, eb, 0, p);
+}
+
 // The role of a launch, or GR_NONE: every field a role fixes at compile time must have exactly that value (TTK_GEMM_ROLE=0 switches the roles off: A/B runs and
 // the test that the specialised kernels give the generic kernel's bits; read again by gemm_roles_refresh at every handle creation).
 int g_gemm_roles = -1;
-void gemm_roles_refresh() { const char* e = getenv("TTK_GEMM_ROLE"); g_gemm_roles = e ? (atoi(e) == 1 ? 0x1E : atoi(e)) : 0x1E; }      // 0 = off, 1 = all, else a bit mask of GemmRole values
+void gemm_roles_refresh() { g_mixed_mode = -1; const char* e = getenv("TTK_GEMM_ROLE"); g_gemm_roles = e ? (atoi(e) == 1 ? 0x1E : atoi(e)) : 0x1E; }      // 0 = off, 1 = all, else a bit mask of GemmRole values
 static int gemm_role_of_unmasked(const GemmParams& p, int es);
 static int gemm_role_of(const GemmParams& p, int es) {
 	const int r = gemm_role_of_unmasked(p, es);
@@ -580,6 +645,13 @@ static int gemm_role_of_unmasked(const GemmParams& p, int es) {
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
 static void launch_tile_role(int role, const GemmParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	if constexpr (sizeof(T) == 2) {
+		if constexpr (BM == 128 && BN == 64) {      // a few tiles more than CUs: the surplus rows as half-height tiles (k_gemm_mixed)
+			if ((role == GR_IN1x1 || role == GR_CONV3_RES || role == GR_PROJ_RES) && mixed_grid_applies(p)) {
+				if (role == GR_IN1x1) return launch_mixed<T, GR_IN1x1>(p, s, ea, eb);
+				if (role == GR_CONV3_RES) return launch_mixed<T, GR_CONV3_RES>(p, s, ea, eb);
+				return launch_mixed<T, GR_PROJ_RES>(p, s, ea, eb);
+			}
+		}
 		if constexpr (BN <= 128 && BM != 256) {      // the 1024-wide roles run 128 x 64 (one utterance) or 128 x 128 (line batches) tiles
 			if (role == GR_IN1x1) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_IN1x1>(p, s, ea, eb);
 			if (role == GR_CONV3_RES) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_CONV3_RES>(p, s, ea, eb);

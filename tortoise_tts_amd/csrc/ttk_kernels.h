@@ -68,6 +68,7 @@ struct GemmParams {
 	// filled by launch_gemm for the role-specialised instantiations (GemmRole): reciprocals that replace the kernel's run-time integer divisions
 	// (x / d as an f32 product + one correction step, exact for x < 2^23) -- by the m-tile count, rows_per_batch and gn_T
 	int tiles_m; float inv_tiles_m, inv_rpb, inv_gn_T;
+	int mix_full, mix_fm;      // k_gemm_mixed: full tiles (= mix_fm tile rows x 16) in front of the half-height tiles of the remaining rows
 #ifdef TTK_STAMPS
 	unsigned long long* stamps;   // diagnostic build only
 #endif
