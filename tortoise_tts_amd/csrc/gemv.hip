@@ -305,6 +305,7 @@ static void gemv_mt(const GemvParams& p, hipStream_t s, hipEvent_t ea, hipEvent_
 	const int mt = decode_row_tiles(p.M);
 	if (mt == 1) gemv_go<T, 1, ROLE, NW, KPW, W8>(p, s, ea, eb);
 	else if (mt == 2) gemv_go<T, 2, ROLE, NW, KPW, W8>(p, s, ea, eb);
+	else if (mt == 3 && sizeof(T) == 2) gemv_go<T, sizeof(T) == 2 ? 3 : 2, ROLE, NW, KPW, W8>(p, s, ea, eb);
 	else if (sizeof(T) == 2) gemv_go<T, sizeof(T) == 2 ? 4 : 2, ROLE, NW, KPW, W8>(p, s, ea, eb);      // (f32 batches end at 32 rows: gemv_supported)
 }
 

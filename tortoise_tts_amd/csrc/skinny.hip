@@ -465,6 +465,7 @@ static void launch_skinny_t(const SkinnyParams& p, int waves, hipStream_t s, hip
 	const int mt = decode_row_tiles(p.M);
 	if (mt == 1) launch_skinny_mt<T, 1, W8>(p, waves, s, ea, eb);
 	else if (mt == 2) launch_skinny_mt<T, 2, W8>(p, waves, s, ea, eb);
+	else if (mt == 3) launch_skinny_mt<T, 3, W8>(p, waves, s, ea, eb);
 	else launch_skinny_mt<T, 4, W8>(p, waves, s, ea, eb);
 }
 

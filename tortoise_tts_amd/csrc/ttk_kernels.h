@@ -130,10 +130,11 @@ void launch_skinny(int dt, const SkinnyParams& p, int waves, hipStream_t s);
 // folded), one compile-time specialisation per role; bit-identical to k_skinny on the same operands.  launch_gemv returns false (and launches
 // nothing) for a geometry it has no instantiation for: the caller then takes launch_skinny.
 enum GemvRole { GV_QKV = 0, GV_PROJ = 1, GV_FC = 2, GV_HEAD = 3 };
-// Sixteen-row tiles a decode launch is INSTANTIATED for when the batch has M rows (k_gemv / k_skinny: MT = 1, 2 or 4).  A launch requests EVERY tile of
+// Sixteen-row tiles a decode launch is INSTANTIATED for when the batch has M rows (k_gemv / k_skinny: MT = 1, 2, 3 or 4; round 4 added 3: three lines of
+// 16 candidates as one decode batch ran the 4-tile form, a quarter of its MFMA and operand traffic on zero rows).  A launch requests EVERY tile of
 // its instantiation from the fragment-order operands, so the buffers behind them must hold 16 * decode_row_tiles(max_batch) rows: ttk_ar_create sizes
 // them with this function and every decode entry re-checks it (round 3's fault was a create-time size derived from max_batch alone).
-inline int decode_row_tiles(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
+inline int decode_row_tiles(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 48 ? 3 : 4)); }
 
 struct GemvParams {
 	const void* Wp;             // weights in fragment order [n_tile][K/32][lane][8] (GV_QKV / GV_FC: gamma o W)
