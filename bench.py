@@ -136,7 +136,7 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 	L = len(marks_per_line)
 	# candidate shards with several lines: the lines' diffusions are spread over the ranks (dist.assign_diffusers), so THIS rank's "ddim" interval covers the
 	# lines it diffused (one ragged batch) -- possibly none; "_"-prefixed marks bracket time that belongs to no phase of the line that carries them
-	L_ddim = sum(1 for marks in marks_per_line if any(n == "ddim" for n, _ in marks))
+	L_ddim = sum((m[2] if len(m) > 2 else 1) for marks in marks_per_line for m in marks if m[0] == "ddim")
 	e_w = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
 	e_kv = 4 if dtype_name == "f32" else 2
 	peak_f = 157.3e12 if dtype_name == "f32" else 2.5e15

@@ -212,7 +212,8 @@ def test_sharded_lines_diffused_together_equal_the_per_line_calls(small):
 		assert s0 == s1 and torch.equal(m0, m1) and torch.equal(a0["codes"], a1["codes"]) and a0["best"] == a1["best"] and torch.equal(a0["scores"], a1["scores"])
 	# phase marks: every line has its sampling and latent-pass marks, the shared diffusion ends the last line's list
 	# ("_before_ddim" brackets what lies between a line's latent pass and the shared diffusion: bench.phase_roofline keeps "_" marks out of its phases)
-	assert [[n for n, _ in lm] for lm in marks] == [["start", "ar_decode", "latent_pass"]] * 2 + [["start", "ar_decode", "latent_pass", "_before_ddim", "ddim"]]
+	assert marks[2][-1][2] == 3                                      # the shared diffusion's mark says how many lines it served
+	assert [[m[0] for m in lm] for lm in marks] == [["start", "ar_decode", "latent_pass"]] * 2 + [["start", "ar_decode", "latent_pass", "_before_ddim", "ddim"]]
 
 
 def test_tokens_to_waveform_with_the_vocoder(small):

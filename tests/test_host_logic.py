@@ -177,6 +177,10 @@ def test_bench_phase_roofline_on_a_rank_that_diffused_nothing_or_one_of_two_line
 	assert ph["ddim"]["ms"] is None and ph["ddim"]["frac"] is None and ph["ddim"]["flop"] == 0 and ph["ddim"]["lines_diffused_here"] == 0
 	assert ph["ar_decode"]["ms"] == 1800.0 and ph["whole_step_ms"] == 1900.0
 	# rank 0 of a 2-line text at N >= 2: line 0 is diffused here (after line 1 was sampled: the wait is bracketed by "_before_ddim"), line 1 elsewhere
+	# one rank, both lines diffused as ONE batch: the interval sits on the last line's marks and says that it served two lines
+	both = bench.phase_roofline([no_ddim, no_ddim + [("_before_ddim", Ev(1000.0)), ("ddim", Ev(2200.0), 2)]], "bf16", 256, 32, 500, 200)
+	one_line = bench.phase_roofline([no_ddim + [("ddim", Ev(1550.0))]], "bf16", 256, 32, 500, 200)
+	assert both["ddim"]["lines_diffused_here"] == 2 and both["ddim"]["flop"] == 2 * one_line["ddim"]["flop"] and both["ddim"]["ms"] == 1200.0
 	line0 = no_ddim + [("_before_ddim", Ev(1900.0)), ("ddim", Ev(2600.0))]
 	ph = bench.phase_roofline([line0, no_ddim], "bf16", 256, 32, 500, 200)
 	one = bench.phase_roofline([no_ddim + [("ddim", Ev(1650.0))]], "bf16", 256, 32, 500, 200)

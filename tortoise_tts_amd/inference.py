@@ -64,11 +64,11 @@ class HotPathStages:
 		self.diffusion_temp, self.sampler = diffusion_temp, diffusion_sampler
 		self.pad_token = self.ar.stop_mel_token
 
-	def _mark(self, name):
+	def _mark(self, name, *extra):
 		if self.phase_marks is not None:
 			ev = torch.cuda.Event(enable_timing=True)
 			ev.record()
-			self.phase_marks.append((name, ev))
+			self.phase_marks.append((name, ev) + extra)
 
 	def sample(self, lo, hi, n_candidates):
 		self._mark("start")
@@ -121,7 +121,7 @@ class HotPathStages:
 		else:
 			mels = [self.diffuser.sample_loop(self.diff, (1, 100, T), sampler=self.sampler, noise=n, model_kwargs={"precomputed_aligned_embeddings": E},
 											  progress=False, consume_rng=self.sampler != "ddim") for (_, n, T), E in zip(prepared, Es)]
-		self._mark("ddim")
+		self._mark("ddim", len(prepared))      # (name, event, lines diffused in this batch): bench.phase_roofline prices the interval with that many lines' work
 		return mels
 
 	def diffuse(self, codes, latents):
