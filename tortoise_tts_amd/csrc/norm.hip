@@ -287,6 +287,62 @@ __global__ __launch_bounds__(GN_TOUCH_WAVE ? 320 : 256) void k_gn_apply_c1024(Gn
 #endif
 }
 
+// k_gn_apply_c1024 with the rows dealt EVENLY over the chip: grid (strips, batch) with strips x batch <= 256 workgroups, strip w owning q rows + one more for the
+// first `rem` strips (q = T / strips, rem = T % strips, both from the host: no division here) -- one workgroup per CU, 8 or 9 rows each at the DDIM step's T = 1088.
+// The fixed 4-row strips make 544 workgroups there, 2.125 per CU: the 32 CUs that hold three set the launch (4.4 us against 3.7 us for the same launch at T = 1024,
+// where 512 workgroups are two per CU; profiles/r04_ddim_chain_T1024_vs_T1088.log).  Up to GN_MAXR rows per thread, every request up front; elementwise, same
+// arithmetic: bit-identical output.
+template <typename OT, int GN_MAXR>
+__global__ __launch_bounds__(320) void k_gn_apply_c1024_even(GnApplyParams p, int q, int rem) {
+	constexpr int C = 1024;
+	__shared__ unsigned pf_sink[64 * 4];
+	TTK_PIN_ARGS(TTK_S(p.x), TTK_S(p.ms), TTK_S(p.gamma), TTK_S(p.beta), TTK_S(p.scale), TTK_S(p.shift), TTK_S(p.ss_stride), TTK_S(p.T), TTK_S(p.nchunks),
+				 TTK_S(p.act), TTK_S(p.out), TTK_S(p.pf), TTK_S(p.pf_bytes), TTK_S(p.pf_taps), TTK_S(q), TTK_S(rem));
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 0);
+	const int tid = threadIdx.x;
+	if (tid >= 256) {      // the touch wave: the following GEMM's weights into L2 (see GnApplyParams), then gone
+		if (p.pf) l2_touch_for_next(p.pf, p.pf_bytes, p.pf_taps, __builtin_amdgcn_readfirstlane(lds_byte_addr(pf_sink)), blockIdx.y * gridDim.x + blockIdx.x,
+									gridDim.x * gridDim.y, tid - 256, 64);
+		return;
+	}
+	const int b = blockIdx.y, w = blockIdx.x;
+	const int t0 = w * q + (w < rem ? w : rem), nrows = q + (w < rem ? 1 : 0);
+	const int c = tid * 4;
+	float4 xv[GN_MAXR];
+#pragma unroll
+	for (int i = 0; i < GN_MAXR; ++i)
+		if (i < nrows) xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + t0 + i) * C + c);
+	const float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
+	float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+	if (p.scale) { sc = *(const float4*)(p.scale + (int64_t)b * p.ss_stride + c); sh = *(const float4*)(p.shift + (int64_t)b * p.ss_stride + c); }
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 1);
+	float mean, rstd;
+	{
+		const int g = tid >> 3, sub = tid & 7;
+		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
+		gn_merge_triples(part, p.nchunks, sub, [](const float* qq) { return *qq; }, mean, rstd);
+	}
+	TTK_WSTAMPD(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 2, rstd);
+	float a0, a1, a2, a3, d0, d1, d2, d3;
+	gn_fold_coef(mean, rstd, ga.x, be.x, sc.x, sh.x, a0, d0); gn_fold_coef(mean, rstd, ga.y, be.y, sc.y, sh.y, a1, d1);
+	gn_fold_coef(mean, rstd, ga.z, be.z, sc.z, sh.z, a2, d2); gn_fold_coef(mean, rstd, ga.w, be.w, sc.w, sh.w, a3, d3);
+#pragma unroll
+	for (int i = 0; i < GN_MAXR; ++i) {
+		if (i >= nrows) continue;
+		float o0 = gn_fold_apply(xv[i].x, a0, d0), o1 = gn_fold_apply(xv[i].y, a1, d1), o2 = gn_fold_apply(xv[i].z, a2, d2), o3 = gn_fold_apply(xv[i].w, a3, d3);
+		if (p.act == ACT_SILU) { o0 = silu_f(o0); o1 = silu_f(o1); o2 = silu_f(o2); o3 = silu_f(o3); }
+		OT* dst = (OT*)p.out + ((int64_t)b * p.T + t0 + i) * C + c;
+		if (sizeof(OT) == 1) *(unsigned*)dst = pack4_fp8(o0, o1, o2, o3);
+		else if (sizeof(OT) == 2) *(uint2*)dst = pack4_16<OT>(o0, o1, o2, o3);
+		else *(float4*)dst = make_float4(o0, o1, o2, o3);
+	}
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 4);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 5);
+#endif
+}
+
 template <int PASSES>
 static void launch_gn_apply_p(int dt, const GnApplyParams& p, hipStream_t s) {
 	const int strip = (256 / (p.C / 4)) * PASSES;
@@ -303,6 +359,21 @@ void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
 	if (fast && p.C == 1024 && !p.row_idx && p.Tout == p.T && passes == 2 && p.nb <= 65535) {      // the DDIM loop's launches: k_gn_apply_c1024
 		// rows per thread: with 2 the 1088 five-wave workgroups of a DDIM step do not fit the chip at once (two waves of each land on one SIMD: 4 per CU, 1024 slots) and
 		// the last 64 start 3 us late; with 4 all 544 are resident within 0.5 us (tests/diag/ddim_chain: 4.5 / 5.1 / 5.2 -> 4.2 / 4.7 / 4.8 us per launch)
+		// rows dealt evenly, one workgroup per CU (k_gn_apply_c1024_even), when a sequence's rows split into <= 256 / nb strips of 4 .. 18 rows and the batch is not ragged
+		static const int even = [] { const char* e = getenv("TTK_GN_EVEN"); return e ? atoi(e) : 1; }();
+		if (even && !p.tlen && p.nb >= 1 && p.nb <= 64) {
+			const int strips = 256 / p.nb, q = p.T / strips, rem = p.T % strips;
+			if (q >= 4 && q + (rem ? 1 : 0) <= 18) {
+				const dim3 grid(strips, p.nb);
+#define GN_EVEN(OT) hipLaunchKernelGGL((k_gn_apply_c1024_even<OT, 18>), grid, dim3(320), 0, s, p, q, rem)
+				if (p.out_f8) GN_EVEN(f8);
+				else if (p.out_f32 || dt == DT_F32) GN_EVEN(float);
+				else if (dt == DT_F16) GN_EVEN(f16);
+				else GN_EVEN(bf16);
+#undef GN_EVEN
+				return;
+			}
+		}
 		static const int cp = [] { const char* e = getenv("TTK_GN_C1024_PASSES"); return e && atoi(e) == 2 ? 2 : 4; }();
 		const dim3 grid((p.T + cp - 1) / cp, p.nb);
 		// the weight touches on a fifth wave (default) or, TTK_GN_TOUCH_WAVE=0, issued by the four working waves once their own loads are consumed:
