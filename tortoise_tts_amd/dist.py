@@ -151,15 +151,14 @@ def _move_item(tensors: Optional[List[torch.Tensor]], src: int, dev, group=None)
 	shape) + one broadcast per tensor, on the communicator the mel broadcast uses anyway.  <= 2 MB per line (latents [1, L, d] + start noise [1, 100, T])."""
 	rank = dist.get_rank(group)
 	gsrc = dist.get_global_rank(group, src) if group is not None else src
-	head = torch.zeros(1 + 8 * 6, dtype=torch.long, device=dev)
+	words = [0] * (1 + 8 * 6)
 	if rank == src:
 		assert len(tensors) <= 8 and all(t.dim() <= 4 for t in tensors)
-		head[0] = len(tensors)
+		words[0] = len(tensors)
 		for i, t in enumerate(tensors):
-			head[1 + 6 * i] = _DTYPES.index(t.dtype)
-			head[2 + 6 * i] = t.dim()
-			for j, n in enumerate(t.shape):
-				head[3 + 6 * i + j] = n
+			words[1 + 6 * i], words[2 + 6 * i] = _DTYPES.index(t.dtype), t.dim()
+			words[3 + 6 * i: 3 + 6 * i + t.dim()] = list(t.shape)
+	head = torch.tensor(words, dtype=torch.long).to(dev)      # (built on the host: one copy, not one per word)
 	dist.broadcast(head, src=gsrc, group=group)
 	h = head.tolist()
 	out = []
