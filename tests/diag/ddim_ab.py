@@ -10,10 +10,11 @@ dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 df = DiffusionTTS(W.synth_state_dict(W.diffusion_shapes(W.DIFF_FULL), 0), W.DIFF_FULL, dtype=os.environ.get("TTK_DDIM_DTYPE", "bf16"), device=dev)
 g = torch.Generator().manual_seed(1)
-T = 1088
+T = int(os.environ.get("TTK_AB_T", "1088"))      # frames (TTK_AB_T=2176: a configs[3] line)
 E = torch.randn(1, 1024, T, generator=g).to(dev)
 noise = torch.randn(1, 100, T, generator=g).to(dev)
-run = lambda: get_diffuser(80, True).sample_loop(df, (1, 100, T), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E})
+STEPS = int(os.environ.get("TTK_AB_STEPS", "80"))
+run = lambda: get_diffuser(STEPS, True).sample_loop(df, (1, 100, T), sampler="ddim", noise=noise, model_kwargs={"precomputed_aligned_embeddings": E})
 with torch.inference_mode():
 	run(); torch.cuda.synchronize()
 	ts = []

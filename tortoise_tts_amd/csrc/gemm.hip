@@ -652,7 +652,7 @@ static void launch_tile_role(int role, const GemmParams& p, hipStream_t s, hipEv
 				return launch_mixed<T, GR_PROJ_RES>(p, s, ea, eb);
 			}
 		}
-		if constexpr (BN <= 128 && BM != 256) {      // the 1024-wide roles run 128 x 64 (one utterance) or 128 x 128 (line batches) tiles
+		if constexpr (BN <= 128) {      // the 1024-wide roles run 128 x 64 (one utterance), 128 x 128 or 256 x 128 tiles (longer utterances, line batches)
 			if (role == GR_IN1x1) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_IN1x1>(p, s, ea, eb);
 			if (role == GR_CONV3_RES) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_CONV3_RES>(p, s, ea, eb);
 			if (role == GR_PROJ_RES) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_PROJ_RES>(p, s, ea, eb);
@@ -689,11 +689,18 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 	// GEMM of a DDIM step at T = 1088 (408 tiles -> 216).  In-kernel stamps inside the replayed chain (tests/diag/ddim_chain.cpp): the second round starts
 	// 11.2 us into a 21.1 us launch; 256 x 128 x 8 waves takes 18.5 us.  (2-stage ring, two workgroups per CU: 25.6; 128 x 64: 22.9.)  Same k order per
 	// output element, so the same bits.  TTK_GEMM_TILE_WIDE overrides (tuning).
+	// Round 4: the same choice by ROUNDS, statistics GEMMs included.  Both tiles run one workgroup per CU (96 / 144 KiB of LDS), so a launch lasts rounds x tile time, a
+	// 256 x 128 tile taking ~1.5 x a 128 x 128 one (twice the work at the 64 x 64 wave block's better LDS economy): take the wide tile when ceil(t256 / 256) x 1.5 is
+	// more than a tenth below ceil(t128 / 256).  One line of T = 2176 (M = 4352, N = 1024: 272 tiles of 128 x 128 = two rounds for 6 % more than one; QKV 816 = four
+	// rounds) runs 40 DDIM steps in 124.7 ms with wide tiles against 133.7 ms (tests/diag/ddim_ab.py, TTK_AB_T=2176); the benchmarked T = 1088 and the latent pass choose as before.
 	static const int wide = [] { const char* e = getenv("TTK_GEMM_TILE_WIDE"); return e ? atoi(e) : -2; }();
-	if (g_force_tile < 100 && tile == 0 && !p.gn_part) {
+	if (g_force_tile < 100 && tile == 0) {
 		const int t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128), t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
 		if (wide >= 0) { if (p.N >= 3072) tile = wide; }
-		else if (wide == -2 && t128 > 256 && t128 < 512 && t256 <= 256 && sizeof(T) == 2) tile = 8;
+		else if (wide == -2 && sizeof(T) == 2 && t128 > 256) {
+			const int r128 = (t128 + 255) / 256, r256 = (t256 + 255) / 256;
+			if (15 * r256 < 9 * r128) tile = 8;      // 1.5 r256 < 0.9 r128
+		}
 	}
 	const int role = gemm_role_of(p, (int)sizeof(T));
 	if (tile == 0) launch_tile_role<T, 128, 128, 2, 4, 3>(role, p, s, ea, eb);       // 8 waves, wave block 64 x 32, two workgroups per CU
@@ -703,7 +710,7 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 	else if (tile == 5) launch_tile<T, 128, 64, 4, 2, 3>(p, s, ea, eb);   // as 1 with 8 waves (wave block 32 x 32): twice the waves issuing the LDS-DMA pieces
 	else if (tile == 6) launch_tile<T, 128, 64, 2, 4, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 16
 	else if (tile == 7) launch_tile<T, 256, 64, 4, 2, 3>(p, s, ea, eb);   // 8 waves, wave block 64 x 32, 120 KiB: one workgroup per CU
-	else if (tile == 8) launch_tile_role<T, 256, 128, 4, 2, 3>(role == GR_QKV ? role : GR_NONE, p, s, ea, eb);  // 8 waves, wave block 64 x 64, 144 KiB: one workgroup per CU
+	else if (tile == 8) launch_tile_role<T, 256, 128, 4, 2, 3>(role, p, s, ea, eb);  // 8 waves, wave block 64 x 64, 144 KiB: one workgroup per CU
 	else if (tile == 9) launch_tile<T, 128, 128, 2, 4, 2>(p, s, ea, eb);  // as 0 with a 2-stage ring (64 KiB: two workgroups per CU)
 	// (128 x 64 as TWO waves of 64 x 64 -- a third less fragment traffic out of LDS per flop -- 158.9 ms per DDIM loop against 138.9 for tile 1 everywhere; with a 4-stage ring 213.7: not kept)
 	else launch_tile<T, 64, 64, 2, 2, 3>(p, s, ea, eb);
