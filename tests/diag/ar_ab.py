@@ -9,11 +9,12 @@ from tortoise_tts_amd.autoregressive import UnifiedVoice
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 B = int(os.environ.get("TTK_AB_B", "16"))
-ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtype=os.environ.get("TTK_AB_DTYPE", "bf16"), device=dev, max_batch=B, max_ctx=64 + 4 + 250 + 8)
+NTEXT, NNEW = int(os.environ.get("TTK_AB_TEXT", "64")), int(os.environ.get("TTK_AB_NEW", "250"))      # TTK_AB_B=32 TTK_AB_TEXT=256 TTK_AB_NEW=500: a configs[3] shard
+ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(W.AR_FULL), 0), W.AR_FULL, dtype=os.environ.get("TTK_AB_DTYPE", "bf16"), device=dev, max_batch=B, max_ctx=NTEXT + 4 + NNEW + 8)
 g = torch.Generator().manual_seed(1234)
-text = torch.randint(1, 255, (1, 64), generator=g).to(dev)
+text = torch.randint(1, 255, (1, NTEXT), generator=g).to(dev)
 cond = torch.randn(1, 1024, generator=g).to(dev)
-run = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=B, max_generate_length=250, suppress_tokens=[8193])
+run = lambda: ar.inference_speech(cond, text, do_sample=True, temperature=0.8, top_k=0, num_return_sequences=B, max_generate_length=NNEW, suppress_tokens=[8193])
 with torch.inference_mode():
 	run(); run(); torch.cuda.synchronize()
 	ts = []
