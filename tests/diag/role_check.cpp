@@ -18,10 +18,17 @@ static float frand() { return (float)(rand() & 0xFFFFFF) / 16777216.f * 2.f - 1.
 
 int main(int argc, char** argv) {
 	const int T = argc > 1 ? atoi(argv[1]) : 1088, nb = argc > 2 ? atoi(argv[2]) : 2, M = nb * T, C = 1024;
+	const bool f8 = argc > 3 && !strcmp(argv[3], "f8");      // fp8-e4m3 operands (one byte per element, tensor scale 2^-3 in the epilogue) instead of bf16
+	const int dt = f8 ? DT_FP8 : DT_BF16;
 	srand(1);
 	std::vector<unsigned short> hA((size_t)M * C), hW((size_t)3 * 3 * C * C);
 	for (auto& v : hA) v = f2bf(frand());
 	for (auto& v : hW) v = f2bf(frand() * 0.05f);
+	if (f8) {      // the same buffers read as bytes: random e4m3 codes below the NaN encodings (exponent field < 15), either sign
+		unsigned char* a8 = (unsigned char*)hA.data(); unsigned char* w8 = (unsigned char*)hW.data();
+		for (size_t i = 0; i < hA.size() * 2; ++i) a8[i] = (unsigned char)(((rand() & 1) << 7) | (rand() % 0x60));
+		for (size_t i = 0; i < hW.size() * 2; ++i) w8[i] = (unsigned char)(((rand() & 1) << 7) | (rand() % 0x50));
+	}
 	std::vector<float> hb(3 * C), hr((size_t)M * C);
 	for (auto& v : hb) v = frand();
 	for (auto& v : hr) v = frand();
@@ -40,6 +47,7 @@ int main(int argc, char** argv) {
 			g_gemm_roles = pass == 0 ? 0 : 0x1E;
 			GemmParams g = {};
 			g.W = Wt; g.ldw = C; g.M = M; g.K = C; g.bias = bias; g.C = Cout[pass];
+			if (f8) g.out_scale = 0.125f;
 			CK(hipMemset(Cout[pass], 0xFF, (size_t)M * 3 * C * 4)); CK(hipMemset(part[pass], 0xFF, (size_t)nb * 32 * nch * 3 * 4));
 			if (role == GR_QKV) { g.nseg = 1; g.seg[0] = {A, C, 0, 0}; g.N = 3 * C; g.ldc = 3 * C; g.out_f32 = 0; cbytes = (size_t)M * 3 * C * 2; }
 			else {
@@ -52,7 +60,7 @@ int main(int argc, char** argv) {
 					g.residual = Cout[pass]; g.ldr = C;
 				}
 			}
-			launch_gemm(DT_BF16, g, s);
+			launch_gemm(dt, g, s);
 			CK(hipStreamSynchronize(s));
 		}
 		if (skipped) continue;

@@ -26,11 +26,11 @@ def build(diff_sd, dtype, roles, monkeypatch):
 	return DiffusionTTS(diff_sd, W.DIFF_FULL, dtype=dtype, device=DEV)
 
 
-@pytest.mark.parametrize("dtype,T", [("bf16", 1088), ("bf16", 1000), ("f16", 1088), ("bf16", 320), ("bf16", 1216), ("bf16", 2176)])
+@pytest.mark.parametrize("dtype,T", [("bf16", 1088), ("bf16", 1000), ("f16", 1088), ("bf16", 320), ("bf16", 1216), ("bf16", 2176), ("fp8", 1088), ("fp8", 1000)])
 def test_role_kernels_equal_the_generic_kernel_bit_for_bit(diff_sd, monkeypatch, dtype, T):
 	"""T = 1088: the benchmarked shape (M = 2176: the MIXED grid of k_gemm_mixed -- 256 full 128 x 64 tiles + the 17th tile row as 32 half-height tiles on two
 	waves -- for the three statistics roles, 256 x 128 tiles for QKV); T = 1216: M = 2432, 48 half-height tiles; T = 1000: M = 2000 is not a multiple of the
-	tile height (guarded epilogue, rows beyond M); T = 320: 128 x 64 tiles for QKV as well; T = 2176 (a configs[3] line): 256 x 128 tiles for every role, statistics included.  Three DDIM steps each, and one plain evaluation."""
+	tile height (guarded epilogue, rows beyond M); T = 320: 128 x 64 tiles for QKV as well; T = 2176 (a configs[3] line): 256 x 128 tiles for every role, statistics included; dtype fp8: the same roles on fp8 operands (tensor scale in the epilogue).  Three DDIM steps each, and one plain evaluation."""
 	from tortoise_tts_amd.diffusion import get_diffuser
 	noise = torch.randn(1, 100, T, generator=gen(3)).to(DEV)
 	E = torch.randn(1, 1024, T, generator=gen(4)).to(DEV)

@@ -80,6 +80,7 @@ __device__ __forceinline__ void gn_block_stats(const f32x4 (&acc)[MI][NI], float
 // serialise 64 dependent L2 round trips per lane.  GUARD = tile crosses the M or N edge.
 template <typename T, int MODE, bool GUARD, int MI, int NI>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[MI][NI], int row0, int col0, int lane) {
+#pragma clang fp contract(off)      // scale, bias and residual stay three rounded operations in every instantiation (the role epilogue writes them the same way)
 	const int lr = 4 * (lane >> 4), lc = lane & 15;
 	typedef typename OutOf<T>::type OT;
 	if (p.out_scale != 0.f) {
@@ -202,6 +203,7 @@ __device__ __forceinline__ void load_residual_role(const GemmParams& p, float (&
 // PRE: `res` already holds the residual (requested under the last k-tiles, see the role kernels' tail)
 template <typename T, int ROLE, bool GUARD, int MI, int NI, bool PRE = false>
 __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[MI][NI], float (&res)[MI][4][NI], int row0, int col0, int lane) {
+#pragma clang fp contract(off)
 	typedef GRole<ROLE> R;
 	typedef typename OutOf<T>::type OT;
 	constexpr int N = R::N;
@@ -209,6 +211,7 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 	float bj[NI];
 #pragma unroll
 	for (int j = 0; j < NI; ++j) bj[j] = p.bias[col0 + 16 * j + lc];
+	const float os = sizeof(T) == 1 ? p.out_scale : 1.f;      // fp8 operands: the weights' power-of-two tensor scale (16-bit roles have none)
 	if constexpr (R::RES && !PRE) {      // all residual loads before the first store: C aliases the residual
 #pragma unroll
 		for (int i = 0; i < MI; ++i)
@@ -227,7 +230,9 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 			const int gm = row0 + 16 * i + lr + r;
 #pragma unroll
 			for (int j = 0; j < NI; ++j) {
-				float v = acc[i][j][r] + bj[j];
+				float v = acc[i][j][r];
+				if constexpr (sizeof(T) == 1) v = v * os;
+				v = v + bj[j];
 				if constexpr (R::RES) v += res[i][r][j];
 				acc[i][j][r] = v;
 				if (GUARD && gm >= p.M) continue;
@@ -248,7 +253,7 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, const int wave) {
 	typedef GRole<ROLE> R;
-	static_assert(!R::on || (sizeof(T) == 2 && R::N % BN == 0), "roles are 16-bit, N a multiple of the tile width");
+	static_assert(!R::on || (sizeof(T) <= 2 && R::N % BN == 0), "roles are 16-bit or fp8, N a multiple of the tile width");
 	constexpr int ES = sizeof(T);
 	constexpr bool F8 = ES == 1;       // fp8 operands: a lane's 16-byte read feeds two 16x16x32 MFMAs (k order is free as long as A and W agree)
 	constexpr int BKE = 128 / ES;      // K elements per tile row
@@ -448,7 +453,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	// that follow simply allow RESN more loads in flight.  (Round 3 requested the tile at the top of the kernel: 32 loads in front of the first DMA request cost more
 	// than the epilogue gained.)  Same values into the same additions: same bits.
 	constexpr int RESN = MI * 4 * NI;
-	constexpr bool PRE_RES = R::on && R::RES && NSTAGE == 3 && PER_TILE + RESN <= 63 && !F8;
+	constexpr bool PRE_RES = R::on && R::RES && NSTAGE == 3 && PER_TILE + RESN <= 63;
 	if constexpr (PRE_RES) {
 		constexpr int NT = R::NSEG * (GR_K / BKE);
 		static_assert(!PRE_RES || (NT % 2 == 0 && NT >= 8), "the peeled tail assumes an even tile count");
@@ -628,7 +633,8 @@ static int gemm_role_of(const GemmParams& p, int es) {
 }
 static int gemm_role_of_unmasked(const GemmParams& p, int es) {
 	if (g_gemm_roles < 0) gemm_roles_refresh();
-	if (!g_gemm_roles || es != 2 || p.K != GR_K || p.ldw != GR_K || !p.bias || p.act != ACT_NONE || p.out_scale != 0.f || p.transpose_out || p.m_major) return GR_NONE;
+	// (fp8 operands, es == 1: the same roles with the weights' tensor scale in the epilogue; 16-bit launches carry no scale)
+	if (!g_gemm_roles || (es != 2 && es != 1) || p.K != GR_K || p.ldw != GR_K || !p.bias || p.act != ACT_NONE || (es == 2) != (p.out_scale == 0.f) || p.transpose_out || p.m_major) return GR_NONE;
 	if (p.M < 1 || p.M > (1 << 19) || p.seg[0].lda != GR_K || p.seg[0].w_off != 0) return GR_NONE;      // 32-bit byte offsets and M * N < 2^30 element indices
 	if (p.nseg == 1 && p.seg[0].shift == 0) {
 		if (p.N == 3072 && !p.out_f32 && p.ldc == 3072 && !p.residual && !p.gn_part) return GR_QKV;
@@ -644,7 +650,7 @@ static int gemm_role_of_unmasked(const GemmParams& p, int es) {
 }
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE>
 static void launch_tile_role(int role, const GemmParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-	if constexpr (sizeof(T) == 2) {
+	if constexpr (sizeof(T) <= 2) {
 		if constexpr (BM == 128 && BN == 64) {      // a few tiles more than CUs: the surplus rows as half-height tiles (k_gemm_mixed)
 			if ((role == GR_IN1x1 || role == GR_CONV3_RES || role == GR_PROJ_RES) && mixed_grid_applies(p)) {
 				if (role == GR_IN1x1) return launch_mixed<T, GR_IN1x1>(p, s, ea, eb);
@@ -697,7 +703,7 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 	if (g_force_tile < 100 && tile == 0) {
 		const int t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128), t256 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
 		if (wide >= 0) { if (p.N >= 3072) tile = wide; }
-		else if (wide == -2 && sizeof(T) == 2 && t128 > 256) {
+		else if (wide == -2 && sizeof(T) <= 2 && t128 > 256) {
 			const int r128 = (t128 + 255) / 256, r256 = (t256 + 255) / 256;
 			if (15 * r256 < 9 * r128) tile = 8;      // 1.5 r256 < 0.9 r128
 		}
