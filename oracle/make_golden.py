@@ -22,6 +22,11 @@ Fixtures
   stft_ref.npz    STFT(1024, 256, 1024).transform magnitudes on seeded audio (arch_utils.py:560-623)
   tokenizer.npz   VoiceBpeTokenizer.encode / decode / preprocess_text on the reference vocabulary, digit-free ASCII texts (tokenizer.py:154-177)
   schedule.npz    get_diffuser(steps) tables for steps in 4, 30, 80, 200    (diffusion.py:1576-1590)
+  stress_ar.npz / stress_ar_full.npz / stress_diff.npz / stress_diff_cfg1.npz
+                  the same reference classes on weights moved to a trained checkpoint's numerical regime (tortoise_tts_amd/weights.py stress_*):
+                  peaked logits and attention rows, outlier residual channels, a near-constant GroupNorm group, large scale / shift; logits,
+                  latents, sample_stream ids under the CLI's warpers (top-k 16, top-p, repetition penalty, the reference's TypicalLogitsWarper),
+                  E / evaluations / DDIM steps, small models in full and full-size slices
 """
 import math
 import os
@@ -403,6 +408,221 @@ def sample_stream_case(uv_mod):
 	return out
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The stress family: the same reference classes on `tortoise_tts_amd.weights.stress_*` weights -- peaked softmax rows,
+# attention scores in the tens, outlier residual channels, a GroupNorm group of almost no variance, large scale / shift.
+# ------------------------------------------------------------------------------------------------------------------------------------
+STRESS_STREAM_CASES = (
+	# name, B, Tt, max new tokens, generation keywords (top_k 16 / temperature 0.8 are the CLI's defaults, __main__.py:16-19; the other flags are the ones
+	# it exposes :18-20 and unified_voice.py:633's typical_sampling / typical_mass)
+	("topk16", 4, 9, 24, dict(temperature=0.8, top_k=16)),
+	("topk16_topp_pen", 4, 9, 24, dict(temperature=0.8, top_k=16, top_p=0.8, repetition_penalty=2.0)),
+	("topk16_typical", 4, 9, 24, dict(temperature=0.8, top_k=16, typical_mass=0.9)),
+	("topp_only", 3, 7, 20, dict(temperature=1.0, top_p=0.8)),
+	("typical_only", 3, 7, 20, dict(temperature=1.0, typical_mass=0.9, repetition_penalty=1.5)),
+)
+
+
+STRESS_LOGIT_COLS = list(range(0, 96)) + list(range(8100, 8194))
+STRESS_ROW_STEPS = (1, 13)
+
+
+def _stream_with_logits(uv_mod, m, cfg, cond, text, B, max_new, kw):
+	"""The reference's sample_stream on model `m` with the processors / warpers generate() would build; the typical warper is the reference's OWN class
+	(unified_voice.py:47-75), placed where generate() puts a caller's logits_processor: behind the default processors (HF `_merge_criteria_processor_list`),
+	in front of the warpers.  Also returns the logits every token was drawn from (the model's output for the sequence the reference itself sampled)."""
+	import importlib
+	from transformers import GenerationConfig, LogitsProcessorList, RepetitionPenaltyLogitsProcessor, SuppressTokensLogitsProcessor
+	sg = importlib.import_module("tortoise_tts.models.stream_generator")
+	seen = []
+
+	class _Tap:                                        # first "processor": records the raw next-token logits, changes nothing
+		def __call__(self, input_ids, scores):
+			seen.append(scores.clone())
+			return scores
+	with torch.inference_mode():
+		ids = m.compute_embeddings(cond, text).repeat(B, 1)
+		im = m.inference_model
+		procs = LogitsProcessorList([_Tap()])
+		if kw.get("repetition_penalty", 1.0) != 1.0:
+			procs.append(RepetitionPenaltyLogitsProcessor(penalty=kw["repetition_penalty"]))
+		if kw.get("suppress_tokens"):
+			procs.append(SuppressTokensLogitsProcessor(kw["suppress_tokens"]))
+		if kw.get("typical_mass") is not None:
+			procs.append(uv_mod.TypicalLogitsWarper(mass=kw["typical_mass"]))
+		gc = GenerationConfig(do_sample=True, num_beams=1, temperature=kw.get("temperature", 1.0), top_k=kw.get("top_k", 0), top_p=kw.get("top_p", 1.0))
+		warpers = sg.NewGenerationMixin._get_logits_warper(im, gc)
+		sg.setup_seed(0)
+		toks, lats = [], []
+		for tok, lat in sg.NewGenerationMixin.sample_stream(
+				im, ids, logits_processor=procs, logits_warper=warpers, stopping_criteria=_ScalarMaxLength(ids.shape[1] + max_new),
+				pad_token_id=cfg.stop_mel_token, eos_token_id=cfg.stop_mel_token, output_hidden_states=True, return_dict_in_generate=False,
+				use_cache=True, attention_mask=torch.ones_like(ids)):
+			toks.append(tok.clone())
+			lats.append(lat.clone())
+	return torch.stack(toks, 1), torch.stack(lats, 1), torch.stack(seen, 1)
+
+
+def stress_ar_case(uv_mod):
+	"""UnifiedVoice(small) on `stress_ar` weights, both variants: prefill + decode logits + latents as `ar_case` stores them, and the reference's own
+	sample_stream under the CLI's warpers -- yielded ids, latents and the logits each token was drawn from."""
+	import json
+	cfg, seed = W.AR_SMALL, 14
+	out = dict(seed=np.int64(seed))
+	for variant in ("peaked", "outlier"):
+		base = W.synth_state_dict(W.ar_shapes(cfg), seed)
+		sd = W.stress_ar(base, cfg, variant)
+		m = uv_mod.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, checkpointing=False)
+		load_into(m, sd)
+		B, Tt, n_dec, M = 2, 12, 4, 10
+		text = torch.randint(1, 255, (1, Tt), generator=gen(seed + 1))
+		cond = torch.randn(1, cfg.model_dim, generator=gen(seed + 2))
+		dec_tokens = torch.randint(0, 8192, (B, n_dec), generator=gen(seed + 3))
+		codes = torch.randint(0, 8192, (B, M), generator=gen(seed + 4))
+		with torch.inference_mode():
+			ids = m.compute_embeddings(cond, text).repeat(B, 1)
+			im = m.inference_model
+			P1 = ids.shape[1]
+			r = im.forward(input_ids=ids, attention_mask=torch.ones(B, P1, dtype=torch.long), use_cache=True, return_dict=True)
+			pre, past, dec = r.logits[:, -1].float(), r.past_key_values, []
+			for k in range(1, n_dec + 1):
+				r = im.forward(input_ids=dec_tokens[:, k - 1:k], past_key_values=past, attention_mask=torch.ones(B, P1 + k, dtype=torch.long), use_cache=True, return_dict=True)
+				past = r.past_key_values
+				dec.append(r.logits[:, -1].float())
+			dec = torch.stack(dec, 1)
+			lat = m.forward(cond.repeat(B, 1), text.repeat(B, 1), torch.tensor([Tt] * B, dtype=torch.int32), codes,
+							torch.tensor([M * cfg.mel_length_compression] * B), return_latent=True, clip_inputs=False)
+		pmax = torch.softmax(dec / 0.8, -1).max(-1)[0]
+		print(f"  {variant}: logits std {float(dec.std()):.2f}, max token probability at T=0.8: median {float(pmax.median()):.3f}, max {float(pmax.max()):.3f}; |latent| max {float(lat.abs().max()):.1f}")
+		p = variant + "::"
+		out.update({p + "text": text.numpy(), p + "cond": cond.numpy(), p + "dec_tokens": dec_tokens.numpy(), p + "codes": codes.numpy(),
+					p + "prefill_logits": pre.numpy(), p + "decode_logits": dec.numpy(), p + "latents": lat.numpy()})
+		for name, B, Tt, max_new, kw in STRESS_STREAM_CASES:
+			text = torch.randint(1, 255, (1, Tt), generator=gen(seed + 11))
+			cond = torch.randn(1, cfg.model_dim, generator=gen(seed + 12))
+			toks, lats, logits = _stream_with_logits(uv_mod, m, cfg, cond, text, B, max_new, kw)
+			q = f"{variant}::{name}::"
+			# the logits every token was drawn from: a vocabulary slice at every step, whole rows at two steps of the cases whose cut is a cumulative mass
+			out.update({q + "text": text.numpy(), q + "cond": cond.numpy(), q + "ids": toks.numpy(), q + "latents": lats.numpy(), q + "logits_sub": logits[:, :, STRESS_LOGIT_COLS].numpy(),
+						q + "meta": np.array(json.dumps(dict(B=B, Tt=Tt, max_new=max_new, kw=kw)))})
+			if name in ("topk16_topp_pen", "typical_only"):
+				out.update({q + "row_steps": np.array(STRESS_ROW_STEPS, dtype=np.int64), q + "logit_rows": logits[:, list(STRESS_ROW_STEPS)].numpy()})
+			pm = torch.softmax(logits / kw.get("temperature", 1.0), -1).max(-1)[0]
+			print(f"  {variant}/{name}: {toks.shape[1]} yields, max-prob median {float(pm.median()):.3f}, ids[0][:10] = {toks[0, :10].tolist()}")
+	return out
+
+
+def stress_ar_full_case(uv_mod):
+	"""Full-size UnifiedVoice on the `outlier` stress weights: prefill + 2 decode steps (logit slices), a latent slice, and 12 tokens of the reference's
+	sample_stream with top-k 16 + repetition penalty (ids, the logits they were drawn from on a vocabulary slice)."""
+	import json
+	cfg, seed = W.AR_FULL, 15
+	sd = W.stress_ar(W.synth_state_dict(W.ar_shapes(cfg), seed), cfg, "outlier")
+	m = uv_mod.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, checkpointing=False)
+	load_into(m, sd)
+	B, Tt, n_dec, M = 2, 8, 2, 6
+	text = torch.randint(1, 255, (1, Tt), generator=gen(seed + 1))
+	cond = torch.randn(1, cfg.model_dim, generator=gen(seed + 2))
+	dec_tokens = torch.randint(0, 8192, (B, n_dec), generator=gen(seed + 3))
+	codes = torch.randint(0, 8192, (B, M), generator=gen(seed + 4))
+	sel = torch.cat([torch.arange(0, 96), torch.arange(8100, 8194)])
+	with torch.inference_mode():
+		ids = m.compute_embeddings(cond, text).repeat(B, 1)
+		im = m.inference_model
+		P1 = ids.shape[1]
+		r = im.forward(input_ids=ids, attention_mask=torch.ones(B, P1, dtype=torch.long), use_cache=True, return_dict=True)
+		pre, past, dec = r.logits[:, -1].float(), r.past_key_values, []
+		for k in range(1, n_dec + 1):
+			r = im.forward(input_ids=dec_tokens[:, k - 1:k], past_key_values=past, attention_mask=torch.ones(B, P1 + k, dtype=torch.long), use_cache=True, return_dict=True)
+			past = r.past_key_values
+			dec.append(r.logits[:, -1].float())
+		dec = torch.stack(dec, 1)
+		lat = m.forward(cond.repeat(B, 1), text.repeat(B, 1), torch.tensor([Tt] * B, dtype=torch.int32), codes,
+						torch.tensor([M * cfg.mel_length_compression] * B), return_latent=True, clip_inputs=False)
+	kw = dict(temperature=0.8, top_k=16, repetition_penalty=2.0)
+	toks, lats, logits = _stream_with_logits(uv_mod, m, cfg, cond, text, 2, 12, kw)
+	pm = torch.softmax(logits / 0.8, -1).max(-1)[0]
+	print(f"  full outlier: logits std {float(dec.std()):.2f}, max-prob median {float(pm.median()):.3f}; ids[0] = {toks[0].tolist()}")
+	return dict(seed=np.int64(seed), B=np.int64(B), text=text.numpy(), cond=cond.numpy(), dec_tokens=dec_tokens.numpy(), codes=codes.numpy(),
+				logit_cols=sel.numpy(), prefill_logits=pre[:, sel].numpy(), decode_logits=dec[:, :, sel].numpy(), latents=lat[:, :, :128].numpy(),
+				stream_ids=toks.numpy(), stream_logits=logits[:, :, sel].numpy(), stream_latents=lats[:, :, :128].numpy(),
+				stream_meta=np.array(json.dumps(dict(B=2, max_new=12, kw=kw))))
+
+
+def _attn_score_probe(d_mod, m, x_in):
+	"""largest |score + bias| inside the first main-layer AttentionBlock, for the log only"""
+	import importlib
+	au = importlib.import_module("tortoise_tts.models.arch_utils")
+	blk = m.layers[0].attn
+	with torch.inference_mode():
+		qkv = blk.qkv(blk.norm(x_in))
+		bs, width, length = qkv.shape
+		ch = width // (3 * blk.num_heads)
+		q, k, _ = qkv.reshape(bs * blk.num_heads, ch * 3, length).split(ch, dim=1)
+		s = 1 / math.sqrt(math.sqrt(ch))
+		wgt = torch.einsum("bct,bcs->bts", q * s, k * s)
+		wgt = blk.relative_pos_embeddings(wgt.reshape(bs, blk.num_heads, length, length))
+	return float(wgt.abs().max()), float(torch.softmax(wgt.float(), -1).max(-1)[0].median())
+
+
+def stress_diff_case(d_mod):
+	"""DiffusionTTS(small) on `stress_diffusion` weights: timestep_independent, one conditioned + one conditioning-free evaluation, and 8 DDIM steps
+	(the reference's own loop, guidance ramp on) from seeded noise, x kept after 2 / 4 / 8 steps."""
+	cfg, seed, b, M = W.DIFF_SMALL, 23, 2, 10
+	sd = W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), seed), cfg)
+	m = d_mod.DiffusionTTS(model_channels=cfg.model_channels, num_layers=cfg.num_layers, in_latent_channels=cfg.in_latent_channels, num_heads=cfg.num_heads)
+	load_into(m, sd)
+	T = M * 4 * 24000 // 22050
+	lat = torch.randn(b, M, cfg.in_latent_channels, generator=gen(seed + 1))
+	cond = torch.randn(b, 2 * cfg.model_channels, generator=gen(seed + 2))
+	x = torch.randn(b, 100, T, generator=gen(seed + 3))
+	t = torch.tensor([1333, 2666][:b])
+	noise = torch.randn(1, 100, T, generator=gen(seed + 5))
+	out = dict(latents=lat.numpy(), cond=cond.numpy(), x=x.numpy(), t=t.numpy(), T=np.int64(T), seed=np.int64(seed), noise=noise.numpy())
+	with torch.inference_mode():
+		E = m.timestep_independent(lat, cond, T, False)
+		yc = m(x, t, precomputed_aligned_embeddings=E)
+		yu = m(x, t, precomputed_aligned_embeddings=E, conditioning_free=True)
+		print(f"  small: |E| max {float(E.abs().max()):.1f}, |y| max {float(yc.abs().max()):.1f}, first-layer |score| max / median top weight: {_attn_score_probe(d_mod, m, E)}")
+		diffuser = d_mod.get_diffuser(steps=8, cond_free=True)
+		torch.manual_seed(0)
+		done = 0
+		for o in diffuser.ddim_sample_loop_progressive(m, (1, 100, T), noise=noise, clip_denoised=True, model_kwargs={"precomputed_aligned_embeddings": E[:1]},
+														device="cpu", progress=False, eta=0.0):
+			done += 1
+			if done in (2, 4, 8):
+				out[f"x_after_{done}"] = o["sample"].numpy().copy()
+	out.update(E=E.numpy(), y_cond=yc.numpy(), y_uncond=yu.numpy())
+	return out
+
+
+def stress_diff_cfg1_case(d_mod):
+	"""Full-size DiffusionTTS on `stress_diffusion` weights at configs[1]'s T = 1088: E, one evaluation pair (every 8th frame) and the LAST 4 steps of the
+	80-step DDIM schedule from seeded x (final mel whole)."""
+	cfg = W.DIFF_FULL
+	sd = W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), 2), cfg)
+	m = d_mod.DiffusionTTS(model_channels=cfg.model_channels, num_layers=cfg.num_layers, in_channels=cfg.in_channels,
+						   in_latent_channels=cfg.in_latent_channels, out_channels=cfg.out_channels, num_heads=cfg.num_heads)
+	load_into(m, sd)
+	M, T = 250, 250 * 4 * 24000 // 22050
+	lat = torch.randn(1, M, 1024, generator=gen(31))
+	dcond = torch.randn(1, 2048, generator=gen(32))
+	x = torch.randn(1, 100, T, generator=gen(33))
+	t = torch.tensor([1500])
+	diffuser = d_mod.get_diffuser(steps=80, cond_free=True)
+	with torch.inference_mode():
+		E = m.timestep_independent(lat, dcond, T, False)
+		yc = m(x, t, precomputed_aligned_embeddings=E)
+		yu = m(x, t, precomputed_aligned_embeddings=E, conditioning_free=True)
+		print(f"  full: |E| max {float(E.abs().max()):.1f}, |y| max {float(yc.abs().max()):.1f}, first-layer |score| max / median top weight: {_attn_score_probe(d_mod, m, E)}", flush=True)
+		xm = x
+		torch.manual_seed(0)
+		for i in reversed(range(4)):
+			xm = diffuser.ddim_sample(m, xm, torch.tensor([i]), clip_denoised=True, model_kwargs={"precomputed_aligned_embeddings": E}, eta=0.0)["sample"]
+	return dict(T=np.int64(T), M=np.int64(M), stride=np.int64(8), E_sub=E[:, :, ::8].numpy(), y_cond_sub=yc[:, :, ::8].numpy(),
+				y_uncond_sub=yu[:, :, ::8].numpy(), mel=xm.numpy())
+
+
 def vocoder_case(cfg, seed, T):
 	"""The reference BigVGAN generator (models/bigvgan.py) on synthetic weights: the anti-aliasing filter it builds, the weight-normed
 	state_dict key names, one AMP block, `forward` internals and `inference` (waveform)."""
@@ -578,6 +798,10 @@ def main():
 		("hf_sample_loop", hf_sample_loop_case),
 		("wrapper", lambda: wrapper_case(uv_mod)),
 		("sample_stream", lambda: sample_stream_case(uv_mod)),
+		("stress_ar", lambda: stress_ar_case(uv_mod)),
+		("stress_ar_full", lambda: stress_ar_full_case(uv_mod)),
+		("stress_diff", lambda: stress_diff_case(d_mod)),
+		("stress_diff_cfg1", lambda: stress_diff_cfg1_case(d_mod)),
 		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
 		("clvp_small", lambda: clvp_case(W.CLVP_SMALL, 61)),
 		("tokenizer", tokenizer_case),

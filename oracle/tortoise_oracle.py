@@ -222,15 +222,37 @@ def warp_top_p(scores: Tensor, top_p: float, min_tokens_to_keep: int = 1) -> Ten
 	return scores.masked_fill(remove, -float("inf"))
 
 
+def warp_typical(scores: Tensor, mass: float, min_tokens_to_keep: int = 1) -> Tensor:
+	"""unified_voice.py:47-75 TypicalLogitsWarper.__call__ (the reference's own class; `inference_speech(typical_sampling=True)` hands it to generate() as
+	a custom logits_processor, :657): tokens ordered by |(-log p) - H|, the closest ones kept until their mass reaches `mass`.  Pinned by
+	tests/golden/stress_ar.npz, whose `*_typical` cases ran that class inside the reference's sample_stream."""
+	logp = F.log_softmax(scores, dim=-1)
+	p = torch.exp(logp)
+	ent = -(logp * p).nansum(-1, keepdim=True)
+	dist = torch.abs((-logp) - ent)
+	sorted_dist, order = torch.sort(dist, descending=False)
+	cum = scores.gather(-1, order).softmax(dim=-1).cumsum(dim=-1)
+	last = (cum < mass).sum(dim=1)
+	last[last < 0] = 0
+	remove_sorted = sorted_dist > sorted_dist.gather(1, last.view(-1, 1))
+	if min_tokens_to_keep > 1:
+		remove_sorted[..., :min_tokens_to_keep] = 0
+	remove = remove_sorted.scatter(1, order, remove_sorted)
+	return scores.masked_fill(remove, -float("inf"))
+
+
 def process_logits(input_ids: Tensor, logits: Tensor, *, temperature=1.0, top_k=0, top_p=1.0,
-					repetition_penalty=1.0, suppress_tokens=None) -> Tensor:
+					repetition_penalty=1.0, suppress_tokens=None, typical_mass=None) -> Tensor:
 	"""Processor order of the reference's sample branch: HF `_get_logits_processor` (repetition penalty,
-	... suppress_tokens) then `_get_logits_warper` (stream_generator.py:80-85: Temperature -> TopK -> TopP)."""
+	... suppress_tokens, then the caller's `logits_processor` -- the typical warper, unified_voice.py:657 -- which HF's
+	`_merge_criteria_processor_list` appends behind the defaults) then `_get_logits_warper` (stream_generator.py:80-85: Temperature -> TopK -> TopP)."""
 	s = logits
 	if repetition_penalty is not None and repetition_penalty != 1.0:
 		s = warp_repetition_penalty(input_ids, s, repetition_penalty)
 	if suppress_tokens:
 		s = warp_suppress(s, suppress_tokens)
+	if typical_mass is not None:
+		s = warp_typical(s, typical_mass)
 	if temperature is not None and temperature != 1.0:
 		s = warp_temperature(s, temperature)
 	if top_k is not None and top_k != 0:
@@ -242,7 +264,8 @@ def process_logits(input_ids: Tensor, logits: Tensor, *, temperature=1.0, top_k=
 
 def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return_sequences=1,
 					max_generate_length=None, temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0,
-					suppress_tokens=None, sample_device="cpu", seed=0, return_logits=False, forced_tokens=None, input_tokens=None):
+					suppress_tokens=None, sample_device="cpu", seed=0, return_logits=False, forced_tokens=None, input_tokens=None,
+					typical_sampling=False, typical_mass=0.9):
 	"""unified_voice.py:632-668 + stream_generator.py:213-639 (sample branch) + HF `_sample`
 	HF:generation/utils.py:2894-2937.
 
@@ -292,7 +315,7 @@ def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_ret
 		if return_logits:
 			all_logits.append(logits.clone())
 		scores = process_logits(input_ids, logits, temperature=temperature, top_k=top_k, top_p=top_p,
-								repetition_penalty=repetition_penalty, suppress_tokens=suppress_tokens)
+								repetition_penalty=repetition_penalty, suppress_tokens=suppress_tokens, typical_mass=typical_mass if typical_sampling else None)
 		probs = F.softmax(scores.to(sample_device), dim=-1)
 		nxt = torch.multinomial(probs, num_samples=1).squeeze(1).cpu()
 		if forced_tokens is not None and n_drawn < forced_tokens.shape[1]:
@@ -313,7 +336,8 @@ def inference_speech(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_ret
 
 
 def sample_stream(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return_sequences=1, max_generate_length=None,
-				  temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0, suppress_tokens=None, sample_device="cpu", seed=0, prompt=None):
+				  temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.0, suppress_tokens=None, sample_device="cpu", seed=0, prompt=None,
+				  typical_mass=None, return_logits=False):
 	"""a6: `NewGenerationMixin.sample_stream` (stream_generator.py:911-1190) as `get_generator` drives it (unified_voice.py:670-679),
 	a generator of (next_tokens [B], latent [B, d]).  Pinned by tests/golden/sample_stream.npz, which the REFERENCE's own loop produced
 	(oracle/make_golden.py: sample_stream_case).  What that pin fixes:
@@ -342,11 +366,12 @@ def sample_stream(ar: AROracle, cond_latent: Tensor, text: Tensor, *, num_return
 	k = 0 if prompt is None else prompt.shape[1]
 	while True:
 		scores = process_logits(input_ids, logits, temperature=temperature, top_k=top_k, top_p=top_p,
-								repetition_penalty=repetition_penalty, suppress_tokens=suppress_tokens)
+								repetition_penalty=repetition_penalty, suppress_tokens=suppress_tokens, typical_mass=typical_mass)
 		probs = F.softmax(scores.to(sample_device), dim=-1)
 		nxt = torch.multinomial(probs, num_samples=1).squeeze(1).cpu()
 		nxt = nxt * unfinished + c.stop_mel_token * (1 - unfinished)
-		yield nxt, layer_norm(hidden, ar.w["final_norm.weight"], ar.w["final_norm.bias"])
+		lat = layer_norm(hidden, ar.w["final_norm.weight"], ar.w["final_norm.bias"])
+		yield (nxt, lat, logits) if return_logits else (nxt, lat)
 		input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
 		k += 1
 		unfinished = unfinished * (nxt != c.stop_mel_token).long()

@@ -1,0 +1,181 @@
+"""The oracle in the numerical regime of a trained checkpoint: tests/golden/stress_*.npz were produced by the REFERENCE's classes on
+`tortoise_tts_amd.weights.stress_*` weights (oracle/make_golden.py: stress_ar_case, stress_ar_full_case, stress_diff_case, stress_diff_cfg1_case) -- logits of
+std 8 (max token probability > 0.5), GPT-2 / diffusion attention scores in the tens to +-100, two residual channels x 300, one GroupNorm group of 3.0 +- 1e-2, large
+scale / shift.  The restatement must reproduce them like the random-weight fixtures: ids bit for bit on the CPU generator, activations to f32 summation-order noise."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import tortoise_oracle as O
+from tortoise_tts_amd import weights as W
+
+
+def t(a):
+	return torch.from_numpy(np.asarray(a))
+
+
+def _ar(variant, cfg=W.AR_SMALL, seed=14):
+	return O.AROracle(W.stress_ar(W.synth_state_dict(W.ar_shapes(cfg), seed), cfg, variant), cfg)
+
+
+def test_stress_transforms_touch_what_they_say():
+	cfg = W.AR_SMALL
+	base = W.synth_state_dict(W.ar_shapes(cfg), 14)
+	pk, ol = W.stress_ar(base, cfg, "peaked"), W.stress_ar(base, cfg, "outlier")
+	d = cfg.model_dim
+	assert torch.equal(pk["mel_head.weight"], base["mel_head.weight"] * 8)
+	w0, w1 = base["gpt.h.1.attn.c_attn.weight"], pk["gpt.h.1.attn.c_attn.weight"]
+	assert torch.equal(w1[:, :2 * d], w0[:, :2 * d] * 4) and torch.equal(w1[:, 2 * d:], w0[:, 2 * d:])
+	changed = [k for k in base if not torch.equal(base[k], pk[k])]
+	assert sorted(changed) == sorted(["mel_head.weight"] + [f"gpt.h.{i}.attn.c_attn.{l}" for i in range(cfg.layers) for l in ("weight", "bias")])
+	ch = list(W.AR_STRESS_CHANNELS)
+	e0, e1 = base["mel_embedding.weight"], ol["mel_embedding.weight"]
+	keep = [c for c in range(d) if c not in ch]
+	assert torch.equal(e1[:, ch], e0[:, ch] * 300) and torch.equal(e1[:, keep], e0[:, keep])
+	dc = W.DIFF_SMALL
+	db = W.synth_state_dict(W.diffusion_shapes(dc), 23)
+	ds = W.stress_diffusion(db, dc)
+	hd = dc.head_dim
+	q0, q1 = db["layers.0.attn.qkv.weight"], ds["layers.0.attn.qkv.weight"]
+	for h in range(dc.num_heads):
+		r = h * 3 * hd
+		assert torch.equal(q1[r:r + 2 * hd], q0[r:r + 2 * hd] * 4) and torch.equal(q1[r + 2 * hd:r + 3 * hd], q0[r + 2 * hd:r + 3 * hd])
+	cpg = dc.model_channels // 32
+	g = slice(W.DIFF_STRESS_GROUP * cpg, (W.DIFF_STRESS_GROUP + 1) * cpg)
+	assert bool((ds["layers.1.resblk.in_layers.2.bias"][g] == 3.0).all()) and float(ds["layers.1.resblk.in_layers.2.weight"][g].abs().max()) < 5e-3
+	assert torch.equal(ds["layers.0.resblk.emb_layers.1.weight"], db["layers.0.resblk.emb_layers.1.weight"] * 4)
+	assert torch.equal(ds["inp_block.weight"], db["inp_block.weight"])
+
+
+@pytest.mark.parametrize("variant", ["peaked", "outlier"])
+def test_ar_logits_and_latents_in_the_peaked_regime(golden, variant):
+	g = golden("stress_ar")
+	p = variant + "::"
+	ar = _ar(variant)
+	text, cond, toks, codes = t(g[p + "text"]), t(g[p + "cond"]), t(g[p + "dec_tokens"]), t(g[p + "codes"])
+	B = toks.shape[0]
+	want_dec = t(g[p + "decode_logits"])
+	# the regime itself: the fixture's rows are peaked
+	pmax = torch.softmax(want_dec / 0.8, -1).max(-1)[0]
+	assert float(pmax.median()) > 0.5 and float(want_dec.std()) > 6
+	with torch.inference_mode():
+		logits, past, _ = ar.prefill(ar.prefix_embeddings(cond, text), B)
+		assert (logits[:, -1] - t(g[p + "prefill_logits"])).abs().max() < 2e-3          # logits of +-30: 2e-3 is 1e-4 of their std-8 scale x ~3 sigma
+		for k in range(1, toks.shape[1] + 1):
+			lg, past, _ = ar.decode(toks[:, k - 1], k, past)
+			assert (lg - want_dec[:, k - 1]).abs().max() < 2e-3, k
+		lat = ar.forward_latents(cond.repeat(B, 1), text.repeat(B, 1), codes)
+	assert (lat - t(g[p + "latents"])).abs().max() < 2e-4
+
+
+@pytest.mark.parametrize("variant", ["peaked", "outlier"])
+def test_sample_stream_under_the_cli_warpers_equals_the_reference(golden, variant):
+	"""ids bit for bit, latents and the logits every token was drawn from, for every warper combination of the fixture -- the typical cases ran the reference's
+	own TypicalLogitsWarper (unified_voice.py:47-75), which pins `warp_typical` and its place in the chain"""
+	g = golden("stress_ar")
+	ar = _ar(variant)
+	names = sorted({k.split("::")[1] for k in g if k.startswith(variant + "::") and k.count("::") == 2})
+	assert names == sorted(["topk16", "topk16_topp_pen", "topk16_typical", "topp_only", "typical_only"])
+	cols = torch.cat([torch.arange(0, 96), torch.arange(8100, 8194)])
+	for name in names:
+		q = f"{variant}::{name}::"
+		meta = json.loads(str(g[q + "meta"]))
+		kw = dict(meta["kw"])
+		kw.setdefault("top_k", 0)
+		want_ids, want_lat, want_lg = t(g[q + "ids"]), t(g[q + "latents"]), t(g[q + "logits_sub"])
+		with torch.inference_mode():
+			out = list(O.sample_stream(ar, t(g[q + "cond"]), t(g[q + "text"]), num_return_sequences=meta["B"], max_generate_length=meta["max_new"], return_logits=True, **kw))
+			ids2 = O.inference_speech(ar, t(g[q + "cond"]), t(g[q + "text"]), num_return_sequences=meta["B"], max_generate_length=meta["max_new"],
+									   typical_sampling=kw.get("typical_mass") is not None, typical_mass=kw.get("typical_mass", 0.9),
+									   **{k: v for k, v in kw.items() if k != "typical_mass"})
+		ids = torch.stack([o[0] for o in out], 1)
+		assert torch.equal(ids, want_ids), (variant, name, (ids != want_ids).nonzero()[:4].tolist())
+		assert torch.equal(ids2, want_ids), (variant, name)
+		assert (torch.stack([o[1] for o in out], 1) - want_lat).abs().max() < 2e-4, (variant, name)
+		lg = torch.stack([o[2] for o in out], 1)
+		assert (lg[:, :, cols] - want_lg).abs().max() < 2e-3, (variant, name)
+		if q + "logit_rows" in g:
+			steps = g[q + "row_steps"].tolist()
+			assert (lg[:, steps] - t(g[q + "logit_rows"])).abs().max() < 2e-3
+
+
+def test_typical_warper_equals_the_reference_class_on_its_own_rows(golden):
+	"""`warp_typical` on the reference's stored logit rows keeps exactly the set HF-style masking would: checked against a from-definition f64 evaluation (tokens
+	sorted by |-log p - H|, kept up to and including the first whose cumulative mass reaches `mass`), away from f32 ties"""
+	g = golden("stress_ar")
+	rows = t(g["peaked::typical_only::logit_rows"]).reshape(-1, 8194)
+	kept = torch.isfinite(O.warp_typical(rows, 0.9))
+	for r in range(rows.shape[0]):
+		lp = torch.log_softmax(rows[r].double(), -1)
+		p = lp.exp()
+		H = -(lp * p).sum()
+		dist = (-lp - H).abs()
+		order = torch.argsort(dist)
+		cum = p[order].cumsum(0)
+		n_keep = int((cum < 0.9).sum()) + 1
+		want = torch.zeros(8194, dtype=torch.bool)
+		want[order[:n_keep]] = True
+		margin = min(abs(float(cum[n_keep - 1]) - 0.9), abs(float(cum[max(n_keep - 2, 0)]) - 0.9))
+		if margin > 1e-5:
+			assert torch.equal(kept[r], want), r
+	assert 1 <= int(kept.sum(-1).min()) and int(kept.sum(-1).max()) < 8194
+
+
+def test_ar_full_size_outlier_weights(golden):
+	g = golden("stress_ar_full")
+	cfg = W.AR_FULL
+	ar = _ar("outlier", cfg, int(g["seed"]))
+	text, cond, toks, codes = t(g["text"]), t(g["cond"]), t(g["dec_tokens"]), t(g["codes"])
+	B, cols = int(g["B"]), t(g["logit_cols"])
+	with torch.inference_mode():
+		logits, past, _ = ar.prefill(ar.prefix_embeddings(cond, text), B)
+		assert (logits[:, -1][:, cols] - t(g["prefill_logits"])).abs().max() < 5e-3
+		for k in range(1, toks.shape[1] + 1):
+			lg, past, _ = ar.decode(toks[:, k - 1], k, past)
+			assert (lg[:, cols] - t(g["decode_logits"])[:, k - 1]).abs().max() < 5e-3
+		lat = ar.forward_latents(cond.repeat(B, 1), text.repeat(B, 1), codes)
+		assert (lat[:, :, :128] - t(g["latents"])).abs().max() < 1e-3
+		meta = json.loads(str(g["stream_meta"]))
+		out = list(O.sample_stream(ar, cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], return_logits=True, **meta["kw"]))
+	assert torch.equal(torch.stack([o[0] for o in out], 1), t(g["stream_ids"]))
+	assert (torch.stack([o[2] for o in out], 1)[:, :, cols] - t(g["stream_logits"])).abs().max() < 5e-3
+	assert (torch.stack([o[1] for o in out], 1)[:, :, :128] - t(g["stream_latents"])).abs().max() < 1e-3
+
+
+def test_diffusion_small_in_the_peaked_regime(golden):
+	g = golden("stress_diff")
+	cfg = W.DIFF_SMALL
+	d = O.DiffusionOracle(W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), int(g["seed"])), cfg), cfg)
+	T = int(g["T"])
+	with torch.inference_mode():
+		E = d.timestep_independent(t(g["latents"]), t(g["cond"]), T)
+		assert (E - t(g["E"])).abs().max() < 1e-3 * max(1.0, float(np.abs(g["E"]).max()))
+		x, ts, Eg = t(g["x"]), t(g["t"]), t(g["E"])
+		sc = max(1.0, float(np.abs(g["y_cond"]).max()))
+		assert (d.forward(x, ts, Eg) - t(g["y_cond"])).abs().max() < 1e-3 * sc
+		assert (d.forward(x, ts, Eg, conditioning_free=True) - t(g["y_uncond"])).abs().max() < 1e-3 * sc
+		sched = O.SpacedSchedule(steps=8, cond_free=True)
+		xm, done = t(g["noise"]), 0
+		for i in reversed(range(8)):
+			xm = sched.ddim_step(d, xm, i, Eg[:1])
+			done += 1
+			if done in (2, 4, 8):
+				assert (xm - t(g[f"x_after_{done}"])).abs().max() < 2e-3, done
+
+
+def test_diffusion_full_size_evaluation_in_the_peaked_regime(golden):
+	"""one full-size evaluation pair at a short T through the oracle is enough here (the T = 1088 fixture is the GPU tests'): the oracle's blocks are the small
+	model's; what is checked is that the full-size stress fixture's subsampled E regenerates"""
+	g = golden("stress_diff_cfg1")
+	cfg = W.DIFF_FULL
+	d = O.DiffusionOracle(W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), 2), cfg), cfg)
+	M, T = int(g["M"]), int(g["T"])
+	gen = lambda s: torch.Generator().manual_seed(s)
+	lat = torch.randn(1, M, 1024, generator=gen(31))
+	dcond = torch.randn(1, 2048, generator=gen(32))
+	with torch.inference_mode():
+		E = d.timestep_independent(lat, dcond, T)
+	want = t(g["E_sub"])
+	assert (E[:, :, ::8] - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))

@@ -330,6 +330,79 @@ def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int, bf16_exact: 
 	return out
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The "stress" family: the seeded weights above moved to the numerical regime a TRAINED checkpoint lives in.  `gain / sqrt(fan_in)` Gaussians
+# give logits of std 1 (max token probability < 1 %), attention scores below 8 and unit-scale residual streams; trained TorToiSe weights
+# (models/__init__.py:23-44, download only) give peaked softmax rows, |score| in the tens, outlier residual channels and GroupNorm groups of
+# almost no variance.  The transforms are deterministic functions of the seeded tensors, so the fixture generator (oracle/make_golden.py, through
+# the reference's classes) and the tests (oracle and HIP path, on any box) build identical weights.
+# ------------------------------------------------------------------------------------------------------------------------------------
+AR_STRESS_CHANNELS = (5, 77)          # the two residual channels of the `outlier` variant (both < AR_SMALL.model_dim)
+DIFF_STRESS_GROUP = 3                 # the GroupNorm32 group every ResBlock's in_layers conv leaves almost constant
+DIFF_STRESS_FLAT_VALUE = 3.0
+DIFF_STRESS_FLAT_GAIN = 1e-2
+
+
+def stress_ar(sd: Dict[str, torch.Tensor], c: ARConfig, variant: str = "peaked") -> Dict[str, torch.Tensor]:
+	"""`peaked`: `mel_head.weight` x 8 (logits of std ~8: max token probability > 0.5, top-k / top-p / typical cuts inside a sharp distribution) and the
+	q / k columns (+ biases) of every `attn.c_attn` x 4 (GPT-2 scores x 16: attention rows close to one-hot, |score| in the tens).
+	`outlier`: `peaked` plus two channels of the four embedding tables x 300 -- massive activations in fixed residual channels, the stream a LayerNorm
+	(and the decode path's folded LayerNorm) then has to normalise."""
+	assert variant in ("peaked", "outlier"), variant
+	out, d = dict(sd), c.model_dim
+	out["mel_head.weight"] = sd["mel_head.weight"] * 8.0
+	for i in range(c.layers):
+		for leaf in ("weight", "bias"):
+			k = f"gpt.h.{i}.attn.c_attn.{leaf}"
+			t = sd[k].clone()
+			t[..., :2 * d] *= 4.0
+			out[k] = t
+	if variant == "outlier":
+		for k in ("text_embedding.weight", "mel_embedding.weight", "mel_pos_embedding.emb.weight", "text_pos_embedding.emb.weight"):
+			t = sd[k].clone()
+			t[:, list(AR_STRESS_CHANNELS)] *= 300.0
+			out[k] = t
+	return out
+
+
+def stress_diffusion(sd: Dict[str, torch.Tensor], c: DiffusionConfig) -> Dict[str, torch.Tensor]:
+	"""Every AttentionBlock: the q / k rows of `qkv` (head-major [H][3][hd] split, arch_utils.py:76-79) x 4 and `relative_attention_bias` x 10 -- scores of
+	+-60 .. 100, softmax rows close to one-hot.  Every ResBlock: `emb_layers` x 4 (large scale / shift) and the `in_layers` conv rows of GroupNorm group
+	DIFF_STRESS_GROUP x 1e-2 with bias 3.0: `out_layers.0` normalises a group whose channels are 3.0 +- 1e-2 (mean^2 / variance ~ 1e5)."""
+	out, ch = dict(sd), c.model_channels
+	hd = c.head_dim
+	groups = 32
+	if ch <= 16:                               # arch_utils.py:24-44 normalization()
+		groups = 8
+	elif ch <= 64:
+		groups = 16
+	while ch % groups:
+		groups //= 2
+	cpg = ch // groups
+	qk_rows = torch.tensor([r for r in range(3 * ch) if r % (3 * hd) < 2 * hd])
+	flat = slice(DIFF_STRESS_GROUP * cpg, (DIFF_STRESS_GROUP + 1) * cpg)
+	for k, v in sd.items():
+		if k.endswith("qkv.weight") or k.endswith("qkv.bias"):
+			if v.shape[0] != 3 * ch:          # the conditioning encoders' wider blocks are not on this path
+				continue
+			t = v.clone()
+			t[qk_rows] *= 4.0
+			out[k] = t
+		elif k.endswith("relative_attention_bias.weight"):
+			out[k] = v * 10.0
+		elif ".emb_layers.1." in k:
+			out[k] = v * 4.0
+		elif k.endswith("in_layers.2.weight"):
+			t = v.clone()
+			t[flat] *= DIFF_STRESS_FLAT_GAIN
+			out[k] = t
+		elif k.endswith("in_layers.2.bias"):
+			t = v.clone()
+			t[flat] = DIFF_STRESS_FLAT_VALUE
+			out[k] = t
+	return out
+
+
 def n_params(shapes: Dict[str, Tuple[int, ...]]) -> int:
 	n = 0
 	for s in shapes.values():
