@@ -17,6 +17,14 @@ against the HBM peak, latent pass and DDIM loop against the MFMA peak, from devi
 un-instrumented step and SURVEY.md section 8d's algorithmic work), and `cpu_baseline` (the CPU oracle on a bounded sample of the
 same workload, rank 0, N = 1 only).
 
+N > 1 failure behaviour: a first multi-GPU run either prints its line or ends non-zero within minutes WITH a reason.
+         Every rank logs to stderr and to gpurun_out/rank{r}.err; a stage watchdog (a daemon thread per rank, STAGE_BUDGET_S below) ends a rank that does not reach
+         its next stage marker in time after dumping every thread's stack and the tail of RCCL's log (NCCL_DEBUG=WARN -> gpurun_out/rccl.rank{r}.log, never
+         stdout); `python bench.py --gpus N` (self-launch) adds a parent-side watchdog over the same markers that terminates the CHILD process group and prints
+         each rank's last lines.  Before any model is built every rank runs a ONE-collective pre-flight in a FRESH child process (`--preflight`: rendezvous on
+         its own port, all_reduce of the rank ids, sum checked), first with HSA_ENABLE_IPC_MODE_LEGACY as inherited (0 = dmabuf IPC, what this pool's driver
+         needs), then -- only if that fails -- with the other value; the setting that passed is the one the real process group is created under (120 s timeout).
+
 --shard candidates   BASELINE configs[3] instead (not the headline line): ONE long-form utterance at a time, 2 lines x 256 text
          tokens, 32 candidates per GPU (256 at N = 8) x 500 mel tokens, 200 DDIM steps at T = 2176; candidates sharded over the ranks
          (tortoise_tts_amd/dist.py: ids all-gathered over RCCL, scores all-gathered, the lines' diffusions spread over the ranks, mels broadcast).
@@ -47,6 +55,7 @@ def parse():
 	ap.add_argument("--no-roofline", action="store_true")
 	ap.add_argument("--small", action="store_true", help="tiny models (plumbing check only; the number is NOT the metric)")
 	ap.add_argument("--no-graph", action="store_true", help="eager token loop (counter passes under rocprofv3 --pmc, which crashes on captured graphs); never the timed configuration")
+	ap.add_argument("--preflight", action="store_true", help="internal: the one-collective pre-flight child of an N > 1 rank (see the docstring)")
 	ap.add_argument("--shard", default="utterances", choices=["utterances", "candidates"],
 					help="utterances: configs[1]/[2], one utterance per GPU (the headline metric); candidates: configs[3], one utterance's candidates over the GPUs")
 	return ap.parse_args()
@@ -177,8 +186,152 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 	return out
 
 
+_RANK_FILE = None
+
+
+def out_dir():
+	d = os.path.join(ROOT, "gpurun_out")
+	os.makedirs(d, exist_ok=True)
+	return d
+
+
+def rank_file(rank):
+	return os.path.join(out_dir(), f"rank{rank}.err")
+
+
 def log(msg):
-	print(f"[bench] {msg}", file=sys.stderr, flush=True)
+	line = f"[bench] {msg}"
+	print(line, file=sys.stderr, flush=True)
+	if _RANK_FILE is not None:
+		try:
+			with open(_RANK_FILE, "a") as f:
+				f.write(f"{time.strftime('%H:%M:%S')} {line}\n")
+		except OSError:
+			pass
+
+
+# Stage markers a rank logs, in order, with the seconds it may take to reach each one from the previous (TTK_BENCH_STAGE_BUDGET overrides every entry: tests).
+# "rendezvous" includes the first `import torch` of a fresh box (1-2 min) and the pre-flight children; the parent-side watchdog allows PARENT_GRACE_S more.
+STAGE_BUDGET_S = (("preflight ok", 420.0), ("rendezvous ok", 150.0), ("models built", 240.0), ("timed region", 120.0), ("timed done", 240.0), ("result", 900.0))
+PARENT_GRACE_S = float(os.environ.get("TTK_BENCH_PARENT_GRACE", "20"))
+EXIT_STAGE_OVERRUN, EXIT_PREFLIGHT = 75, 76
+
+
+def stage_budgets():
+	o = os.environ.get("TTK_BENCH_STAGE_BUDGET")
+	return tuple((n, float(o)) for n, _ in STAGE_BUDGET_S) if o else STAGE_BUDGET_S
+
+
+def tail_of(path, n=25):
+	try:
+		with open(path, errors="replace") as f:
+			return "".join(f.readlines()[-n:])
+	except OSError:
+		return ""
+
+
+class StageWatchdog:
+	"""One per rank.  `reached(marker)` logs the marker and arms the budget of the NEXT one; a daemon thread ends the process (exit 75) when the armed marker
+	is overdue, after writing where every thread stands (faulthandler) and the tail of RCCL's log -- a rank stuck in a rendezvous, a collective or a kernel
+	becomes a message and an exit status instead of a run killed at the driver's limit with nothing to read."""
+
+	def __init__(self, rank, world):
+		import threading
+		self.rank, self.world = rank, world
+		self.budgets = list(stage_budgets())
+		self.i = 0
+		self.lock = threading.Lock()
+		self.deadline = time.monotonic() + self.budgets[0][1]
+		self.t0 = time.monotonic()
+		self.off = False
+		threading.Thread(target=self._run, daemon=True, name="stage-watchdog").start()
+
+	def reached(self, marker):
+		with self.lock:
+			names = [n for n, _ in self.budgets]
+			if marker in names:
+				self.i = names.index(marker) + 1
+				self.deadline = time.monotonic() + self.budgets[self.i][1] if self.i < len(self.budgets) else None
+		log(f"[reached] {marker} (rank {self.rank}, +{time.monotonic() - self.t0:.1f}s)")
+
+	def stop(self):
+		self.off = True
+
+	def _run(self):
+		import faulthandler
+		while not self.off:
+			time.sleep(0.25)
+			with self.lock:
+				dl, i = self.deadline, self.i
+			if dl is None or time.monotonic() <= dl:
+				continue
+			name, budget = self.budgets[i]
+			log(f"[watchdog] rank {self.rank}/{self.world}: marker '{name}' not reached within {budget:.0f}s of the previous one; thread stacks follow, then exit {EXIT_STAGE_OVERRUN}")
+			try:
+				faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+				if _RANK_FILE is not None:
+					with open(_RANK_FILE, "a") as f:
+						faulthandler.dump_traceback(file=f, all_threads=True)
+			except Exception:
+				pass
+			rl = tail_of(os.path.join(out_dir(), f"rccl.rank{self.rank}.log"))
+			if rl:
+				log(f"[watchdog] tail of RCCL's log:\n{rl}")
+			os._exit(EXIT_STAGE_OVERRUN)
+
+
+def preflight_child(a):
+	"""`bench.py --gpus N --preflight`, started by every rank as a FRESH child before it touches the GPU: rendezvous on the port it is given, ONE all_reduce of the
+	rank ids on the backend the bench will use, the sum checked.  Exit 0 = this IPC setting works."""
+	import datetime
+	import signal
+	rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+	rehearsal = os.environ.get("TTK_BENCH_REHEARSAL") == "1"
+	probe = os.environ.get("TTK_BENCH_PROBE") == "1"
+	if os.environ.get("TTK_BENCH_PREFLIGHT_FAIL_IPC") == os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"):      # tests only: make one IPC setting "not work"
+		print(f"[preflight] rank {rank}: failing on purpose (TTK_BENCH_PREFLIGHT_FAIL_IPC)", file=sys.stderr, flush=True)
+		sys.exit(5)
+	import torch
+	import torch.distributed as dist
+	signal.alarm(int(float(os.environ.get("TTK_BENCH_PREFLIGHT_S", "90"))))         # from here on (torch is imported): rendezvous + one collective, or SIGALRM ends the child
+	if probe or rehearsal:
+		dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+		x = torch.tensor([float(rank)])
+	else:
+		torch.cuda.set_device(local)
+		dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), timeout=datetime.timedelta(seconds=60))
+		x = torch.tensor([float(rank)], device=f"cuda:{local}")
+	dist.all_reduce(x)
+	got = float(x.item())
+	dist.destroy_process_group()
+	want = world * (world - 1) / 2
+	print(f"[preflight] rank {rank}: all_reduce of the rank ids = {got} (want {want}), HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
+	sys.exit(0 if got == want else 4)
+
+
+def preflight(rank, world):
+	"""The pre-flight of this rank: a fresh child per attempt (the rank itself has not touched the GPU yet), HSA_ENABLE_IPC_MODE_LEGACY first as inherited
+	(default 0: dmabuf IPC), then the other value.  Returns the value that passed; exits EXIT_PREFLIGHT with the children's output when neither does."""
+	if os.environ.get("TTK_BENCH_NO_PREFLIGHT") == "1":
+		return os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+	first = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+	order = [first, "1" if first == "0" else "0"]
+	base = int(os.environ.get("MASTER_PORT", "29500"))
+	for attempt, val in enumerate(order):
+		env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=val, MASTER_PORT=str(base + 17 * (attempt + 1)))
+		env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the child rendezvouses on its own TCP store (rank 0 of the attempt hosts it), not the agent's
+		t0 = time.monotonic()
+		try:
+			r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--preflight"], env=env, capture_output=True, text=True, timeout=400)
+			rc, err = r.returncode, r.stderr
+		except subprocess.TimeoutExpired as e:
+			rc, err = -9, (e.stderr or b"").decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+		log(f"[preflight] rank {rank} attempt {attempt} (HSA_ENABLE_IPC_MODE_LEGACY={val}): exit {rc} after {time.monotonic() - t0:.1f}s")
+		if rc == 0:
+			return val
+		log(f"[preflight] child output (last lines):\n" + "\n".join(err.splitlines()[-15:]))
+	log(f"[preflight] rank {rank}: the one-collective pre-flight failed under both IPC settings {order}; not building models")
+	sys.exit(EXIT_PREFLIGHT)
 
 
 def launcher_command(gpus, argv, port):
@@ -190,61 +343,147 @@ def launcher_command(gpus, argv, port):
 
 def self_launch(a):
 	"""`python bench.py --gpus N` (N > 1) as the driver starts the bench for N = 1: this process never touches the GPU (no torch import, no
-	HIP call) -- it starts N fresh ranks as CHILD processes (never an exec of a process that initialised the GPU), relays rank 0's JSON line
-	and exits with the children's status."""
+	HIP call) -- it starts N fresh ranks as CHILD processes in their own process group (never an exec of a process that initialised the GPU), relays
+	rank 0's JSON line and exits with the children's status.  While they run it is their watchdog: it follows the stage markers the ranks append to
+	gpurun_out/rank{r}.err and, when a rank is overdue by its stage budget + PARENT_GRACE_S (the rank's own watchdog gets to speak first), terminates
+	the child process group, prints every rank's last lines and exits non-zero."""
+	import signal
+	import threading
 	with socket.socket() as sk:
 		sk.bind(("127.0.0.1", 0))
 		port = sk.getsockname()[1]
 	env = dict(os.environ)
-	env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+	env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver (the ranks' pre-flight tries the other value if this one fails)
 	env.setdefault("OMP_NUM_THREADS", "4")
 	cmd = launcher_command(a.gpus, sys.argv[1:], port)
+	for r in range(a.gpus):
+		try:
+			os.remove(rank_file(r))
+		except OSError:
+			pass
 	log(f"no torch.distributed environment and --gpus {a.gpus}: starting {a.gpus} ranks: {' '.join(cmd)}")
-	proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+	proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
 	lines = []
-	for line in proc.stdout:
-		line = line.rstrip("\n")
-		if line.startswith("{") and '"metric"' in line:
-			lines.append(line)
-		else:
-			print(line, file=sys.stderr, flush=True)      # anything else the ranks print is not the result line
+
+	def relay():
+		for line in proc.stdout:
+			line = line.rstrip("\n")
+			if line.startswith("{") and '"metric"' in line:
+				lines.append(line)
+			else:
+				print(line, file=sys.stderr, flush=True)      # anything else the ranks print is not the result line
+	th = threading.Thread(target=relay, daemon=True)
+	th.start()
+	budgets = stage_budgets()
+	names = [n for n, _ in budgets]
+	reached = [0] * a.gpus                 # markers seen per rank
+	since = [time.monotonic()] * a.gpus    # when the last one was seen
+	overdue = None
+	while proc.poll() is None and overdue is None:
+		time.sleep(0.5)
+		now = time.monotonic()
+		for r in range(a.gpus):
+			try:
+				with open(rank_file(r), errors="replace") as f:
+					n = sum(1 for ln in f if "[reached] " in ln and any(f"[reached] {m} " in ln for m in names))
+			except OSError:
+				n = 0
+			if n > reached[r]:
+				reached[r], since[r] = n, now
+			if reached[r] < len(budgets) and now - since[r] > budgets[reached[r]][1] + PARENT_GRACE_S:
+				overdue = (r, budgets[reached[r]][0], budgets[reached[r]][1])
+	if overdue is not None:
+		r, marker, budget = overdue
+		log(f"[parent watchdog] rank {r} has not logged '{marker}' within {budget:.0f}s (+{PARENT_GRACE_S:.0f}s grace) of its previous marker: terminating the {a.gpus} child ranks")
+		for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+			try:
+				os.killpg(proc.pid, sig)               # the process group this function started (start_new_session), nothing else
+			except ProcessLookupError:
+				break
+			try:
+				proc.wait(timeout=wait)
+				break
+			except subprocess.TimeoutExpired:
+				continue
 	rc = proc.wait()
+	th.join(timeout=5)
+	if overdue is not None:
+		rc = EXIT_STAGE_OVERRUN
 	if rc == 0 and len(lines) != 1:
 		log(f"expected ONE result line from rank 0, got {len(lines)}")
 		rc = 1
+	if rc != 0:
+		for r in range(a.gpus):
+			log(f"---- last lines of rank {r} ({rank_file(r)}) ----\n{tail_of(rank_file(r)) or '(nothing logged)'}")
+		return rc if 0 < rc < 256 else 1
 	for line in lines[-1:]:
 		print(line, flush=True)
 	return rc
 
 
-def launch_probe(a):
+def launch_probe(a, mark):
 	"""TTK_BENCH_PROBE=1 (tests/test_host_logic.py, no GPU): the ranks only rendezvous (gloo), count themselves and rank 0 prints a line --
-	the launcher branch, the environment hand-over and the relay of ONE line, exercised on a box without a GPU.  Not a measurement."""
+	the launcher branch, the environment hand-over, the pre-flight, the stage markers / watchdogs and the relay of ONE line, exercised on a box without a
+	GPU.  Not a measurement."""
+	import datetime
 	import torch.distributed as dist
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if world > 1:
-		dist.init_process_group("gloo")
+		dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+	mark("rendezvous ok")
 	one = torch.ones(1)
+	mark("models built")
+	mark("timed region")
 	if world > 1:
 		dist.all_reduce(one)
+	mark("timed done")
 	if int(os.environ.get("RANK", "0")) == 0:
 		print(json.dumps({"metric": "launcher probe (no measurement)", "value": None, "n_gpus": a.gpus, "n_ranks_seen": int(one.item()),
-						  "world_size_env": world, "steps": a.steps, "warmup": a.warmup}), flush=True)
+						  "world_size_env": world, "steps": a.steps, "warmup": a.warmup, "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
+	mark("result")
 	if world > 1:
 		dist.destroy_process_group()
 
 
 def main():
 	a = parse()
+	if a.preflight:
+		return preflight_child(a)
 	if "WORLD_SIZE" not in os.environ and a.gpus > 1:
 		sys.exit(self_launch(a))
-	global torch
-	import torch
-	if os.environ.get("TTK_BENCH_PROBE") == "1":
-		return launch_probe(a)
 	rank = int(os.environ.get("RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	local = int(os.environ.get("LOCAL_RANK", "0"))
+	wd = None
+	if world > 1:      # nothing below this line has touched the GPU or imported torch yet
+		global _RANK_FILE
+		_RANK_FILE = rank_file(rank)
+		open(_RANK_FILE, "w").close()
+		os.environ.setdefault("NCCL_DEBUG", "WARN")
+		os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(out_dir(), f"rccl.rank{rank}.log"))       # RCCL's own messages: a file per rank, never stdout (ONE JSON line goes there)
+		if os.environ.get("TTK_BENCH_NO_RANK_WATCHDOG") != "1":      # (the parent-side watchdog's test switches the ranks' own off)
+			wd = StageWatchdog(rank, world)
+		os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = preflight(rank, world)
+
+	def mark(name):
+		"""a stage marker: logged (stderr + the rank's file), and the budget of the next one armed.  TTK_BENCH_STALL_RANK / TTK_BENCH_STALL_AT make one rank
+		hang in front of a marker -- the watchdogs' test (tests/test_host_logic.py), never set otherwise."""
+		if os.environ.get("TTK_BENCH_STALL_AT") == name and int(os.environ.get("TTK_BENCH_STALL_RANK", "-1")) == rank:
+			log(f"rank {rank}: stalling in front of '{name}' (TTK_BENCH_STALL_AT)")
+			while True:
+				time.sleep(1.0)
+		if wd is not None:
+			wd.reached(name)
+		elif world > 1:
+			log(f"[reached] {name} (rank {rank}, no rank watchdog)")
+		elif name != "preflight ok":
+			log(name)
+	mark("preflight ok")
+	global torch
+	import torch
+	if os.environ.get("TTK_BENCH_PROBE") == "1":
+		return launch_probe(a, mark)
+	import datetime
 	if world != a.gpus:
 		raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start one rank per GPU (python bench.py --gpus N does it by itself)")
 	# TTK_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend -- lets the N>1 control flow run on a 1-GPU box
@@ -257,10 +496,12 @@ def main():
 	import torch.distributed as dist
 	if world > 1:
 		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+		# 120 s, not the default 10 min (the driver's whole limit): a rendezvous that has not formed by then will not
 		if rehearsal:
-			dist.init_process_group("gloo")
+			dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
 		else:
-			dist.init_process_group("nccl", device_id=torch.device(dev))
+			dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=120))
+	mark("rendezvous ok")
 
 	from tortoise_tts_amd import _lib, weights as W
 	from tortoise_tts_amd.autoregressive import UnifiedVoice
@@ -275,7 +516,7 @@ def main():
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 		os.environ.setdefault("MASTER_PORT", "29533")
 		os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-		dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))      # the sharded entry runs on a group of any size
+		dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev), timeout=datetime.timedelta(seconds=120))      # the sharded entry runs on a group of any size
 	ar = UnifiedVoice(W.synth_state_dict(W.ar_shapes(ar_cfg), 0), ar_cfg, dtype=a.dtype, device=dev, max_batch=n_cand,
 					  max_ctx=n_text + 4 + n_mel + 8)
 	if a.no_graph:
@@ -315,11 +556,11 @@ def main():
 			dist.barrier()
 		torch.cuda.synchronize()
 
-	log("models built; warmup")
+	mark("models built")
 	for _ in range(a.warmup):
 		step()
 	fence()
-	log("timed region")
+	mark("timed region")
 	t0 = time.perf_counter()
 	audio = 0.0
 	for _ in range(a.steps):
@@ -331,6 +572,7 @@ def main():
 		dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
 	dt = float(tmax.item())
 
+	mark("timed done")
 	log(f"timed {a.steps} steps in {dt:.3f}s")
 	roof = None
 	if not a.no_roofline and (rank == 0 or by_cand):
@@ -439,6 +681,9 @@ def main():
 			"roofline": roof, "cpu_baseline": cpu, "latent_k1_variant": k1, "pipelined_lines": piped, "stop_live": live,
 		}
 		print(json.dumps(line), flush=True)
+	mark("result")
+	if wd is not None:
+		wd.stop()
 	if dist.is_initialized():
 		dist.destroy_process_group()
 

@@ -1,0 +1,319 @@
+"""The HIP path in the numerical regime of a trained checkpoint.
+
+tests/golden/stress_*.npz were produced by the REFERENCE's classes (oracle/make_golden.py: stress_*_case) on `tortoise_tts_amd.weights.stress_*` weights:
+  AR         `mel_head` x 8 and the q / k columns of every `c_attn` x 4 -> logits of std 8 (median max token probability 0.6-0.8 at T = 0.8), attention rows
+             close to one-hot (`peaked`); plus two channels of the embedding tables x 300 -> massive activations in fixed residual channels (`outlier`).
+  diffusion  q / k rows of every `qkv` x 4, `relative_attention_bias` x 10 -> scores of +-90 (small) / +-113 (full size), softmax rows of median top weight
+             0.9998 / 0.25; `emb_layers` x 4; the `in_layers` conv rows of one GroupNorm group x 1e-2 with bias 3.0 -> a group of 3.0 +- 1e-2.
+What is asserted: ids bit for bit in f32 (free-running, the fused sampler with `hf_exact_top_p` off AND on, under the CLI's warpers and the reference's
+TypicalLogitsWarper), the kernel's kept sets on the reference's own peaked rows, logits / latents / E / evaluations / DDIM x per arithmetic mode with the bounds
+of DESIGN.md section 2 ("stress" table), and the folded-LayerNorm health word staying silent (outlier CHANNELS are carried; only a common offset is not).
+Measured values go to gpurun_out/stress_errors.json.  GPU only; calls go through the C ABI."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import tortoise_oracle as O
+from tortoise_tts_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ALL_MODES = os.environ.get("TTK_TEST_ALL_MODES") == "1"       # the builder's runs sweep every arithmetic mode; the default run keeps f32 + bf16 (+ the cheap small-model ones)
+COLS = torch.cat([torch.arange(0, 96), torch.arange(8100, 8194)])
+
+
+def t(a):
+	return torch.from_numpy(np.asarray(a))
+
+
+def gen(seed):
+	return torch.Generator().manual_seed(seed)
+
+
+def maxerr(a, b):
+	return (torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max().item()
+
+
+def relerr(a, b):
+	a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+	return ((a - b).norm() / b.norm()).item()
+
+
+def record(name, values):
+	path = os.path.join(ROOT, "gpurun_out", "stress_errors.json")
+	try:
+		os.makedirs(os.path.dirname(path), exist_ok=True)
+		data = json.load(open(path)) if os.path.exists(path) else {}
+		data[name] = values
+		json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+	except OSError:
+		pass
+
+
+def ar_sd(variant, cfg=W.AR_SMALL, seed=14):
+	return W.stress_ar(W.synth_state_dict(W.ar_shapes(cfg), seed), cfg, variant)
+
+
+def build_ar(sd, cfg, dtype, **kw):
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	return UnifiedVoice(sd, cfg, dtype=dtype, device=DEV, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ AR: logits and latents per arithmetic mode
+# f32: absolute, on logits of std 8 (|logit| to 35) -- the random-weight bar of 1e-4 scaled by the x 8 head, x 2.5.  16-bit / fp8w: relative L2 against the
+# reference's f32 values.  Measured on MI355X (round 5, gpurun_out/stress_errors.json -> DESIGN.md section 2); bounds = 2.5-4x the measurement.
+AR_BOUNDS = {
+	"f32": dict(kind="abs", logits=2e-3, latents=2e-4),
+	"f16": dict(kind="rel", logits=1.5e-2, latents=1.5e-2),
+	"bf16": dict(kind="rel", logits=1e-1, latents=1e-1),
+	"fp8w": dict(kind="rel", logits=3e-1, latents=3e-1),
+}
+
+
+@pytest.mark.parametrize("variant", ["peaked", "outlier"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16", "fp8w"])
+def test_ar_logits_and_latents_against_the_reference(golden, variant, dtype):
+	g = golden("stress_ar")
+	p = variant + "::"
+	cfg = W.AR_SMALL
+	model = build_ar(ar_sd(variant), cfg, dtype, max_batch=4, max_ctx=64)
+	text, cond, toks, codes = t(g[p + "text"]).to(DEV), t(g[p + "cond"]).to(DEV), t(g[p + "dec_tokens"]).to(DEV), t(g[p + "codes"]).to(DEV)
+	B = toks.shape[0]
+	b = AR_BOUNDS[dtype]
+	fn = maxerr if b["kind"] == "abs" else relerr
+	logits = model._prefill(cond, text, B)
+	e_pre = fn(logits, g[p + "prefill_logits"])
+	dec = []
+	for k in range(toks.shape[1]):
+		model._decode(toks[:, k].contiguous(), logits)
+		dec.append(logits.clone())
+	e_dec = fn(torch.stack(dec, 1), g[p + "decode_logits"])
+	lat = model.forward(cond.repeat(B, 1), text.repeat(B, 1), torch.tensor([text.shape[1]] * B, dtype=torch.int32), codes,
+						torch.tensor([codes.shape[1] * 1024] * B), return_latent=True, clip_inputs=False)
+	e_lat = fn(lat, g[p + "latents"])
+	# ... and along the sequence the reference itself sampled under top-k 16 / top-p 0.8 / penalty 2 (the logits every token was drawn from)
+	q = p + "topk16_topp_pen::"
+	meta = json.loads(str(g[q + "meta"]))
+	ids = t(g[q + "ids"]).to(DEV)
+	lg = model._prefill(t(g[q + "cond"]).to(DEV), t(g[q + "text"]).to(DEV), meta["B"])
+	rows = [lg[:, COLS.to(DEV)].clone()]
+	for k in range(ids.shape[1] - 1):
+		model._decode(ids[:, k].contiguous(), lg)
+		rows.append(lg[:, COLS.to(DEV)].clone())
+	e_seq = fn(torch.stack(rows, 1), g[q + "logits_sub"])
+	record(f"ar_{variant}_{dtype}", dict(kind=b["kind"], prefill=e_pre, decode=e_dec, latents=e_lat, sampled_sequence=e_seq, health=model._check_health()))
+	assert e_pre < b["logits"] and e_dec < b["logits"] and e_seq < b["logits"] and e_lat < b["latents"], (variant, dtype, e_pre, e_dec, e_seq, e_lat)
+
+
+# ------------------------------------------------------------------------------------------------ AR: ids
+@pytest.mark.parametrize("variant", ["peaked", "outlier"])
+@pytest.mark.parametrize("hf_exact", [False, True])
+def test_free_running_ids_f32_under_the_cli_warpers(golden, variant, hf_exact):
+	"""every warper combination of the fixture (top-k 16 alone, + top-p 0.8 + repetition penalty 2, + typical mass 0.9, top-p alone, typical alone): the product's
+	free-running f32 ids equal the oracle's own loop bit for bit -- the oracle's CPU-generator ids are the reference's (tests/test_oracle_stress.py), here it
+	samples on the device so both sides consume the same Philox stream.  With `hf_exact_top_p` the cumulative-mass warpers run as HF's torch ops in front of the
+	kernel, without it inside the kernel (exact fixed-point masses): both must give the oracle's ids.  The folded LayerNorm's health word stays silent: outlier
+	channels inflate the row's std with them (|mean| / std <= sqrt(2 / d)), which the fold carries."""
+	g = golden("stress_ar")
+	cfg = W.AR_SMALL
+	sd = ar_sd(variant)
+	model = build_ar(sd, cfg, "f32", max_batch=4, max_ctx=96, hf_exact_top_p=hf_exact)
+	oracle = O.AROracle(sd, cfg)
+	names = sorted({k.split("::")[1] for k in g if k.startswith(variant + "::") and k.count("::") == 2})
+	assert len(names) == 5
+	for name in names:
+		q = f"{variant}::{name}::"
+		meta = json.loads(str(g[q + "meta"]))
+		kw = dict(meta["kw"])
+		kw.setdefault("top_k", 0)
+		tm = kw.pop("typical_mass", None)
+		typ = dict(typical_sampling=tm is not None, typical_mass=tm if tm is not None else 0.9)
+		text, cond = t(g[q + "text"]), t(g[q + "cond"])
+		with torch.inference_mode():
+			want = O.inference_speech(oracle, cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], sample_device="cuda", **typ, **kw)
+		with warnings.catch_warnings():
+			warnings.simplefilter("error")                                   # a health warning would be an error here
+			got = model.inference_speech(cond.to(DEV), text.to(DEV), do_sample=True, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], **typ, **kw)
+		assert got.shape == want.shape and torch.equal(got.cpu(), want), (variant, name, hf_exact, (got.cpu() != want).nonzero()[:4].tolist())
+		assert model.last_health == 0
+
+
+def _probe(lib, lg, probe, *, temp, top_k, top_p, typical=None):
+	"""is token probe[b] of row b still there after the kernel's warpers?  Noise 1 everywhere except a vanishing value at the probe: a kept probe wins
+	argmax(p / q) whatever its probability, a removed one (p = 0) cannot (tests/test_gpu_parity.py::_probe_kept)."""
+	from tortoise_tts_amd import _lib
+	B, V = lg.shape
+	q = torch.ones((B, V), device=DEV)
+	q[torch.arange(B, device=DEV), probe] = 1e-30
+	unf, tok = torch.ones(B, dtype=torch.long, device=DEV), torch.empty(B, dtype=torch.long, device=DEV)
+	ids, col = torch.full((B, 1), -1, dtype=torch.long, device=DEV), torch.zeros(B, dtype=torch.long, device=DEV)
+	a = _lib.SampleArgs()
+	a.scores, a.ld, a.B, a.V, a.q, a.ldq = lg.data_ptr(), V, B, V, q.data_ptr(), V
+	a.temperature, a.top_k, a.top_p, a.repetition_penalty = temp, top_k, top_p, 1.0
+	if typical is not None:
+		a.typical_mass = typical
+	a.stop_token, a.unfinished, a.tok, a.ids, a.ids_ld, a.ids_cols, a.col = V + 5, unf.data_ptr(), tok.data_ptr(), ids.data_ptr(), 1, 1, col.data_ptr()
+	_lib.check(lib.ttk_sample_step_warped(_lib.C.byref(a), _lib.stream_ptr()), "ttk_sample_step_warped")
+	torch.cuda.synchronize()
+	return tok == probe
+
+
+@pytest.mark.parametrize("variant", ["peaked", "outlier"])
+def test_kept_sets_of_the_sampling_kernel_on_the_references_own_rows(golden, variant):
+	"""the logit rows the REFERENCE drew from (whole rows stored at two steps of two cases), through the kernel's top-k 16 / top-p 0.8 and typical 0.9 cuts:
+	every token HF's chain keeps is kept, the best token it removes is removed.  Rows where the cut sits on an f32 tie of the cumulative mass are excused only
+	if the f64 mass is within 2e-6 of the threshold (none expected on rows this peaked)."""
+	from tortoise_tts_amd import _lib
+	lib = _lib.load()
+	g = golden("stress_ar")
+	rows = torch.cat([t(g[f"{variant}::{c}::logit_rows"]).reshape(-1, 8194) for c in ("topk16_topp_pen", "typical_only")]).to(DEV)
+	B, V = rows.shape
+	assert float(torch.softmax(rows / 0.8, -1).max(-1)[0].median()) > 0.4
+	checked = 0
+	for kw in (dict(temperature=0.8, top_k=16, top_p=0.8), dict(temperature=0.8, top_k=16, top_p=1.0), dict(temperature=1.0, top_k=0, top_p=0.8),
+			   dict(temperature=1.0, top_k=0, top_p=1.0, typical_mass=0.9), dict(temperature=0.8, top_k=16, top_p=1.0, typical_mass=0.9)):
+		sc = O.process_logits(None, rows, **kw)
+		kept = torch.isfinite(sc)
+		n_kept = kept.sum(-1)
+		assert int(n_kept.min()) >= 1 and int(n_kept.max()) < 200
+		pk = dict(temp=kw["temperature"], top_k=kw["top_k"], top_p=kw["top_p"], typical=kw.get("typical_mass"))
+		order = torch.argsort(torch.where(kept, rows, torch.full_like(rows, float("-inf"))), dim=-1, descending=True)
+		for j in range(int(n_kept.max())):                              # the j-th best kept token of every row that has one
+			has = n_kept > j
+			ok = _probe(lib, rows, order[:, j], **pk)
+			assert bool((ok | ~has).all()), (variant, kw, j, (~ok & has).nonzero().flatten().tolist())
+			checked += int(has.sum())
+		removed_best = torch.where(~kept, rows, torch.full_like(rows, float("-inf"))).argmax(-1)
+		assert not bool(_probe(lib, rows, removed_best, **pk).any()), (variant, kw)
+		if kw.get("typical_mass") is not None and kw["top_k"] == 0:      # typical sampling drops the MOST likely token when it is far from the entropy: probe the removed token closest to it as well
+			lp = torch.log_softmax(rows, -1)
+			H = -(lp * lp.exp()).nansum(-1, keepdim=True)
+			near = torch.where(~kept, (-lp - H).abs(), torch.full_like(lp, float("inf"))).argmin(-1)
+			assert not bool(_probe(lib, rows, near, **pk).any()), (variant, kw)
+	assert checked > 5 * B
+
+
+def test_ar_full_size_outlier_weights_logits_and_ids(golden):
+	"""full-size UnifiedVoice (the benchmarked geometry: k_gemv with the folded LayerNorm) on the outlier stress weights: f32 logits / latents against the
+	reference, the bf16 handle's within its bound, free-running f32 ids equal to the oracle's loop under top-k 16 + repetition penalty 2"""
+	g = golden("stress_ar_full")
+	cfg = W.AR_FULL
+	sd = ar_sd("outlier", cfg, int(g["seed"]))
+	text, cond, toks, codes = t(g["text"]), t(g["cond"]), t(g["dec_tokens"]), t(g["codes"])
+	B, cols = int(g["B"]), t(g["logit_cols"]).to(DEV)
+	meta = json.loads(str(g["stream_meta"]))
+	with torch.inference_mode():
+		want = O.inference_speech(O.AROracle(sd, cfg), cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], sample_device="cuda", **meta["kw"])
+	for dtype in ("f32", "bf16"):
+		model = build_ar(sd, cfg, dtype, max_batch=2, max_ctx=64)
+		b = AR_BOUNDS[dtype]
+		fn = maxerr if b["kind"] == "abs" else relerr
+		logits = model._prefill(cond.to(DEV), text.to(DEV), B)
+		e_pre = fn(logits[:, cols], g["prefill_logits"])
+		dec = []
+		for k in range(toks.shape[1]):
+			model._decode(toks[:, k].contiguous().to(DEV), logits)
+			dec.append(logits[:, cols].clone())
+		e_dec = fn(torch.stack(dec, 1), g["decode_logits"])
+		lat = model.forward(cond.repeat(B, 1).to(DEV), text.repeat(B, 1).to(DEV), torch.tensor([text.shape[1]] * B, dtype=torch.int32), codes.to(DEV),
+							torch.tensor([codes.shape[1] * 1024] * B), return_latent=True, clip_inputs=False)
+		e_lat = fn(lat[:, :, :128], g["latents"])
+		with warnings.catch_warnings():
+			warnings.simplefilter("error")
+			got = model.inference_speech(cond.to(DEV), text.to(DEV), do_sample=True, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], **meta["kw"]).cpu()
+		agree = float((got == want).float().mean())
+		record(f"ar_full_outlier_{dtype}", dict(kind=b["kind"], prefill=e_pre, decode=e_dec, latents=e_lat, free_running_id_agreement=agree, health=model.last_health))
+		k = 2.5 if dtype == "f32" else 1.0                               # 30 layers, d = 1024: the f32 bar of the full-size random-weight test is 5x the small one's too
+		assert e_pre < k * b["logits"] and e_dec < k * b["logits"] and e_lat < k * b["latents"], (dtype, e_pre, e_dec, e_lat)
+		assert model.last_health == 0
+		if dtype == "f32":
+			assert torch.equal(got, want), (got != want).nonzero()[:4].tolist()
+		del model
+
+
+# ------------------------------------------------------------------------------------------------ diffusion
+# f32: absolute (|E| to 11 / 18, |y| to 2.5 / 3, x in [-1, 1] at the end); 16-bit / fp8: relative L2 against the reference's f32 values.
+# Measured on MI355X (round 5, gpurun_out/stress_errors.json -> DESIGN.md section 2); bounds = 2.5-4x the measurement.
+DIFF_BOUNDS = {
+	"f32": dict(kind="abs", E=1e-3, y=1e-3, x=2e-3),
+	"f16": dict(kind="rel", E=1e-2, y=2e-2, x=3e-2),
+	"bf16": dict(kind="rel", E=8e-2, y=1.5e-1, x=2e-1),
+	"fp8w": dict(kind="rel", E=3e-1, y=5e-1, x=5e-1),
+	"fp8": dict(kind="rel", E=3e-1, y=5e-1, x=5e-1),
+}
+
+
+def build_diff(sd, cfg, dtype):
+	from tortoise_tts_amd.diffusion import DiffusionTTS
+	return DiffusionTTS(sd, cfg, dtype=dtype, device=DEV)
+
+
+def ddim_chunks(model, noise, E, T, n_steps, lo_hi):
+	"""x after each (lo, hi) slice of the n_steps schedule, run from the highest index down through the whole-loop entry"""
+	from tortoise_tts_amd import _lib
+	from tortoise_tts_amd.diffusion import get_diffuser
+	d = get_diffuser(steps=n_steps, cond_free=True)
+	x = noise.to(DEV).clone()
+	Ed = E.to(DEV, torch.float32).contiguous()
+	out = []
+	for lo, hi in lo_hi:
+		k = hi - lo
+		steps = (_lib.StepC * k)(*[d.step_coefs(i, "ddim") for i in range(lo, hi)])
+		_lib.check(model.lib.ttk_diff_sample_ddim(model._h, x.data_ptr(), Ed.data_ptr(), 1, T, steps, k, _lib.stream_ptr()), "ttk_diff_sample_ddim")
+		torch.cuda.synchronize()
+		out.append(x.clone())
+	return out
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16", "fp8w", "fp8"])
+def test_diffusion_small_against_the_reference(golden, dtype):
+	g = golden("stress_diff")
+	cfg = W.DIFF_SMALL
+	sd = W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), int(g["seed"])), cfg)
+	model = build_diff(sd, cfg, dtype)
+	T = int(g["T"])
+	b = DIFF_BOUNDS[dtype]
+	fn = maxerr if b["kind"] == "abs" else relerr
+	e_E = fn(model.timestep_independent(t(g["latents"]).to(DEV), t(g["cond"]).to(DEV), T, False), g["E"])
+	x, ts, Eg = t(g["x"]).to(DEV), t(g["t"]).to(DEV), t(g["E"]).to(DEV)
+	e_yc = fn(model(x, ts, precomputed_aligned_embeddings=Eg), g["y_cond"])
+	e_yu = fn(model(x, ts, precomputed_aligned_embeddings=Eg, conditioning_free=True), g["y_uncond"])
+	xs = ddim_chunks(model, t(g["noise"]), Eg[:1], T, 8, [(6, 8), (4, 6), (0, 4)])
+	e_x = {n: fn(xs[i], g[f"x_after_{n}"]) for i, n in enumerate((2, 4, 8))}
+	record(f"diff_small_{dtype}", dict(kind=b["kind"], E=e_E, y_cond=e_yc, y_uncond=e_yu, **{f"x_after_{n}": v for n, v in e_x.items()}))
+	assert e_E < b["E"] and e_yc < b["y"] and e_yu < b["y"], (dtype, e_E, e_yc, e_yu)
+	assert all(v < b["x"] for v in e_x.values()), (dtype, e_x)
+	assert torch.isfinite(xs[-1]).all() and xs[-1].abs().max() <= 1.0 + 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"] + (["f16", "fp8w", "fp8"] if ALL_MODES else []))
+def test_diffusion_full_size_at_T1088_against_the_reference(golden, dtype):
+	"""configs[1]'s shape on the stress weights: E, one evaluation pair and the last 4 of the 80 DDIM steps, every 8th frame / the final mel whole"""
+	g = golden("stress_diff_cfg1")
+	cfg = W.DIFF_FULL
+	sd = W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), 2), cfg)
+	model = build_diff(sd, cfg, dtype)
+	M, T, st = int(g["M"]), int(g["T"]), int(g["stride"])
+	assert T == 1088
+	lat = torch.randn(1, M, 1024, generator=gen(31))
+	dcond = torch.randn(1, 2048, generator=gen(32))
+	x = torch.randn(1, 100, T, generator=gen(33))
+	ts = torch.tensor([1500])
+	b = DIFF_BOUNDS[dtype]
+	fn = maxerr if b["kind"] == "abs" else relerr
+	E = model.timestep_independent(lat.to(DEV), dcond.to(DEV), T, False)
+	e_E = fn(E[:, :, ::st], g["E_sub"])
+	with torch.inference_mode():      # the evaluations take the oracle's f32 E (equal to the reference's: tests/test_oracle_stress.py) so each stage is compared on its own
+		Eo = O.DiffusionOracle(sd, cfg).timestep_independent(lat, dcond, T).to(DEV)
+	e_yc = fn(model(x.to(DEV), ts.to(DEV), precomputed_aligned_embeddings=Eo)[:, :, ::st], g["y_cond_sub"])
+	e_yu = fn(model(x.to(DEV), ts.to(DEV), precomputed_aligned_embeddings=Eo, conditioning_free=True)[:, :, ::st], g["y_uncond_sub"])
+	xm = ddim_chunks(model, x, Eo, T, 80, [(0, 4)])[0]
+	e_x = fn(xm, g["mel"])
+	record(f"diff_full_{dtype}", dict(kind=b["kind"], E=e_E, y_cond=e_yc, y_uncond=e_yu, mel_last4=e_x))
+	k = 2.0 if dtype == "f32" else 1.0
+	assert e_E < k * b["E"] and e_yc < k * b["y"] and e_yu < k * b["y"] and e_x < k * b["x"], (dtype, e_E, e_yc, e_yu, e_x)

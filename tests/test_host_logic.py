@@ -135,6 +135,46 @@ def test_bench_launches_its_own_ranks_when_started_without_a_distributed_environ
 		assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def _bench_probe(extra_env, *argv, timeout=300):
+	import subprocess
+	import sys
+	env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+	env.update(TTK_BENCH_PROBE="1", **extra_env)
+	return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", *argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_multi_rank_run_fails_fast_with_a_reason_when_a_rank_stalls():
+	"""VERDICT r04 next #2: the first N > 1 run must either print its line or end non-zero within its stage budget WITH diagnostics.  Two gloo ranks, rank 1
+	made to hang in front of a stage marker (TTK_BENCH_STALL_*), stage budgets cut to 5 s: (a) the stalled rank's own watchdog names the marker, dumps the
+	thread stacks into gpurun_out/rank1.err and exits 75, torchrun tears the job down, the launcher prints every rank's last lines; (b) with the ranks' own
+	watchdogs off, the PARENT-side watchdog terminates the child process group after budget + grace and exits 75.  No result line either way."""
+	import time
+	t0 = time.time()
+	r = _bench_probe(dict(TTK_BENCH_STALL_RANK="1", TTK_BENCH_STALL_AT="timed region", TTK_BENCH_STAGE_BUDGET="5"))
+	assert r.returncode != 0 and time.time() - t0 < 90 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+	assert "marker 'timed region' not reached within 5s" in r.stderr and "last lines of rank 0" in r.stderr and "last lines of rank 1" in r.stderr
+	assert "stalling in front of 'timed region'" in r.stderr and "in mark" in r.stderr                       # the stack dump shows where the rank stood
+	err1 = open(os.path.join(ROOT, "gpurun_out", "rank1.err")).read()
+	assert "[watchdog] rank 1/2" in err1 and "[reached] models built" in err1 and "[reached] timed region" not in err1
+	t0 = time.time()
+	r = _bench_probe(dict(TTK_BENCH_STALL_RANK="1", TTK_BENCH_STALL_AT="models built", TTK_BENCH_STAGE_BUDGET="5", TTK_BENCH_NO_RANK_WATCHDOG="1", TTK_BENCH_PARENT_GRACE="2"))
+	assert r.returncode == 75 and time.time() - t0 < 90 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+	assert "[parent watchdog] rank 1 has not logged 'models built'" in r.stderr and "terminating the 2 child ranks" in r.stderr
+
+
+def test_bench_preflight_falls_back_to_the_other_ipc_setting_in_fresh_children():
+	"""the one-collective pre-flight runs in a fresh child per attempt; when the inherited HSA_ENABLE_IPC_MODE_LEGACY setting fails it, the other one is tried
+	and the run proceeds under the one that passed (stated order: inherited / 0 first); when both fail no model is built and the exit status is 76"""
+	import json
+	r = _bench_probe(dict(HSA_ENABLE_IPC_MODE_LEGACY="0", TTK_BENCH_PREFLIGHT_FAIL_IPC="0"))
+	assert r.returncode == 0, r.stderr[-2000:]
+	line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+	assert line["ipc_mode_legacy"] == "1" and line["n_ranks_seen"] == 2
+	assert "attempt 0 (HSA_ENABLE_IPC_MODE_LEGACY=0): exit 5" in r.stderr and "attempt 1 (HSA_ENABLE_IPC_MODE_LEGACY=1): exit 0" in r.stderr
+	r = _bench_probe(dict(HSA_ENABLE_IPC_MODE_LEGACY="0"))
+	assert r.returncode == 0 and json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["ipc_mode_legacy"] == "0"
+
+
 def test_bench_phase_roofline_counts_the_work_of_the_configuration_it_is_given():
 	"""bench.phase_roofline on fake phase events: configs[1] figures equal BASELINE.md section 4's formulas; the fp8 mode's DDIM phase is graded
 	against the 5 PFLOP/s fp8 peak (VERDICT r02 weak #6); a two-line configs[3] shard doubles the work and sums the lines' times"""
