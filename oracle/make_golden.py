@@ -492,6 +492,17 @@ def stress_ar_case(uv_mod):
 			dec = torch.stack(dec, 1)
 			lat = m.forward(cond.repeat(B, 1), text.repeat(B, 1), torch.tensor([Tt] * B, dtype=torch.int32), codes,
 							torch.tensor([M * cfg.mel_length_compression] * B), return_latent=True, clip_inputs=False)
+			# the REFERENCE'S OWN 16-bit deviation in this regime: the same calls under the autocast region inference.py:331 opens (bf16, on the CPU here)
+			with torch.autocast("cpu", dtype=torch.bfloat16):
+				r = im.forward(input_ids=ids, attention_mask=torch.ones(B, P1, dtype=torch.long), use_cache=True, return_dict=True)
+				pre_amp, past, dec_amp = r.logits[:, -1].float(), r.past_key_values, []
+				for k in range(1, n_dec + 1):
+					r = im.forward(input_ids=dec_tokens[:, k - 1:k], past_key_values=past, attention_mask=torch.ones(B, P1 + k, dtype=torch.long), use_cache=True, return_dict=True)
+					past = r.past_key_values
+					dec_amp.append(r.logits[:, -1].float())
+				dec_amp = torch.stack(dec_amp, 1)
+		out.update({variant + "::prefill_logits_autocast_bf16": pre_amp.numpy(), variant + "::decode_logits_autocast_bf16": dec_amp.numpy()})
+		print(f"  {variant}: the reference under autocast(bf16) vs itself in f32: rel L2 prefill {float((pre_amp - pre).norm() / pre.norm()):.3e}, decode {float((dec_amp - dec).norm() / dec.norm()):.3e}")
 		pmax = torch.softmax(dec / 0.8, -1).max(-1)[0]
 		print(f"  {variant}: logits std {float(dec.std()):.2f}, max token probability at T=0.8: median {float(pmax.median()):.3f}, max {float(pmax.max()):.3f}; |latent| max {float(lat.abs().max()):.1f}")
 		p = variant + "::"
@@ -583,6 +594,14 @@ def stress_diff_case(d_mod):
 		E = m.timestep_independent(lat, cond, T, False)
 		yc = m(x, t, precomputed_aligned_embeddings=E)
 		yu = m(x, t, precomputed_aligned_embeddings=E, conditioning_free=True)
+		# the reference's OWN 16-bit mode in this regime: DiffusionTTS(use_fp16=True) runs every main layer but the first under autocast (diffusion.py:1559-1561; bf16 is the
+		# CPU autocast type).  (The outer autocast region of inference.py:331 cannot be used here: with use_fp16=False the model switches autocast OFF inside its layers and
+		# then feeds them the bf16 tensor the region produced -- an ordinary dtype error of the reference's own code, CPU and GPU alike.)
+		m.enable_fp16 = True
+		yc_amp = m(x, t, precomputed_aligned_embeddings=E).float()
+		m.enable_fp16 = False
+		out.update(y_cond_ref_fp16mode=yc_amp.numpy())
+		print(f"  small: the reference with use_fp16 (autocast bf16 in layers >= 1) vs itself in f32: rel L2 y_cond {float((yc_amp - yc).norm() / yc.norm()):.3e}")
 		print(f"  small: |E| max {float(E.abs().max()):.1f}, |y| max {float(yc.abs().max()):.1f}, first-layer |score| max / median top weight: {_attn_score_probe(d_mod, m, E)}")
 		diffuser = d_mod.get_diffuser(steps=8, cond_free=True)
 		torch.manual_seed(0)
@@ -614,13 +633,18 @@ def stress_diff_cfg1_case(d_mod):
 		E = m.timestep_independent(lat, dcond, T, False)
 		yc = m(x, t, precomputed_aligned_embeddings=E)
 		yu = m(x, t, precomputed_aligned_embeddings=E, conditioning_free=True)
+		m.enable_fp16 = True                    # the reference's own 16-bit mode (see stress_diff_case)
+		yc_amp = m(x, t, precomputed_aligned_embeddings=E).float()
+		m.enable_fp16 = False
+		amp = dict(y_cond_ref_fp16mode_sub=yc_amp[:, :, ::8].numpy())
+		print(f"  full: the reference with use_fp16 (autocast bf16 in layers >= 1) vs itself in f32: rel L2 y_cond {float((yc_amp - yc).norm() / yc.norm()):.3e}", flush=True)
 		print(f"  full: |E| max {float(E.abs().max()):.1f}, |y| max {float(yc.abs().max()):.1f}, first-layer |score| max / median top weight: {_attn_score_probe(d_mod, m, E)}", flush=True)
 		xm = x
 		torch.manual_seed(0)
 		for i in reversed(range(4)):
 			xm = diffuser.ddim_sample(m, xm, torch.tensor([i]), clip_denoised=True, model_kwargs={"precomputed_aligned_embeddings": E}, eta=0.0)["sample"]
 	return dict(T=np.int64(T), M=np.int64(M), stride=np.int64(8), E_sub=E[:, :, ::8].numpy(), y_cond_sub=yc[:, :, ::8].numpy(),
-				y_uncond_sub=yu[:, :, ::8].numpy(), mel=xm.numpy())
+				y_uncond_sub=yu[:, :, ::8].numpy(), mel=xm.numpy(), **amp)
 
 
 def vocoder_case(cfg, seed, T):

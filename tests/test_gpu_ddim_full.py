@@ -30,13 +30,15 @@ CHECKPOINTS = (8, 16, 40, 72, 80)
 # Measured on MI355X (round 4, gpurun_out/ddim_full_errors.json -> DESIGN.md section 2), loop alone, after 8 / 16 / 40 / 72 / 80 steps:
 #   f32  abs 1.3e-6 / 1.7e-6 / 7.1e-6 / 2.2e-5 / 3.8e-5        f16  rel 1.4e-5 / 3.4e-5 / 2.5e-4 / 1.0e-3 / 1.2e-3
 #   bf16 rel 1.1e-4 / 2.5e-4 / 1.8e-3 / 6.9e-3 / 9.3e-3        fp8w rel 8.5e-4 / 2.4e-3 / 2.0e-2 / 7.8e-2 / 1.0e-1      fp8 rel 8.9e-4 / 2.6e-3 / 2.1e-2 / 8.2e-2 / 1.0e-1
-# (early x is mostly the start noise, which every mode carries exactly; the error that matters is the last column).  Bounds = 2.5-5x the measurement.
+# (early x is mostly the start noise, which every mode carries exactly; the error that matters is the last column).  Bounds = 2.5-5x the measurement for f32 / f16 / bf16.
+# fp8 / fp8w (a bound at 2.5x of a 10 % error would accept a 2x accuracy regression): tied to an independent criterion instead -- 16 x the bf16 mode's MEASURED
+# error at the same checkpoint (e4m3 keeps four fewer significand bits than bf16: 2^4), i.e. 1.8e-3 / 4e-3 / 2.9e-2 / 1.1e-1 / 1.5e-1.
 LOOP_BOUNDS = {
 	"f32": dict(kind="abs", at={8: 2e-5, 16: 2e-5, 40: 5e-5, 72: 1.5e-4, 80: 2e-4}),
 	"f16": dict(kind="rel", at={8: 1e-4, 16: 2e-4, 40: 1e-3, 72: 4e-3, 80: 5e-3}),
 	"bf16": dict(kind="rel", at={8: 5e-4, 16: 1e-3, 40: 6e-3, 72: 2.5e-2, 80: 3e-2}),
-	"fp8w": dict(kind="rel", at={8: 3e-3, 16: 8e-3, 40: 6e-2, 72: 2e-1, 80: 2.5e-1}),
-	"fp8": dict(kind="rel", at={8: 3e-3, 16: 8e-3, 40: 6e-2, 72: 2e-1, 80: 2.5e-1}),
+	"fp8w": dict(kind="rel", at={8: 1.8e-3, 16: 4e-3, 40: 2.9e-2, 72: 1.1e-1, 80: 1.5e-1}),
+	"fp8": dict(kind="rel", at={8: 1.8e-3, 16: 4e-3, 40: 2.9e-2, 72: 1.1e-1, 80: 1.5e-1}),
 }
 # the end-to-end chain adds the latent pass and timestep_independent in the same arithmetic in front of the loop.  Measured:
 #   f32  latents 6.3e-6, E 2.5e-5 abs; x 1.5e-6 / 2.4e-6 / 2.3e-5 / 8.4e-5 / 8.9e-5 abs
@@ -45,7 +47,8 @@ LOOP_BOUNDS = {
 E2E_BOUNDS = {
 	"f32": dict(kind="abs", lat=1e-4, E=2e-4, at={8: 2e-5, 16: 2e-5, 40: 1e-4, 72: 4e-4, 80: 4e-4}),
 	"bf16": dict(kind="rel", lat=2e-2, E=2e-2, at={8: 8e-4, 16: 2e-3, 40: 1.2e-2, 72: 4e-2, 80: 5e-2}),
-	"fp8": dict(kind="rel", lat=1.5e-1, E=1.2e-1, at={8: 4e-3, 16: 1e-2, 40: 8e-2, 72: 3e-1, 80: 3.5e-1}),
+	# fp8: 16 x the bf16 chain's measured error at each checkpoint (2.7e-3 / 7.2e-3 / 5.9e-2 / 2.2e-1 / 2.7e-1); the front stages 20 x bf16's (latents 1.0e-1, E 9e-2)
+	"fp8": dict(kind="rel", lat=1.0e-1, E=9e-2, at={8: 2.7e-3, 16: 7.2e-3, 40: 5.9e-2, 72: 2.2e-1, 80: 2.7e-1}),
 }
 
 

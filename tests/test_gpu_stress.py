@@ -65,14 +65,19 @@ def build_ar(sd, cfg, dtype, **kw):
 
 
 # ------------------------------------------------------------------------------------------------ AR: logits and latents per arithmetic mode
-# f32: absolute, on logits of std 8 (|logit| to 35) -- the random-weight bar of 1e-4 scaled by the x 8 head, x 2.5.  16-bit / fp8w: relative L2 against the
-# reference's f32 values.  Measured on MI355X (round 5, gpurun_out/stress_errors.json -> DESIGN.md section 2); bounds = 2.5-4x the measurement.
+# f32: absolute, on logits of std 8 (|logit| to 35).  16-bit / fp8w: relative L2 against the reference's f32 values.
+# Measured on MI355X (round 5, profiles/r05_stress_errors.json -> DESIGN.md section 2), worst of the two variants and of prefill / decode / the reference's own sampled sequence:
+#   f32  logits 1.2e-4 abs, latents 6.3e-6 abs        f16  logits 2.2e-3, latents 1.4e-3        bf16 logits 1.7e-2, latents 1.7e-2        fp8w logits 1.7e-1, latents 9.3e-2
+# Bounds = 3-4x the measurement.  Independent criteria: (a) bf16 -- the REFERENCE'S OWN deviation under the autocast(bf16) region of inference.py:331, stored in the fixture
+# (peaked: prefill 8.1e-3, decode 9.4e-3; outlier 2.4e-3 / 2.9e-3): the product's bf16 error must stay within BF16_VS_REFERENCE_AUTOCAST x that (measured 0.5-1.4x);
+# (b) fp8w -- 16 x the bf16 bound would be four lost significand bits; the bound below is tighter than that.
 AR_BOUNDS = {
-	"f32": dict(kind="abs", logits=2e-3, latents=2e-4),
-	"f16": dict(kind="rel", logits=1.5e-2, latents=1.5e-2),
-	"bf16": dict(kind="rel", logits=1e-1, latents=1e-1),
-	"fp8w": dict(kind="rel", logits=3e-1, latents=3e-1),
+	"f32": dict(kind="abs", logits=5e-4, latents=5e-5),
+	"f16": dict(kind="rel", logits=8e-3, latents=5e-3),
+	"bf16": dict(kind="rel", logits=6e-2, latents=6e-2),
+	"fp8w": dict(kind="rel", logits=5e-1, latents=3e-1),
 }
+BF16_VS_REFERENCE_AUTOCAST = 2.5
 
 
 @pytest.mark.parametrize("variant", ["peaked", "outlier"])
@@ -108,6 +113,10 @@ def test_ar_logits_and_latents_against_the_reference(golden, variant, dtype):
 	e_seq = fn(torch.stack(rows, 1), g[q + "logits_sub"])
 	record(f"ar_{variant}_{dtype}", dict(kind=b["kind"], prefill=e_pre, decode=e_dec, latents=e_lat, sampled_sequence=e_seq, health=model._check_health()))
 	assert e_pre < b["logits"] and e_dec < b["logits"] and e_seq < b["logits"] and e_lat < b["latents"], (variant, dtype, e_pre, e_dec, e_seq, e_lat)
+	if dtype == "bf16":      # no worse than the reference's own 16-bit mode in this regime
+		r_pre, r_dec = relerr(g[p + "prefill_logits_autocast_bf16"], g[p + "prefill_logits"]), relerr(g[p + "decode_logits_autocast_bf16"], g[p + "decode_logits"])
+		record(f"ar_{variant}_reference_autocast_bf16", dict(kind="rel", prefill=r_pre, decode=r_dec))
+		assert e_pre < BF16_VS_REFERENCE_AUTOCAST * r_pre and e_dec < BF16_VS_REFERENCE_AUTOCAST * r_dec, (variant, e_pre, r_pre, e_dec, r_dec)
 
 
 # ------------------------------------------------------------------------------------------------ AR: ids
@@ -209,11 +218,21 @@ def test_ar_full_size_outlier_weights_logits_and_ids(golden):
 	meta = json.loads(str(g["stream_meta"]))
 	with torch.inference_mode():
 		want = O.inference_speech(O.AROracle(sd, cfg), cond, text, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], sample_device="cuda", **meta["kw"])
+		# f32 noise is what this regime amplifies (300x channels through 30 layers): the yardstick for the f32 handle is the reference's OWN distance from the f64 value of the
+		# same function (the oracle on f64 weights): 3.6e-4 on the prefill logits, 3.1e-4 on the latents -- the product must stay within F32_VS_TRUTH x that
+		o64 = O.AROracle({k: v.double() for k, v in sd.items()}, cfg)
+		lg64, _, _ = o64.prefill(o64.prefix_embeddings(cond.double(), text), B)
+		lg64 = lg64[:, -1][:, cols.cpu()]
+		lat64 = o64.forward_latents(cond.double().repeat(B, 1), text.repeat(B, 1), codes)[:, :, :128]
+		ref_pre64, ref_lat64 = maxerr(g["prefill_logits"], lg64), maxerr(g["latents"], lat64)
+		del o64
+	F32_VS_TRUTH = 4.0
 	for dtype in ("f32", "bf16"):
 		model = build_ar(sd, cfg, dtype, max_batch=2, max_ctx=64)
 		b = AR_BOUNDS[dtype]
 		fn = maxerr if b["kind"] == "abs" else relerr
 		logits = model._prefill(cond.to(DEV), text.to(DEV), B)
+		logits_pre = logits.clone()
 		e_pre = fn(logits[:, cols], g["prefill_logits"])
 		dec = []
 		for k in range(toks.shape[1]):
@@ -227,9 +246,15 @@ def test_ar_full_size_outlier_weights_logits_and_ids(golden):
 			warnings.simplefilter("error")
 			got = model.inference_speech(cond.to(DEV), text.to(DEV), do_sample=True, num_return_sequences=meta["B"], max_generate_length=meta["max_new"], **meta["kw"]).cpu()
 		agree = float((got == want).float().mean())
-		record(f"ar_full_outlier_{dtype}", dict(kind=b["kind"], prefill=e_pre, decode=e_dec, latents=e_lat, free_running_id_agreement=agree, health=model.last_health))
-		k = 2.5 if dtype == "f32" else 1.0                               # 30 layers, d = 1024: the f32 bar of the full-size random-weight test is 5x the small one's too
-		assert e_pre < k * b["logits"] and e_dec < k * b["logits"] and e_lat < k * b["latents"], (dtype, e_pre, e_dec, e_lat)
+		rec = dict(kind=b["kind"], prefill=e_pre, decode=e_dec, latents=e_lat, free_running_id_agreement=agree, health=model.last_health)
+		if dtype == "f32":               # measured: logits 8.9e-4 / 8.7e-4 abs, latents 7.0e-4 abs (|latent| to 33); vs the f64 value 9.6e-4 / 7.3e-4 against the reference's own 3.6e-4 / 3.1e-4
+			t_pre, t_lat = maxerr(logits_pre[:, cols], lg64), maxerr(lat[:, :, :128], lat64)
+			rec.update(prefill_vs_f64=t_pre, latents_vs_f64=t_lat, reference_prefill_vs_f64=ref_pre64, reference_latents_vs_f64=ref_lat64)
+			assert e_pre < 3e-3 and e_dec < 3e-3 and e_lat < 2.5e-3, (dtype, e_pre, e_dec, e_lat)
+			assert t_pre < F32_VS_TRUTH * ref_pre64 and t_lat < F32_VS_TRUTH * ref_lat64, (t_pre, ref_pre64, t_lat, ref_lat64)
+		else:
+			assert e_pre < b["logits"] and e_dec < b["logits"] and e_lat < b["latents"], (dtype, e_pre, e_dec, e_lat)
+		record(f"ar_full_outlier_{dtype}", rec)
 		assert model.last_health == 0
 		if dtype == "f32":
 			assert torch.equal(got, want), (got != want).nonzero()[:4].tolist()
@@ -238,14 +263,22 @@ def test_ar_full_size_outlier_weights_logits_and_ids(golden):
 
 # ------------------------------------------------------------------------------------------------ diffusion
 # f32: absolute (|E| to 11 / 18, |y| to 2.5 / 3, x in [-1, 1] at the end); 16-bit / fp8: relative L2 against the reference's f32 values.
-# Measured on MI355X (round 5, gpurun_out/stress_errors.json -> DESIGN.md section 2); bounds = 2.5-4x the measurement.
+# Measured on MI355X (round 5, profiles/r05_stress_errors.json -> DESIGN.md section 2), small model / full size at T = 1088:
+#   f32  E 1.3e-4 / 6.0e-4, evaluation 3.4e-4 / 1.2e-3, x 3.1e-4 / 2.7e-4 abs          f16  E 7.9e-3 / 7.5e-3, evaluation 2.0e-3 / 1.8e-2, x 2.8e-3 / 3.0e-3
+#   bf16 E 2.8e-2 / 5.9e-2, evaluation 1.6e-2 / 1.2e-1, x 1.9e-2 / 2.0e-2              fp8w E 0.17 / 0.26, evaluation 0.12 / 0.37, x 0.13 / 0.06      fp8 E 0.20 / 0.32, evaluation 0.17 / 0.42, x 0.17 / 0.07
+# Bounds = 2.5-4x the measurement (full size: FULL_K x the small model's bound for f32).  Independent criterion for the 16-bit modes: the REFERENCE'S OWN 16-bit mode
+# (DiffusionTTS(use_fp16=True): layers >= 1 under autocast, diffusion.py:1559-1561) deviates from its f32 evaluation by 5.5e-2 (small) / 2.2e-1 (full size) here -- scores of
+# +-100 through 8-bit significands move softmax weights by tens of percent whoever computes them -- and the product's bf16 evaluation must not be further away than that
+# (measured 0.29x / 0.55x).  The fp8 modes lose the evaluation at 12-42 % in this regime (1.9-2.4x the reference's own 16-bit deviation): reported, bounded loosely, and
+# said in DESIGN.md section 2 -- config 5's e4m3 operands are not usable on peaked attention without keeping q / k in 16 bits.
 DIFF_BOUNDS = {
-	"f32": dict(kind="abs", E=1e-3, y=1e-3, x=2e-3),
-	"f16": dict(kind="rel", E=1e-2, y=2e-2, x=3e-2),
-	"bf16": dict(kind="rel", E=8e-2, y=1.5e-1, x=2e-1),
-	"fp8w": dict(kind="rel", E=3e-1, y=5e-1, x=5e-1),
-	"fp8": dict(kind="rel", E=3e-1, y=5e-1, x=5e-1),
+	"f32": dict(kind="abs", E=5e-4, y=1e-3, x=1e-3),
+	"f16": dict(kind="rel", E=2.5e-2, y=5e-2, x=1e-2),
+	"bf16": dict(kind="rel", E=1.5e-1, y=3e-1, x=6e-2),
+	"fp8w": dict(kind="rel", E=6e-1, y=8e-1, x=4e-1),
+	"fp8": dict(kind="rel", E=6e-1, y=8e-1, x=4e-1),
 }
+FULL_K = 4.0
 
 
 def build_diff(sd, cfg, dtype):
@@ -288,6 +321,10 @@ def test_diffusion_small_against_the_reference(golden, dtype):
 	record(f"diff_small_{dtype}", dict(kind=b["kind"], E=e_E, y_cond=e_yc, y_uncond=e_yu, **{f"x_after_{n}": v for n, v in e_x.items()}))
 	assert e_E < b["E"] and e_yc < b["y"] and e_yu < b["y"], (dtype, e_E, e_yc, e_yu)
 	assert all(v < b["x"] for v in e_x.values()), (dtype, e_x)
+	if dtype in ("bf16", "f16"):      # no further from the reference's f32 evaluation than the reference's own 16-bit mode is
+		r = relerr(g["y_cond_ref_fp16mode"], g["y_cond"])
+		record("diff_small_reference_fp16mode", dict(kind="rel", y_cond=r))
+		assert e_yc < r, (dtype, e_yc, r)
 	assert torch.isfinite(xs[-1]).all() and xs[-1].abs().max() <= 1.0 + 1e-5
 
 
@@ -315,5 +352,9 @@ def test_diffusion_full_size_at_T1088_against_the_reference(golden, dtype):
 	xm = ddim_chunks(model, x, Eo, T, 80, [(0, 4)])[0]
 	e_x = fn(xm, g["mel"])
 	record(f"diff_full_{dtype}", dict(kind=b["kind"], E=e_E, y_cond=e_yc, y_uncond=e_yu, mel_last4=e_x))
-	k = 2.0 if dtype == "f32" else 1.0
+	k = FULL_K if dtype == "f32" else 1.0
 	assert e_E < k * b["E"] and e_yc < k * b["y"] and e_yu < k * b["y"] and e_x < k * b["x"], (dtype, e_E, e_yc, e_yu, e_x)
+	if dtype in ("bf16", "f16"):
+		r = relerr(g["y_cond_ref_fp16mode_sub"], g["y_cond_sub"])
+		record("diff_full_reference_fp16mode", dict(kind="rel", y_cond=r))
+		assert e_yc < r, (dtype, e_yc, r)

@@ -195,8 +195,12 @@ __device__ __forceinline__ void load_residual_role(const GemmParams& p, float (&
 		for (int r = 0; r < 4; ++r)
 #pragma unroll
 			for (int j = 0; j < NI; ++j) {
+				// GUARD: a row beyond M reads the LAST row instead (its value is dropped in the epilogue).  The request must leave unconditionally: the tail's waits
+				// count exactly RESN loads behind the last DMA request, and a wave whose rows all lie beyond M (wm = 1 of the last tile row when M % 128 == 64) would
+				// otherwise issue none -- vmcnt(PER_TILE + RESN) then waits for nothing and its barrier passes before the last two k-tiles have landed.
 				const int gm = row0 + 16 * i + lr + r;
-				res[i][r][j] = (!GUARD || gm < p.M) ? p.residual[(unsigned)(gm * N + col0 + 16 * j + lc)] : 0.f;
+				const int gr = GUARD ? min(gm, p.M - 1) : gm;
+				res[i][r][j] = p.residual[(unsigned)(gr * N + col0 + 16 * j + lc)];
 			}
 }
 
@@ -233,7 +237,7 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 				float v = acc[i][j][r];
 				if constexpr (sizeof(T) == 1) v = v * os;
 				v = v + bj[j];
-				if constexpr (R::RES) v += res[i][r][j];
+				if constexpr (R::RES) v += (PRE && GUARD && gm >= p.M) ? 0.f : res[i][r][j];      // (PRE: rows beyond M hold the clamped row's value)
 				acc[i][j][r] = v;
 				if (GUARD && gm >= p.M) continue;
 				const unsigned o = (unsigned)(gm * N + col0 + 16 * j + lc);
