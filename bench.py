@@ -178,11 +178,19 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 					  note=f"timestep-independent conditioning + {n_ddim} steps x (cond + cond-free evaluation); flop = {2 * n_ddim} F(T) per line diffused on this rank"),
 	}
 	out["ar_decode"]["floor_ms"] = ar_floor
+	eff = effective_floor(dtype_name, n_text, n_cand, n_mel, n_ddim, L, L_ddim)
+	for key, name in (("ar_decode", "ar_decode_ms"), ("latent_pass", "latent_pass_ms"), ("ddim", "ddim_ms")):
+		out[key]["effective_floor_ms"] = eff[name]
+		out[key]["frac_of_effective_floor"] = eff[name] / out[key]["ms"] if out[key].get("ms") else None
+	out["effective_floor"] = {"formula": "sum over dependent launches of [boundary + max(hbm_bytes / hbm_stream, bytes_per_CU / cu_l2_intake, flop / peak)] (bench.py, DESIGN.md section 6)",
+							  "constants": eff["constants"], "launches": eff["launches"], "ddim_step_us": eff["ddim_step_us"], "decode_token_us": eff["decode_token_us_at_mean_ctx"]}
 	if L > 1:
 		out["lines"] = L
 	out["whole_step_floor_ms"] = out["ar_decode"]["floor_ms"] + out["latent_pass"]["floor_ms"] + out["ddim"]["floor_ms"]
 	out["whole_step_ms"] = sum(v for k, v in ms.items() if not k.startswith("_"))
 	out["whole_step_frac_of_floor"] = out["whole_step_floor_ms"] / out["whole_step_ms"] if out["whole_step_ms"] else None
+	out["whole_step_effective_floor_ms"] = eff["ar_decode_ms"] + eff["latent_pass_ms"] + eff["ddim_ms"]
+	out["whole_step_frac_of_effective_floor"] = out["whole_step_effective_floor_ms"] / out["whole_step_ms"] if out["whole_step_ms"] else None
 	return out
 
 
@@ -197,6 +205,77 @@ def out_dir():
 
 def rank_file(rank):
 	return os.path.join(out_dir(), f"rank{rank}.err")
+
+
+# ---- the floor that applies.  The spec-peak fractions above measure the distance to bounds neither loop can reach at B = 16 / b = 2: the token
+# loop is a chain of ~150 DEPENDENT launches per token, and a DDIM step's GEMMs have one tile per CU, whose k-loop runs at what one CU takes in from L2.  The
+# effective floor prices exactly that, from stated constants of MI355X_MICROARCH.md's price table and the launch list of the path:
+#     effective_floor = sum over the phase's dependent launches of [ BOUNDARY_US + max( hbm_bytes / HBM_STREAM , bytes_per_CU / CU_L2_INTAKE , flop / peak ) ]
+#   BOUNDARY_US   1.45   "boundary": dependent kernel boundary on one stream, eager = graph
+#   HBM_STREAM    6.4e12 "ldsdma-fill": what the chip streams from HBM with every CU loading (default policy; 8.0e12 is the spec figure the `frac` fields use)
+#   CU_L2_INTAKE  68e9   "ring-gemm": the median CU takes in 68 GB/s through LDS-DMA; a GEMM tile of BM x BN over K (x taps) stages (BM + BN) * K * taps * sizeof(T) bytes
+#                        per CU and launch-round (rounds = max(1, tiles / 256)); tile shapes as csrc/gemm.hip picks them (`pick_tile`)
+# Launch lists (include/ttk.h entry points -> csrc/ar.hip, csrc/diff.hip): a decode token = 30 x (ln_1+c_attn, attention, c_proj, ln_2+c_fc, mlp.c_proj) + mel_head + sampler
+# = 152 launches over 805 MB of weights + the KV cache; the dense passes (prefill, latent pass) = 30 x (2 LayerNorm + 4 GEMM + attention) + 4; a DDIM step on the cond +
+# cond-free batch = 16 ResBlocks x (2 GroupNorm-apply + 1x1 conv + k=3 conv) + 13 AttentionBlocks x (GroupNorm-apply + qkv + attention + proj_out) + 8 others
+# (layout changes, input / integrating / output convs, out norm, the sampler update) = 124 launches.  Reported NEXT TO `frac`, never instead of it.
+BOUNDARY_US, HBM_STREAM, CU_L2_INTAKE = 1.45, 6.4e12, 68e9
+
+
+def _gemm_floor_us(M, N, K, taps, e, peak):
+	t128, t12864 = -(-M // 128) * -(-N // 128), -(-M // 128) * -(-N // 64)
+	if t128 >= 256:
+		bm, bn, tiles = 128, 128, t128
+		t256 = -(-M // 256) * -(-N // 128)
+		if e <= 2 and t128 > 256 and 15 * -(-t256 // 256) < 9 * -(-t128 // 256):
+			bm, bn, tiles = 256, 128, t256
+	elif t12864 >= 128:
+		bm, bn, tiles = 128, 64, t12864
+	else:
+		bm, bn, tiles = 64, 64, -(-M // 64) * -(-N // 64)
+	rounds = max(1.0, tiles / 256)        # a floor: surplus tiles spread evenly (the mixed grid of csrc/gemm.hip approaches this), never a whole second round
+	return max(rounds * (bm + bn) * K * taps * e / CU_L2_INTAKE, 2.0 * M * N * K * taps / peak) * 1e6
+
+
+def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL_TOKENS, n_ddim=DDIM_STEPS, lines=1, lines_ddim=1):
+	"""{phase: effective_floor_ms, ...} by the formula above; `ar_bytes` etc. as phase_roofline counts them"""
+	e = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 2, "fp8": 2}[dtype_name]      # operand bytes staged per element by the dense GEMMs (fp8w widens at load; fp8 block GEMMs: 1, below)
+	e_w = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
+	e_kv = 4 if dtype_name == "f32" else 2
+	peak = 157.3e12 if dtype_name == "f32" else 2.5e15
+	P1, d = n_text + 4, 1024
+	blocks, head = 377_886_720, 8_398_850 + 4_096
+	# token loop
+	tok_launches = 30 * 5 + 2
+	ar_us = 0.0
+	for k in range(1, n_mel):
+		ctx = P1 + k
+		hbm = blocks * e_w + head * (2 if e_w == 1 else e_w) + n_cand * 30 * 2 * ctx * d * e_kv + n_cand * 8194 * 4
+		ar_us += tok_launches * BOUNDARY_US + hbm / HBM_STREAM * 1e6
+	def dense_pass_us(rows_per_seq, seqs):
+		M = rows_per_seq * seqs
+		g = sum(_gemm_floor_us(M, n, k, 1, e, peak) for n, k in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d)))
+		attn = 2.0 * 2 * rows_per_seq * rows_per_seq * d * seqs / peak * 1e6 / 2      # causal: half the score matrix
+		ln = 2 * (M * d * (4 + e) / 256 / CU_L2_INTAKE) * 1e6
+		return 30 * (7 * BOUNDARY_US + g + attn + ln) + 4 * BOUNDARY_US
+	ar_us += dense_pass_us(P1, 1)                                     # the prefill runs the shared prefix once
+	lat_us = dense_pass_us(n_text + n_mel + 5, n_cand)
+	# DDIM step on the batch of 2 sequences (cond + cond-free) of T frames
+	T = n_mel * 4 * 24000 // 22050
+	M = 2 * T
+	e_blk = 1 if dtype_name == "fp8" else e
+	peak_blk = 5.0e15 if dtype_name == "fp8" else peak
+	gn = M * d * (4 + e_blk) / 256 / CU_L2_INTAKE * 1e6
+	res = 2 * gn + _gemm_floor_us(M, d, d, 1, e_blk, peak_blk) + _gemm_floor_us(M, d, d, 3, e_blk, peak_blk) + 4 * BOUNDARY_US
+	att = gn + _gemm_floor_us(M, 3 * d, d, 1, e_blk, peak_blk) + 2.0 * 2 * T * T * d * 2 / peak * 1e6 + _gemm_floor_us(M, d, d, 1, e_blk, peak_blk) + 4 * BOUNDARY_US
+	other = 8 * BOUNDARY_US + _gemm_floor_us(M, d, 100, 3, e, peak) + _gemm_floor_us(M, d, 2 * d, 1, e, peak) + _gemm_floor_us(M, 200, d, 3, e, peak) + gn
+	step_us = 16 * res + 13 * att + other
+	step_launches = 16 * 4 + 13 * 4 + 8
+	pre_us = 4 * (att - gn) + 8 * BOUNDARY_US                          # timestep_independent: 4 AttentionBlocks on the M latent rows (small), conv, norm, interpolate
+	return {"constants": {"boundary_us": BOUNDARY_US, "hbm_stream_Bps": HBM_STREAM, "cu_l2_intake_Bps": CU_L2_INTAKE},
+			"launches": {"decode_token": tok_launches, "ddim_step": step_launches},
+			"ar_decode_ms": lines * ar_us * 1e-3, "latent_pass_ms": lines * lat_us * 1e-3, "ddim_ms": lines_ddim * (n_ddim * step_us + pre_us) * 1e-3,
+			"ddim_step_us": step_us, "decode_token_us_at_mean_ctx": ar_us / max(n_mel - 1, 1)}
 
 
 def log(msg):

@@ -550,12 +550,22 @@ def stress_ar_full_case(uv_mod):
 		dec = torch.stack(dec, 1)
 		lat = m.forward(cond.repeat(B, 1), text.repeat(B, 1), torch.tensor([Tt] * B, dtype=torch.int32), codes,
 						torch.tensor([M * cfg.mel_length_compression] * B), return_latent=True, clip_inputs=False)
+		with torch.autocast("cpu", dtype=torch.bfloat16):      # the reference's own 16-bit deviation (see stress_ar_case)
+			r = im.forward(input_ids=ids, attention_mask=torch.ones(B, P1, dtype=torch.long), use_cache=True, return_dict=True)
+			pre_amp, past, dec_amp = r.logits[:, -1].float(), r.past_key_values, []
+			for k in range(1, n_dec + 1):
+				r = im.forward(input_ids=dec_tokens[:, k - 1:k], past_key_values=past, attention_mask=torch.ones(B, P1 + k, dtype=torch.long), use_cache=True, return_dict=True)
+				past = r.past_key_values
+				dec_amp.append(r.logits[:, -1].float())
+			dec_amp = torch.stack(dec_amp, 1)
+	print(f"  full outlier: the reference under autocast(bf16) vs itself in f32: rel L2 prefill {float((pre_amp - pre).norm() / pre.norm()):.3e}, decode {float((dec_amp - dec).norm() / dec.norm()):.3e}")
 	kw = dict(temperature=0.8, top_k=16, repetition_penalty=2.0)
 	toks, lats, logits = _stream_with_logits(uv_mod, m, cfg, cond, text, 2, 12, kw)
 	pm = torch.softmax(logits / 0.8, -1).max(-1)[0]
 	print(f"  full outlier: logits std {float(dec.std()):.2f}, max-prob median {float(pm.median()):.3f}; ids[0] = {toks[0].tolist()}")
 	return dict(seed=np.int64(seed), B=np.int64(B), text=text.numpy(), cond=cond.numpy(), dec_tokens=dec_tokens.numpy(), codes=codes.numpy(),
 				logit_cols=sel.numpy(), prefill_logits=pre[:, sel].numpy(), decode_logits=dec[:, :, sel].numpy(), latents=lat[:, :, :128].numpy(),
+				prefill_logits_autocast_bf16=pre_amp[:, sel].numpy(), decode_logits_autocast_bf16=dec_amp[:, :, sel].numpy(),
 				stream_ids=toks.numpy(), stream_logits=logits[:, :, sel].numpy(), stream_latents=lats[:, :, :128].numpy(),
 				stream_meta=np.array(json.dumps(dict(B=2, max_new=12, kw=kw))))
 
