@@ -5,6 +5,11 @@
 // chain: kernel boundaries, start spread, and the phases inside (GEMM: first requests issued, first tile landed, k-loop, epilogue, stores acknowledged).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTTK_STAMPS=2 -I tortoise_tts_amd/csrc tests/diag/ddim_chain.cpp -o tests/diag/ddim_chain.bin
 //   tests/diag/ddim_chain.bin [replays=10]          env: DC_LAYERS (20), DC_T (1088), DC_NB (2), DC_PF (1: GroupNorm-apply / attention touch the next GEMM's weights)
+//   DC_SIDE=k   (round 5) the timed loop runs TWO streams: step j+1's conditioning_timestep_integrator (3 of these layers, own weights and
+//               activations) beside the 13 layers of step j's body (csrc/diff.hip).  With DC_SIDE=k a second stream replays k layers (own buffers, own weights) with
+//               every replay of the main chain, so the stamps and the per-layer time are taken under the contention the bench has (k = 5 beside 20 main layers ~ 3 : 13).
+//   DC_EAGER=1  counter mode: no graph, no stamps -- `replays` x DC_LAYERS layers launched eagerly (~10^3 dispatches: inside what `rocprofv3 --pmc` survives on this
+//               image, which faults on a captured graph's dispatches), then exit.  Build WITHOUT -DTTK_STAMPS for it (tests/diag/pmc_kloop.sh).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +24,11 @@ void ttk::prof_start(int, double, hipStream_t) {}
 void ttk::prof_stop(hipStream_t) {}
 void ttk::prof_pair(int, double, hipEvent_t* a, hipEvent_t* b) { *a = nullptr; *b = nullptr; }
 using namespace ttk;
+#ifdef TTK_STAMPS
+#define SETST(P, V) (P).stamps = (V)
+#else
+#define SETST(P, V) (void)(V)      // the plain build (counter mode) has no stamp field
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e), __LINE__); return 1; } } while (0)
 static int envi(const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; }
 
@@ -40,54 +50,75 @@ int main(int argc, char** argv) {
 		CK(hipMalloc(&L[i].w1, (size_t)C * C * 2)); CK(hipMalloc(&L[i].w3, (size_t)3 * C * C * 2)); CK(hipMalloc(&L[i].wqkv, (size_t)3 * C * C * 2)); CK(hipMalloc(&L[i].wproj, (size_t)C * C * 2));
 		CK(hipMemset(L[i].w1, 0, (size_t)C * C * 2)); CK(hipMemset(L[i].w3, 0, (size_t)3 * C * C * 2)); CK(hipMemset(L[i].wqkv, 0, (size_t)3 * C * C * 2)); CK(hipMemset(L[i].wproj, 0, (size_t)C * C * 2));
 	}
-	float *x, *hf, *ms, *gam, *bet, *bias, *relb; void *a, *qkv, *ao; unsigned long long* stamps;
+	const int NSIDE = envi("DC_SIDE", 0), EAGER = envi("DC_EAGER", 0);
+	std::vector<Layer> LS(NSIDE);
+	for (int i = 0; i < NSIDE; ++i) {
+		CK(hipMalloc(&LS[i].w1, (size_t)C * C * 2)); CK(hipMalloc(&LS[i].w3, (size_t)3 * C * C * 2)); CK(hipMalloc(&LS[i].wqkv, (size_t)3 * C * C * 2)); CK(hipMalloc(&LS[i].wproj, (size_t)C * C * 2));
+		CK(hipMemset(LS[i].w1, 0, (size_t)C * C * 2)); CK(hipMemset(LS[i].w3, 0, (size_t)3 * C * C * 2)); CK(hipMemset(LS[i].wqkv, 0, (size_t)3 * C * C * 2)); CK(hipMemset(LS[i].wproj, 0, (size_t)C * C * 2));
+	}
+	float *gam, *bet, *bias, *relb; unsigned long long* stamps;
+	struct Bufs { float *x, *hf, *ms; void *a, *qkv, *ao; };
 	const int nch = gn_num_chunks(T, C);
-	CK(hipMalloc(&x, (size_t)M * C * 4)); CK(hipMalloc(&hf, (size_t)M * C * 4)); CK(hipMalloc(&ms, (size_t)nb * 32 * nch * 3 * 4));
 	CK(hipMalloc(&gam, C * 4)); CK(hipMalloc(&bet, C * 4)); CK(hipMalloc(&bias, 3 * C * 4)); CK(hipMalloc(&relb, H * 129 * 4));
-	CK(hipMalloc(&a, (size_t)M * C * 2)); CK(hipMalloc(&qkv, (size_t)M * 3 * C * 2)); CK(hipMalloc(&ao, (size_t)M * C * 2));
+	CK(hipMemset(gam, 0, C * 4)); CK(hipMemset(bet, 0, C * 4)); CK(hipMemset(bias, 0, 3 * C * 4)); CK(hipMemset(relb, 0, H * 129 * 4));
 	CK(hipMalloc(&stamps, 8 * SLOTS * 8));
-	CK(hipMemset(x, 0, (size_t)M * C * 4)); CK(hipMemset(hf, 0, (size_t)M * C * 4)); CK(hipMemset(gam, 0, C * 4)); CK(hipMemset(bet, 0, C * 4)); CK(hipMemset(bias, 0, 3 * C * 4)); CK(hipMemset(relb, 0, H * 129 * 4));
-	CK(hipMemset(a, 0, (size_t)M * C * 2)); CK(hipMemset(qkv, 0, (size_t)M * 3 * C * 2)); CK(hipMemset(ao, 0, (size_t)M * C * 2));
-	{   // valid statistics: every chunk (64 rows x 32 channels) count 2048, mean 0, M2 2048
+	Bufs BF[2];
+	for (int b = 0; b < (NSIDE ? 2 : 1); ++b) {
+		Bufs& B = BF[b];
+		CK(hipMalloc(&B.x, (size_t)M * C * 4)); CK(hipMalloc(&B.hf, (size_t)M * C * 4)); CK(hipMalloc(&B.ms, (size_t)nb * 32 * nch * 3 * 4));
+		CK(hipMalloc(&B.a, (size_t)M * C * 2)); CK(hipMalloc(&B.qkv, (size_t)M * 3 * C * 2)); CK(hipMalloc(&B.ao, (size_t)M * C * 2));
+		CK(hipMemset(B.x, 0, (size_t)M * C * 4)); CK(hipMemset(B.hf, 0, (size_t)M * C * 4));
+		CK(hipMemset(B.a, 0, (size_t)M * C * 2)); CK(hipMemset(B.qkv, 0, (size_t)M * 3 * C * 2)); CK(hipMemset(B.ao, 0, (size_t)M * C * 2));
+		// valid statistics: every chunk (64 rows x 32 channels) count 2048, mean 0, M2 2048
 		std::vector<float> h((size_t)nb * 32 * nch * 3);
 		for (size_t i = 0; i < h.size(); i += 3) { h[i] = 2048.f; h[i + 1] = 0.f; h[i + 2] = 2048.f; }
-		CK(hipMemcpy(ms, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+		CK(hipMemcpy(B.ms, h.data(), h.size() * 4, hipMemcpyHostToDevice));
 	}
-	hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	hipStream_t s, s2; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+	hipStream_t cur = s; Bufs* CB = &BF[0];      // the lane the helpers below enqueue into
 
 	auto gn = [&](const float* src, const void* next_w, int64_t next_bytes, int taps, unsigned long long* st) {
 		GnApplyParams p = {};
-		p.x = src; p.ms = ms; p.gamma = gam; p.beta = bet; p.nb = nb; p.T = T; p.Tout = T; p.C = C; p.nchunks = nch; p.act = ACT_SILU; p.out = a;
+		p.x = src; p.ms = CB->ms; p.gamma = gam; p.beta = bet; p.nb = nb; p.T = T; p.Tout = T; p.C = C; p.nchunks = nch; p.act = ACT_SILU; p.out = CB->a;
 		if (pf) { p.pf = next_w; p.pf_bytes = next_bytes; p.pf_taps = taps; }
-		p.stamps = st;
-		launch_gn_apply(DT_BF16, p, s);
+		SETST(p, st);
+		launch_gn_apply(DT_BF16, p, cur);
 	};
-	auto layer = [&](int i, unsigned long long* st) {
+	auto layer_of = [&](const Layer& W, unsigned long long* st) {
+		float *x = CB->x, *hf = CB->hf, *ms = CB->ms; void *a = CB->a, *qkv = CB->qkv, *ao = CB->ao;
 		auto S = [&](int k) { return st ? st + k * SLOTS : nullptr; };
 		// ResBlock
-		gn(x, L[i].w1, (int64_t)C * C * 2, 1, S(0));
+		gn(x, W.w1, (int64_t)C * C * 2, 1, S(0));
 		GemmParams g = {};
-		g.nseg = 1; g.seg[0] = {a, C, 0, 0}; g.W = L[i].w1; g.ldw = C; g.M = M; g.N = C; g.K = C; g.bias = bias; g.C = hf; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; g.stamps = S(1);
-		launch_gemm(DT_BF16, g, s);
-		gn(hf, L[i].w3, (int64_t)C * C * 2, 3, S(2));
+		g.nseg = 1; g.seg[0] = {a, C, 0, 0}; g.W = W.w1; g.ldw = C; g.M = M; g.N = C; g.K = C; g.bias = bias; g.C = hf; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; SETST(g, S(1));
+		launch_gemm(DT_BF16, g, cur);
+		gn(hf, W.w3, (int64_t)C * C * 2, 3, S(2));
 		g = {};
 		g.nseg = 3; for (int j = 0; j < 3; ++j) g.seg[j] = {a, C, j - 1, (int64_t)j * C * C};
-		g.W = L[i].w3; g.ldw = C; g.M = M; g.N = C; g.K = C; g.rows_per_batch = T; g.bias = bias; g.residual = x; g.ldr = C; g.C = x; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; g.stamps = S(3);
-		launch_gemm(DT_BF16, g, s);
+		g.W = W.w3; g.ldw = C; g.M = M; g.N = C; g.K = C; g.rows_per_batch = T; g.bias = bias; g.residual = x; g.ldr = C; g.C = x; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; SETST(g, S(3));
+		launch_gemm(DT_BF16, g, cur);
 		// AttentionBlock
-		gn(x, L[i].wqkv, (int64_t)3 * C * C * 2, 1, S(4));
+		gn(x, W.wqkv, (int64_t)3 * C * C * 2, 1, S(4));
 		g = {};
-		g.nseg = 1; g.seg[0] = {a, C, 0, 0}; g.W = L[i].wqkv; g.ldw = C; g.M = M; g.N = 3 * C; g.K = C; g.bias = bias; g.C = qkv; g.ldc = 3 * C; g.stamps = S(5);
-		launch_gemm(DT_BF16, g, s);
+		g.nseg = 1; g.seg[0] = {a, C, 0, 0}; g.W = W.wqkv; g.ldw = C; g.M = M; g.N = 3 * C; g.K = C; g.bias = bias; g.C = qkv; g.ldc = 3 * C; SETST(g, S(5));
+		launch_gemm(DT_BF16, g, cur);
 		AttnParams at = {};
 		at.qkv = qkv; at.ld = 3 * C; at.q_off = 0; at.k_off = 64; at.v_off = 128; at.head_stride = 192; at.out = ao; at.ldo = C; at.nb = nb; at.T = T; at.H = H; at.bias = relb; at.scale = 0.125f;
-		if (pf) { at.pf = L[i].wproj; at.pf_bytes = (int64_t)C * C * 2; at.pf_taps = 1; }
-		at.stamps = S(6);
-		launch_attn_fwd(DT_BF16, at, s);
+		if (pf) { at.pf = W.wproj; at.pf_bytes = (int64_t)C * C * 2; at.pf_taps = 1; }
+		SETST(at, S(6));
+		launch_attn_fwd(DT_BF16, at, cur);
 		g = {};
-		g.nseg = 1; g.seg[0] = {ao, C, 0, 0}; g.W = L[i].wproj; g.ldw = C; g.M = M; g.N = C; g.K = C; g.bias = bias; g.residual = x; g.ldr = C; g.C = x; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; g.stamps = S(7);
-		launch_gemm(DT_BF16, g, s);
+		g.nseg = 1; g.seg[0] = {ao, C, 0, 0}; g.W = W.wproj; g.ldw = C; g.M = M; g.N = C; g.K = C; g.bias = bias; g.residual = x; g.ldr = C; g.C = x; g.ldc = C; g.out_f32 = 1; g.gn_part = ms; g.gn_T = T; SETST(g, S(7));
+		launch_gemm(DT_BF16, g, cur);
 	};
+	auto layer = [&](int i, unsigned long long* st) { layer_of(L[i], st); };
+	auto side_layers = [&]() { cur = s2; CB = &BF[1]; for (int i = 0; i < NSIDE; ++i) layer_of(LS[i], nullptr); cur = s; CB = &BF[0]; };
+	if (EAGER) {      // counter mode: bounded eager loop, nothing else
+		for (int r = 0; r < replays; ++r) { for (int i = 0; i < NL; ++i) layer(i, nullptr); if (NSIDE) side_layers(); }
+		CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
+		printf("ddim chain (eager counter mode): T %d nb %d, %d layers x %d replays = %d dispatches%s\n", T, nb, NL, replays, NL * replays * 8, NSIDE ? " + side lane" : "");
+		return 0;
+	}
 	for (int i = 0; i < NL; ++i) layer(i, nullptr);
 	CK(hipStreamSynchronize(s));
 	hipGraph_t gr; hipGraphExec_t ge, ges;
@@ -97,12 +128,20 @@ int main(int argc, char** argv) {
 	CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
 	for (int i = 0; i < NL; ++i) layer(i, i == SL ? stamps : nullptr);
 	CK(hipStreamEndCapture(s, &gr)); CK(hipGraphInstantiate(&ges, gr, nullptr, nullptr, 0)); CK(hipGraphDestroy(gr));
+	hipGraphExec_t gside = nullptr;
+	if (NSIDE) {
+		side_layers(); CK(hipStreamSynchronize(s2));
+		CK(hipStreamBeginCapture(s2, hipStreamCaptureModeThreadLocal));
+		side_layers();
+		CK(hipStreamEndCapture(s2, &gr)); CK(hipGraphInstantiate(&gside, gr, nullptr, nullptr, 0)); CK(hipGraphDestroy(gr));
+	}
+	auto launch_main = [&](hipGraphExec_t g) { if (gside) (void)hipGraphLaunch(gside, s2); return hipGraphLaunch(g, s); };
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	float best = 1e9f, best_eager = 1e9f;
 	for (int rep = 0; rep < 4; ++rep) {
 		CK(hipEventRecord(e0, s));
-		for (int r = 0; r < replays; ++r) CK(hipGraphLaunch(ge, s));
-		CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+		for (int r = 0; r < replays; ++r) CK(launch_main(ge));
+		CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipStreamSynchronize(s2));
 		float msv; CK(hipEventElapsedTime(&msv, e0, e1));
 		if (rep >= 1) best = std::min(best, msv);
 	}
@@ -113,6 +152,7 @@ int main(int argc, char** argv) {
 		float msv; CK(hipEventElapsedTime(&msv, e0, e1));
 		if (rep >= 1) best_eager = std::min(best_eager, msv);
 	}
+	if (NSIDE) printf("side lane: %d layers on a second stream with every replay of the main chain\n", NSIDE);
 	printf("ddim chain: T %d nb %d (M = %d), %d layers x %d replays, prefetch %d: graph %.2f us per layer (%.2f per launch), eager %.2f us per layer\n", T, nb, M, NL, replays, pf,
 		   best * 1e3 / (replays * NL), best * 1e3 / (replays * NL * 8), best_eager * 1e3 / (replays * NL));
 
@@ -122,9 +162,9 @@ int main(int argc, char** argv) {
 	std::vector<double> stat[8][10];
 	for (int rep = 0; rep < 9; ++rep) {
 		CK(hipMemsetAsync(stamps, 0, 8 * SLOTS * 8, s));
-		CK(hipGraphLaunch(ge, s)); CK(hipGraphLaunch(ges, s)); CK(hipGraphLaunch(ge, s));
+		CK(launch_main(ge)); CK(launch_main(ges)); CK(launch_main(ge));
 		CK(hipMemcpyAsync(hs.data(), stamps, 8 * SLOTS * 8, hipMemcpyDeviceToHost, s));
-		CK(hipStreamSynchronize(s));
+		CK(hipStreamSynchronize(s)); CK(hipStreamSynchronize(s2));
 		if (rep < 2) continue;
 		double prev_end = 0;
 		for (int k = 0; k < 8; ++k) {
