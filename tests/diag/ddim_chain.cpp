@@ -8,6 +8,7 @@
 //   DC_SIDE=k   (round 5) the timed loop runs TWO streams: step j+1's conditioning_timestep_integrator (3 of these layers, own weights and
 //               activations) beside the 13 layers of step j's body (csrc/diff.hip).  With DC_SIDE=k a second stream replays k layers (own buffers, own weights) with
 //               every replay of the main chain, so the stamps and the per-layer time are taken under the contention the bench has (k = 5 beside 20 main layers ~ 3 : 13).
+//               DC_STAMP_LAYER picks the stamped layer (default the middle one; 2 lies under the side lane, which runs beside the first layers of every replay).
 //   DC_EAGER=1  counter mode: no graph, no stamps -- `replays` x DC_LAYERS layers launched eagerly (~10^3 dispatches: inside what `rocprofv3 --pmc` survives on this
 //               image, which faults on a captured graph's dispatches), then exit.  Build WITHOUT -DTTK_STAMPS for it (tests/diag/pmc_kloop.sh).
 #include <hip/hip_runtime.h>
@@ -43,7 +44,7 @@ static double q(std::vector<double> v, double f) {
 
 int main(int argc, char** argv) {
 	const int replays = argc > 1 ? atoi(argv[1]) : 10;
-	const int NL = envi("DC_LAYERS", 20), SL = NL / 2, T = envi("DC_T", 1088), nb = envi("DC_NB", 2), C = 1024, H = 16, M = nb * T, pf = envi("DC_PF", 1);
+	const int NL = envi("DC_LAYERS", 20), SL = envi("DC_STAMP_LAYER", NL / 2), T = envi("DC_T", 1088), nb = envi("DC_NB", 2), C = 1024, H = 16, M = nb * T, pf = envi("DC_PF", 1);
 	struct Layer { void *w1, *w3, *wqkv, *wproj; };
 	std::vector<Layer> L(NL);
 	for (int i = 0; i < NL; ++i) {
@@ -135,7 +136,9 @@ int main(int argc, char** argv) {
 		side_layers();
 		CK(hipStreamEndCapture(s2, &gr)); CK(hipGraphInstantiate(&gside, gr, nullptr, nullptr, 0)); CK(hipGraphDestroy(gr));
 	}
-	auto launch_main = [&](hipGraphExec_t g) { if (gside) (void)hipGraphLaunch(gside, s2); return hipGraphLaunch(g, s); };
+	hipEvent_t efork; CK(hipEventCreateWithFlags(&efork, hipEventDisableTiming));
+	// the side lane of a replay starts WITH that replay's main chain (an event on the main stream releases it), as step j+1's integrator starts with step j's body
+	auto launch_main = [&](hipGraphExec_t g) { if (gside) { (void)hipEventRecord(efork, s); (void)hipStreamWaitEvent(s2, efork, 0); (void)hipGraphLaunch(gside, s2); } return hipGraphLaunch(g, s); };
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	float best = 1e9f, best_eager = 1e9f;
 	for (int rep = 0; rep < 4; ++rep) {

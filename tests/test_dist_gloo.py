@@ -166,6 +166,19 @@ def _body_spread_lines(rank, world):
 	return out
 
 
+def _body_ancestral_lines_stay_home(rank, world):
+	"""a stage whose diffusion draws from the generator while it runs (sampler="p") must be diffused on its winner's owner -- the per-step noise
+	comes from the generator of the rank that runs the loop, and only the start noise travels with a moved item.  Two lines, both winners on rank 0, the
+	second line's stages marked: nothing is spread (rank 0 runs both as one batch), results as in the unspread run."""
+	sts = [_FakeStages(False), _FakeStages(False)]
+	sts[1].diffusion_draws_while_running = True
+	batches = []
+	for st in sts:
+		st.run_diffusion = (lambda prepared, st=st: (batches.append(len(prepared)), [st.diffuse(c, l) for c, l in prepared])[1])
+	res = D.sharded_candidates_lines(sts, 7)
+	return dict(res=[dict(mel=m, ids=i, scores=s, best=b) for m, i, s, b in res], batches=batches)
+
+
 def _body_subgroups(rank, world):
 	"""a 4-rank world cut into two 2-rank sub-groups (2 utterances x 2-way candidate shards, as configs[2] x configs[3] would combine on 8 GPUs),
 	and a 2-rank sub-group of a 3-rank world: every collective of the sharded path must stay inside the group it was given"""
@@ -326,6 +339,17 @@ def test_assign_diffusers_is_deterministic_balanced_and_keeps_lines_at_home_when
 		a = D.assign_diffusers(owners, world)
 		load = [a.count(r) for r in range(world)]
 		assert max(load) - min(load) <= 1
+
+
+def test_lines_of_an_ancestral_sampler_are_diffused_on_their_owner():
+	got = _run_ranks(_body_ancestral_lines_stay_home)
+	Lmax = max(3 + (c * 5) % 4 for c in range(7))
+	want_ids = torch.stack([_FakeStages.row(c, Lmax) for c in range(7)])
+	want_mel = (want_ids[0].float().sum() * 1.5).view(1, 1, 1) + torch.arange(12.0).view(1, 3, 4)
+	assert got[0]["batches"] == [2] and got[1]["batches"] == []          # both lines on rank 0, nothing moved
+	for r in (0, 1):
+		for k in range(2):
+			assert torch.equal(got[r]["res"][k]["mel"], want_mel) and got[r]["res"][k]["best"] == 0
 
 
 @pytest.mark.parametrize("world", [2, 4])

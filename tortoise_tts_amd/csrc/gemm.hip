@@ -580,6 +580,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmParams p) {
 	} else {                   // half-height tiles of the remaining rows: j = row block * 16 + (n-tile & 1) * 8 + XCD, n-tile = 2 * XCD + (n-tile & 1) -- the XCD whose L2 holds that weight slice
 		// (64 x 32 tiles on ONE wave each, over 64 CUs, were tried as well: a lone wave's k-loop is slower than the full tile beside it -- 116.0 against 114.5 us per
 		// layer, 130.0 against 128.3 ms per loop; profiles/r04_ddim_chain_mixed_quarter.log)
+		// HARDWARE RELIANCE: waves 2 and 3 end here while waves 0 and 1 go on to execute s_barrier in every k-step.  HIP leaves a barrier reached by part
+		// of a workgroup undefined; on gfx950 a wave that has ENDED leaves the workgroup's barrier count (s_endpgm decrements it), so the two remaining waves
+		// synchronise among themselves.  That is what this branch stands on -- pinned by tests/test_gpu_gemm_roles.py at T = 1216 (48 half tiles, bit-identical to
+		// the generic kernel) and by every T = 1088 test of the DDIM loop (16 half tiles per launch).  A port to another target must keep the surplus waves alive instead.
 		if (wave >= 2) return;
 		const int j = b - p.mix_full;
 		gemm_tile<T, 64, 64, 1, 2, 3, ROLE>(p, p.mix_fm * 128 + (j >> 4) * 64, (2 * (j & 7) + ((j >> 3) & 1)) * 64, wave);

@@ -88,6 +88,9 @@ class ShardStages:
 	the CPU tests implement them on plain tensors to run the control flow under gloo."""
 
 	pad_token: int = 0
+	# does `run_diffusion` draw from the rank's generator WHILE it runs (an ancestral sampler's per-step noise)?  Then only the winner's owner has the generator
+	# state the unsharded run would have, and the line must not be handed to another rank (ADVICE r04: only the start noise travels with a prepared item)
+	diffusion_draws_while_running: bool = False
 
 	def sample(self, lo: int, hi: int, n_candidates: int) -> torch.Tensor:
 		"""ids [hi - lo, L_r] of candidates lo..hi-1 (rows lo..hi-1 of the unsharded sampling, ending with this shard's last row)"""
@@ -209,7 +212,8 @@ def sharded_candidates_lines(stages_list, n_candidates: int, group=None, spread:
 	"""`sharded_candidates` for the lines of one text: per line the same exchange (shard sampling, id all-gather, RNG alignment, latent pass and
 	scores on every shard, first maximum wins), with the winner's owner making that line's random draws at once (`prepare_diffusion`: the next
 	line's `generate` reseeds, so the start noise is drawn where the single-GPU run draws it and TRAVELS with the item) -- then the lines'
-	diffusions are spread over the ranks (`assign_diffusers`; spread=False keeps every line on its winner's owner): a line assigned to another rank
+	diffusions are spread over the ranks (`assign_diffusers`; spread=False, or any stage with `diffusion_draws_while_running` -- the ancestral sampler --
+	keeps every line on its winner's owner): a line assigned to another rank
 	than its owner has its prepared item (latents + start noise, <= 2 MB) broadcast inside the group, every rank runs ONE diffusion over the lines
 	assigned to it (`run_diffusion`: a ragged batch on libttk), and the mels are broadcast line by line from where they were made.
 	Returns [(mel, ids, scores, best)] per line, each equal to that line's own `sharded_candidates` result."""
@@ -233,6 +237,8 @@ def sharded_candidates_lines(stages_list, n_candidates: int, group=None, spread:
 		prep = st.prepare_diffusion(codes[idx:idx + 1], lat[idx:idx + 1]) if rank == owner else None
 		picked.append(dict(owner=owner, ids=ids, scores=scores, best=best, prep=prep))
 	owners = [p["owner"] for p in picked]
+	# a sampler that draws per-step noise inside the loop (sampler="p") keeps every line on its winner's owner: the moved item carries the start noise only
+	spread = spread and not any(getattr(st, "diffusion_draws_while_running", False) for st in stages_list)
 	diffusers = assign_diffusers(owners, world) if spread else owners
 	for k, (p, st) in enumerate(zip(picked, stages_list)):
 		p["diffuser"] = diffusers[k]

@@ -62,6 +62,8 @@ class HotPathStages:
 			self.kw["suppress_tokens"] = suppress_tokens
 		self.diffuser = get_diffuser(steps=max_diffusion_steps, cond_free=cond_free)
 		self.diffusion_temp, self.sampler = diffusion_temp, diffusion_sampler
+		# dist.ShardStages: the ancestral sampler draws its per-step noise inside the loop, from the generator of the rank that runs it -- such a line stays on its winner's owner
+		self.diffusion_draws_while_running = diffusion_sampler != "ddim"
 		self.pad_token = self.ar.stop_mel_token
 
 	def _mark(self, name, *extra):
