@@ -201,6 +201,43 @@ def test_bench_phase_roofline_counts_the_work_of_the_configuration_it_is_given()
 	assert abs(two["ddim"]["frac"] - one["ddim"]["frac"]) < 1e-12 and two["ar_decode"]["algorithmic_bytes"] == 2 * one["ar_decode"]["algorithmic_bytes"]
 
 
+def test_bench_effective_floor_follows_its_stated_formula():
+	"""`roofline.phases.*.effective_floor_ms` = sum over dependent launches of [boundary + max(hbm bytes / 6.4 TB/s, bytes per CU / 68 GB/s, flop / peak)]
+	from the guide's constants; reported next to the spec-peak fractions.  The launch lists and a few hand-computed terms are pinned here."""
+	import bench
+	assert (bench.BOUNDARY_US, bench.HBM_STREAM, bench.CU_L2_INTAKE) == (1.45, 6.4e12, 68e9)
+	e = bench.effective_floor("bf16")
+	assert e["launches"] == {"decode_token": 152, "ddim_step": 124}
+	# one decode token at context c: 152 boundaries + (block weights + head + KV cache of 16 candidates + logits) / 6.4 TB/s
+	P1 = 68
+	want = 0.0
+	for k in range(1, 250):
+		hbm = 377_886_720 * 2 + (8_398_850 + 4_096) * 2 + 16 * 30 * 2 * (P1 + k) * 1024 * 2 + 16 * 8194 * 4
+		want += 152 * 1.45 + hbm / 6.4e12 * 1e6
+	assert want * 1e-3 + 0.5 < e["ar_decode_ms"] < want * 1e-3 + 1.5                     # + the prefill's dense pass over 68 rows
+	# the 1x1 conv of a DDIM step: 2176 x 1024 x 1024 -> 272 tiles of 128 x 64, 1.0625 rounds x 192 rows x 1024 x 2 B per CU at 68 GB/s
+	g = bench._gemm_floor_us(2176, 1024, 1024, 1, 2, 2.5e15)
+	assert abs(g - (272 / 256) * 192 * 1024 * 2 / 68e9 * 1e6) < 1e-9 and 6.0 < g < 6.3
+	assert abs(bench._gemm_floor_us(2176, 1024, 1024, 3, 2, 2.5e15) - 3 * g) < 1e-9       # the k = 3 conv stages three taps
+	q = bench._gemm_floor_us(2176, 3072, 1024, 1, 2, 2.5e15)                              # QKV: 408 tiles of 128 x 128 -> 216 of 256 x 128, one round
+	assert abs(q - 384 * 1024 * 2 / 68e9 * 1e6) < 1e-9
+	assert 880 < e["ddim_step_us"] < 950 and abs(e["ddim_ms"] - (80 * e["ddim_step_us"]) * 1e-3) < 0.2
+	f8 = bench.effective_floor("fp8")
+	assert f8["ddim_ms"] < e["ddim_ms"] and f8["ar_decode_ms"] < e["ar_decode_ms"] and f8["latent_pass_ms"] == e["latent_pass_ms"]
+	big = bench.effective_floor("bf16", 256, 32, 500, 200, 2, 1)
+	assert big["ar_decode_ms"] > 4 * e["ar_decode_ms"] and big["ddim_ms"] > 4 * e["ddim_ms"]
+	# and the phases carry it next to the spec-peak fraction
+	class Ev:
+		def __init__(self, t): self.t = t
+		def elapsed_time(self, o): return o.t - self.t
+	marks = [("start", Ev(0.0)), ("ar_decode", Ev(168.0)), ("latent_pass", Ev(176.0)), ("ddim", Ev(302.0))]
+	ph = bench.phase_roofline([marks], "bf16")
+	for k in ("ar_decode", "latent_pass", "ddim"):
+		assert 0 < ph[k]["frac"] < ph[k]["frac_of_effective_floor"] < 1 and ph[k]["effective_floor_ms"] > ph[k]["floor_ms"]
+	assert abs(ph["whole_step_effective_floor_ms"] - (e["ar_decode_ms"] + e["latent_pass_ms"] + e["ddim_ms"])) < 1e-9
+	assert ph["effective_floor"]["constants"]["boundary_us"] == 1.45 and "formula" in ph["effective_floor"]
+
+
 def test_bench_phase_roofline_on_a_rank_that_diffused_nothing_or_one_of_two_lines():
 	"""at N > 1 only the rank a line's diffusion is assigned to has a "ddim" interval for it; the other ranks' marks end with the
 	latent pass.  phase_roofline must report that instead of raising KeyError (rank >= 1 of `bench.py --shard candidates` crashed there), and count
