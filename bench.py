@@ -258,6 +258,7 @@ def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL
 		attn = 2.0 * 2 * rows_per_seq * rows_per_seq * d * seqs / peak * 1e6 / 2      # causal: half the score matrix
 		ln = 2 * (M * d * (4 + e) / 256 / CU_L2_INTAKE) * 1e6
 		return 30 * (7 * BOUNDARY_US + g + attn + ln) + 4 * BOUNDARY_US
+	tok_us = ar_us / max(n_mel - 1, 1)
 	ar_us += dense_pass_us(P1, 1)                                     # the prefill runs the shared prefix once
 	lat_us = dense_pass_us(n_text + n_mel + 5, n_cand)
 	# DDIM step on the batch of 2 sequences (cond + cond-free) of T frames
@@ -275,7 +276,7 @@ def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL
 	return {"constants": {"boundary_us": BOUNDARY_US, "hbm_stream_Bps": HBM_STREAM, "cu_l2_intake_Bps": CU_L2_INTAKE},
 			"launches": {"decode_token": tok_launches, "ddim_step": step_launches},
 			"ar_decode_ms": lines * ar_us * 1e-3, "latent_pass_ms": lines * lat_us * 1e-3, "ddim_ms": lines_ddim * (n_ddim * step_us + pre_us) * 1e-3,
-			"ddim_step_us": step_us, "decode_token_us_at_mean_ctx": ar_us / max(n_mel - 1, 1)}
+			"ddim_step_us": step_us, "decode_token_us_at_mean_ctx": tok_us}
 
 
 def log(msg):
