@@ -213,7 +213,8 @@ def rank_file(rank):
 #     effective_floor = sum over the phase's dependent launches of [ BOUNDARY_US + max( hbm_bytes / HBM_STREAM , bytes_per_CU / CU_L2_INTAKE , flop / peak ) ]
 #   BOUNDARY_US   1.45   "boundary": dependent kernel boundary on one stream, eager = graph
 #   HBM_STREAM    6.4e12 "ldsdma-fill": what the chip streams from HBM with every CU loading (default policy; 8.0e12 is the spec figure the `frac` fields use)
-#   CU_L2_INTAKE  68e9   "ring-gemm": the median CU takes in 68 GB/s through LDS-DMA; a GEMM tile of BM x BN over K (x taps) stages (BM + BN) * K * taps * sizeof(T) bytes
+#   CU_L2_INTAKE  68e9   "ring-gemm": the median CU takes in 68 GB/s through LDS-DMA (for csrc/gemm.hip it is the rate its trip chain runs at per staged byte rather than a bandwidth
+#                        limit -- DESIGN.md section 5's traffic ablation -- i.e. this term prices a k-loop trip); a GEMM tile of BM x BN over K (x taps) stages (BM + BN) * K * taps * sizeof(T) bytes
 #                        per CU and launch-round (rounds = max(1, tiles / 256)); tile shapes as csrc/gemm.hip picks them (`pick_tile`)
 # Launch lists (include/ttk.h entry points -> csrc/ar.hip, csrc/diff.hip): a decode token = 30 x (ln_1+c_attn, attention, c_proj, ln_2+c_fc, mlp.c_proj) + mel_head + sampler
 # = 152 launches over 805 MB of weights + the KV cache; the dense passes (prefill, latent pass) = 30 x (2 LayerNorm + 4 GEMM + attention) + 4; a DDIM step on the cond +

@@ -344,6 +344,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 		for (int i = 0; i < A_PC; ++i) {
 #ifdef TTK_DIAG_SKIP
 			if ((TTK_DIAG_SKIP & 1) && (seg_i > 0 || kk_i > 1)) continue;   // diagnostic: stale A tiles
+			if ((TTK_DIAG_SKIP & 16) && seg_i > 0) continue;                // diagnostic: the traffic of a k = 3 conv whose taps share ONE staged activation image (A fetched for tap 0 only; results wrong on purpose)
 #endif
 			glds16(va[i], srdA, soffA, As + (wave + NW * i) * 1024);
 		}
