@@ -426,8 +426,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	};
 	auto step = [&](int kt, const Frags& cur, Frags& nxt) {
 		wait_tiles(min(NSTAGE - 2, NTILES - 2 - kt));          // tile kt+1 has landed; up to NSTAGE-2 younger ones stay in flight
+#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 32))         // diagnostic 32: what the drain of this wave's fragment reads in front of the barrier costs (only meaningful with 3: no DMA overwrites anything)
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 64))         // diagnostic 64: no workgroup barrier in the k-loop (with 3)
 		__builtin_amdgcn_s_barrier();
+#endif
 		asm volatile("" ::: "memory");
 #ifdef TTK_DIAG_SKIP
 		if ((TTK_DIAG_SKIP & 4) && kt > 0) { if (kt + NSTAGE < NTILES) issue(kt % NSTAGE); mfma_tile(cur); return; }   // diagnostic: no LDS fragment reads (stale registers)
@@ -464,7 +468,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 		static_assert(!PRE_RES || (NT % 2 == 0 && NT >= 8), "the peeled tail assumes an even tile count");
 		auto tail_step = [&](auto wtag, int stage_next, const Frags& cur, Frags& nxt) {
 			wait_vmcnt<decltype(wtag)::value>();
+#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 32))
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 			__builtin_amdgcn_s_barrier();
 			asm volatile("" ::: "memory");
 			read_frags(nxt, stage_next);
