@@ -61,6 +61,9 @@ int main(int argc, char** argv) {
 	CK(hipMemset(x, 0, B * d * 4)); CK(hipMemset(qbuf, 0, B * d * 4)); CK(hipMemset(bias, 0, 4 * d * 4));
 	CK(hipMemset(xfrag, 0, B * d * 2)); CK(hipMemset(ao, 0, B * d * 2)); CK(hipMemset(hb, 0, B * 4 * d * 2));
 	const int hp[2] = {ctx, 68};
+	int pos_slot = -1;
+	if (getenv("AC_POS_LINE") && atoi(getenv("AC_POS_LINE"))) { int* w = nullptr; pos_slot = attn_pos_slot_acquire(&w); if (pos_slot >= 0) dpos = w; }      // round 5: the position words in the attention's link-time line
+	printf("position words: %s\n", pos_slot >= 0 ? "in the position line (AC_POS_LINE=1)" : "behind the d_pos pointer");
 	CK(hipMemcpy(dpos, hp, 8, hipMemcpyHostToDevice));
 	hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 
@@ -74,7 +77,7 @@ int main(int argc, char** argv) {
 		gq.M = B; gq.N = 3 * d; gq.K = d; gq.max_ctx = max_ctx; gq.H = H; gq.q_scale = 0.125f; gq.stamps = p.stamps;
 		if (!(lean && launch_gemv(DT_BF16, GV_QKV, gq, s))) launch_skinny(DT_BF16, p, wv_qkv, s);
 		AttnDecodeParams a = {};
-		a.qbuf = qbuf; a.kcache = L[i].kc; a.vcache = L[i].vc; a.d_pos = dpos; a.B = B; a.H = H; a.max_ctx = max_ctx; a.ctx_hint = ctx; a.out = ao; a.out_frag = 1; a.shared_rows = 1;
+		a.qbuf = qbuf; a.kcache = L[i].kc; a.vcache = L[i].vc; a.d_pos = dpos; a.pos_slot_p1 = pos_slot + 1; a.B = B; a.H = H; a.max_ctx = max_ctx; a.ctx_hint = ctx; a.out = ao; a.out_frag = 1; a.shared_rows = 1;
 		a.stamps = st ? st + 1 * SLOTS : nullptr;
 		launch_attn_decode(DT_BF16, a, s);
 		p = {}; p.Wp = L[i].wproj; p.N = d; p.K = d; p.M = B; p.bias = bias; p.a = ao; p.lda = d; p.a_frag = 1;

@@ -143,3 +143,25 @@ def test_captured_token_step_replayed_after_its_calls_temporaries_are_gone(monke
 		_poison_freed_device_memory()
 	st = [s for s in keep._states.values()]
 	assert any(s.graph is not None for s in st) and any(s.stream_graph is not None for s in st)      # the replayed steps really were captured ones
+
+
+def test_more_decode_handles_than_position_line_slots():
+	"""round 5: the decode attention reads {cache length, shared-prefix length} of up to 8 handles from ONE 64-byte line at a link-time address (csrc/attn.hip: the request
+	leaves beside the kernel-argument loads instead of behind them); a ninth handle keeps the words in its own allocation and its launches take the pointer form.  Ten live
+	handles on the same weights: every one gives the same ids (free-running, graph replay included), a slot is handed back when a handle goes and reused by the next one."""
+	from tortoise_tts_amd.autoregressive import UnifiedVoice
+	cfg = W.AR_SMALL
+	sd = W.synth_state_dict(W.ar_shapes(cfg), 11)
+	text = torch.randint(1, 255, (1, 9), generator=torch.Generator().manual_seed(1)).to(DEV)
+	cond = torch.randn(1, cfg.model_dim, generator=torch.Generator().manual_seed(2)).to(DEV)
+	kw = dict(do_sample=True, num_return_sequences=3, max_generate_length=20, temperature=0.8, top_k=0)
+	models = [UnifiedVoice(sd, cfg, dtype="f32", device=DEV, max_batch=4, max_ctx=96) for _ in range(10)]
+	want = models[0].inference_speech(cond, text, **kw)
+	for i in (3, 7, 8, 9, 0):                       # slots 3, 7; the two handles beyond the line; the first again (its captured step replayed)
+		got = models[i].inference_speech(cond, text, **kw)
+		assert torch.equal(got, want), i
+	del models[2], models[5]
+	torch.cuda.synchronize()
+	fresh = [UnifiedVoice(sd, cfg, dtype="f32", device=DEV, max_batch=4, max_ctx=96) for _ in range(3)]      # two take the freed slots, the third has none
+	for m in fresh + [models[-1]]:
+		assert torch.equal(m.inference_speech(cond, text, **kw), want)

@@ -88,7 +88,8 @@ struct ttk_ar {
 	float *text_emb, *mel_emb, *mel_pos, *text_pos;
 	void *kc, *vc;          // [layers][max_batch][H][max_ctx][64]
 	size_t kv_layer_stride; // elements
-	int* d_pos;             // device: [0] valid cache rows, [1] rows of the shared prefix; then, 8-byte aligned, row_info[max_batch]
+	int* d_pos;             // device: [0] valid cache rows, [1] rows of the shared prefix -- in the attention's position line when pos_slot >= 0, else at the start of the block that holds row_info
+	int pos_slot = -1;
 	int2* d_rowinfo;        // per candidate {first cache row, first candidate of its line}: line batches (ttk_ar_prefill_lines), prefixes right-aligned
 	int lines_mode = 0;     // the current generation was started by ttk_ar_prefill_lines: the attention launches read d_rowinfo
 	float *x, *qbuf;        // decode residual stream / scaled queries [max_batch][d]
@@ -222,7 +223,7 @@ static void decode_rows(ttk_ar* h, int r0, int nrows, int gi, float* logits_out,
 		gq.M = nrows; gq.N = 3 * d; gq.K = d; gq.max_ctx = c.max_ctx; gq.H = H; gq.q_scale = 0.125f; gq.health = h->d_health;
 		if (!(lean && fold_qkv && launch_gemv(dt, GV_QKV, gq, s))) launch_skinny(dt, p, fold_qkv ? wv_small : wv_prologue, s);
 		AttnDecodeParams a = {};
-		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 && h->share_prefix && h->nsplit == 1;
+		a.qbuf = qbuf; a.kcache = kc; a.vcache = vc; a.d_pos = h->d_pos; a.pos_slot_p1 = h->pos_slot + 1; a.B = nrows; a.H = H; a.max_ctx = c.max_ctx; a.ctx_hint = h->P + 2 + h->k; a.out = attn_out; a.out_frag = h->hfrag && r0 == 0 && nrows == h->B; a.shared_rows = r0 == 0 && h->share_prefix && h->nsplit == 1;
 		a.row_info = h->lines_mode && r0 == 0 ? h->d_rowinfo : nullptr;
 		launch_attn_decode(dt, a, s);
 		p = {};
@@ -296,7 +297,7 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	WeightMap wm(w, n_w);
 	const int d = cfg->model_dim;
 	int rc = TTK_OK;
-	auto fail = [&](int code) { h->arena.release(); delete h; return code; };
+	auto fail = [&](int code) { attn_pos_slot_release(h->pos_slot); h->arena.release(); delete h; return code; };
 #define AR_TRY(expr) do { rc = (expr); if (rc != TTK_OK) return fail(rc); } while (0)
 	h->L.resize(cfg->layers);
 	for (int l = 0; l < cfg->layers; ++l) {
@@ -331,6 +332,14 @@ int ttk_ar_create(ttk_ar** out, const ttk_ar_config* cfg, const ttk_weight_view*
 	h->d_rowinfo = (int2*)(h->d_pos + 4);
 	h->d_health = h->d_pos + 2;      // (words 2, 3 of the block are otherwise unused; zeroed with it below)
 	if (hipMemset(h->d_pos, 0, (size_t)(4 + 2 * cfg->max_batch) * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
+	{   // the two position words move into the decode attention's position line when a slot is free (csrc/attn.hip); row_info and the health word stay in the block above
+		int* words = nullptr;
+		h->pos_slot = attn_pos_slot_acquire(&words);
+		if (h->pos_slot >= 0) {
+			h->d_pos = words;
+			if (hipMemset(h->d_pos, 0, 2 * sizeof(int)) != hipSuccess) return fail(TTK_E_HIP);
+		}
+	}
 	AR_TRY(h->arena.alloc((void**)&h->d_ring, sizeof(int64_t)));
 	if (hipMemset(h->d_ring, 0, sizeof(int64_t)) != hipSuccess) return fail(TTK_E_HIP);
 	AR_TRY(h->arena.alloc((void**)&h->x, (size_t)cfg->max_batch * d * sizeof(float)));
@@ -399,6 +408,7 @@ int ttk_ar_destroy(ttk_ar* h) {
 	for (int i = 0; i < 3; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
 	if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
 	h->ws_x.release(); h->ws_a.release(); h->ws_qkv.release(); h->ws_ao.release(); h->ws_h.release();
+	attn_pos_slot_release(h->pos_slot);
 	h->arena.release();
 	delete h;
 	return TTK_OK;

@@ -16,6 +16,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <mutex>
 #include "ttk_common.h"
 #include "ttk_kernels.h"
 
@@ -427,10 +428,33 @@ __device__ __forceinline__ int64_t decode_out_index(const AttnDecodeParams& p, i
 #define TTK_ASTAMPD(i, dep) do {} while (0)
 #endif
 
-template <typename T, int NW, int UN, bool ROWS = false>
+// The position line (round 5).  Every K / V address of the decode attention depends on the cache length, which lives in device memory (one captured step serves every
+// token), behind a pointer that arrives with the kernel arguments: two DEPENDENT round trips -- arguments, then position -- before the first key is asked for (1.52 us from a
+// wave's first instruction to its requests, profiles/r04_ar_chain.log; the GEMV launches, with one round trip, need 0.68).  The words of up to 8 handles therefore sit in ONE
+// 64-byte line of this code object: its address is known at link time, so lane i asks for word i of the line with the wave's first instructions, beside the argument loads, and the
+// slot index (an argument) only selects the lane to read when both have arrived.  Writers (prefill, the head launch's bump) reach the words through the ordinary pointer.
+__device__ __attribute__((aligned(64))) int g_pos_line[16];
+static unsigned g_pos_slots_used = 0;
+static std::mutex g_pos_slots_mutex;
+int attn_pos_slot_acquire(int** words_out) {
+	std::lock_guard<std::mutex> lock(g_pos_slots_mutex);
+	void* base = nullptr;
+	if (hipGetSymbolAddress(&base, HIP_SYMBOL(g_pos_line)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+	for (int s = 0; s < 8; ++s)
+		if (!(g_pos_slots_used & (1u << s))) { g_pos_slots_used |= 1u << s; *words_out = (int*)base + 2 * s; return s; }
+	return -1;
+}
+void attn_pos_slot_release(int slot) {
+	std::lock_guard<std::mutex> lock(g_pos_slots_mutex);
+	if (slot >= 0 && slot < 8) g_pos_slots_used &= ~(1u << slot);
+}
+
+template <typename T, int NW, int UN, bool ROWS = false, bool SLOT = false>
 __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	typedef typename Frag<T>::type FragT;
 	constexpr int NP = NW * 8;           // (wave, slot) partial softmaxes
+	int line_word = 0;
+	if (SLOT) line_word = __builtin_nontemporal_load(g_pos_line + (threadIdx.x & 15));      // (link-time address: nothing to wait for)
 	TTK_PIN_ARGS(TTK_S(p.qbuf), TTK_S(p.kcache), TTK_S(p.vcache), TTK_S(p.d_pos), TTK_S(p.H), TTK_S(p.max_ctx), TTK_S(p.out), TTK_S(p.out_frag),
 				 TTK_S(p.row_info), TTK_S(p.shared_rows));
 	const int h = blockIdx.x, b = blockIdx.y;
@@ -448,7 +472,9 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 	// loads -- position, wait, prefix length, wait -- in front of every K / V address: 1.76 us from a wave's first instruction to its requests
 	// (profiles/r03_ar_chain_lean.log).  Both words sit in device memory, not in the kernel arguments: a captured token step is replayed for later
 	// calls with other prefix lengths.
-	const int2 dp = *(const int2*)p.d_pos;
+	int2 dp;
+	if (SLOT) { const int w = 2 * (p.pos_slot_p1 - 1); dp.x = __builtin_amdgcn_readlane(line_word, w); dp.y = __builtin_amdgcn_readlane(line_word, w + 1); }
+	else dp = *(const int2*)p.d_pos;
 	const int n = min(dp.x + 1, p.max_ctx) - start;
 	// rows [0, shared) are read from the line's first candidate
 	const int sh0 = p.shared_rows ? dp.y : 0;
@@ -549,7 +575,11 @@ __global__ __launch_bounds__(64 * NW) void k_attn_decode(AttnDecodeParams p) {
 
 template <typename T, int NW, int UN>
 static void launch_attn_decode_t(const AttnDecodeParams& p, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-	if (p.row_info) hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN, true>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
+	static const bool no_line = [] { const char* e = getenv("TTK_ATTN_POS_LINE"); return e && atoi(e) == 0; }();      // A/B knob: 0 = always through d_pos
+	const bool slot = p.pos_slot_p1 > 0 && !no_line;
+	if (p.row_info) { if (slot) hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN, true, true>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
+					  else hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN, true>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p); }
+	else if (slot) hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN, false, true>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
 	else hipExtLaunchKernelGGL((k_attn_decode<T, NW, UN>), dim3(p.H, p.B), dim3(64 * NW), 0, s, ea, eb, 0, p);
 }
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s) {

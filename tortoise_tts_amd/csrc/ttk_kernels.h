@@ -219,6 +219,8 @@ struct AttnDecodeParams {
 	const int2* row_info;     // null, or [B] {start, first}: several text lines decoded as one batch (ttk_ar_prefill_lines).  The lines' prefixes are
 	                          // right-aligned: candidate b's cache begins at row `start` (its line is that much shorter than the longest), and `first`
 	                          // = first candidate of its line, the owner of its shared prefix rows.  Selects the kernel variant that reads it.
+	int pos_slot_p1;          // 0: the two position words are read through d_pos.  s + 1: d_pos points at slot s of the position line (attn_pos_slot_acquire), a 64-byte
+	                          // line at a LINK-TIME address that the kernel requests before its arguments have arrived (one round trip instead of two in front of the keys)
 	int shared_rows;          // != 0: cache rows [0, d_pos[1]) are identical for every candidate (one conditioning latent + one text line: the
 	                          // prefill computed the same prefix B times): read them from candidate 0's slice, which the 16 workgroups of a head
 	                          // -- equal blockIdx.x, so one XCD -- then share in L2 instead of fetching B copies from HBM
@@ -227,6 +229,10 @@ struct AttnDecodeParams {
 #endif
 };
 void launch_attn_decode(int dt, const AttnDecodeParams& p, hipStream_t s);
+// the position line (csrc/attn.hip): up to 8 decode handles keep {valid cache rows, shared-prefix rows} in one 64-byte line of the code object.  acquire returns the slot
+// (and the device address of its two words), or -1 when all are taken -- the handle then keeps the words in its own allocation and the kernel reads them through d_pos
+int attn_pos_slot_acquire(int** words_out);
+void attn_pos_slot_release(int slot);
 
 // copy k/v of a dense qkv buffer [B*S][3d] (GPT-2 order q|k|v, head h at h*64) into the cache rows [0,S)
 void launch_kv_scatter(int dt, const void* qkv, int B, int S, int H, void* kcache, void* vcache, int max_ctx, hipStream_t s, int t0 = 0);
