@@ -196,10 +196,21 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 
 	load_kv(0);
 	for (int kt = 0; kt < nkt; ++kt) {
+		// (TTK_DIAG_ATTN, diagnostic builds of tests/diag/ddim_chain.cpp only, results wrong on purpose: 1 = no workgroup barriers in the key loop, 2 = K / V staged once and
+		// never again: profiles/r05_ddim_chain_attn_ablation.log)
+#if !(defined(TTK_DIAG_ATTN) && (TTK_DIAG_ATTN & 1))
 		__syncthreads();            // previous tile's readers are done
+#endif
+#if defined(TTK_DIAG_ATTN) && (TTK_DIAG_ATTN & 2)
+		if (kt == 0)
+#endif
 		store_kv();
+#if !(defined(TTK_DIAG_ATTN) && (TTK_DIAG_ATTN & 1))
 		__syncthreads();
+#endif
+#if !(defined(TTK_DIAG_ATTN) && (TTK_DIAG_ATTN & 2))
 		load_kv(kt + 1 < nkt ? kt + 1 : kt);   // unconditional (the last tile is re-read): keeps the staging registers out of scratch
+#endif
 
 		const int k0 = kt * 64;
 		const bool wave_active = (!CAUSAL || k0 <= q0 + QW - 1) && (!BAL || wave < cnt);
