@@ -4,7 +4,8 @@
 // captured graph: (a) microseconds per layer, and (b) in-kernel timestamps of EVERY wave of the eight kernels of one layer in the middle of the
 // chain: kernel boundaries, start spread, and the phases inside (GEMM: first requests issued, first tile landed, k-loop, epilogue, stores acknowledged).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTTK_STAMPS=2 -I tortoise_tts_amd/csrc tests/diag/ddim_chain.cpp -o tests/diag/ddim_chain.bin
-//   tests/diag/ddim_chain.bin [replays=10]          env: DC_LAYERS (20), DC_T (1088), DC_NB (2), DC_PF (1: GroupNorm-apply / attention touch the next GEMM's weights)
+//   tests/diag/ddim_chain.bin [replays=10]          env: DC_LAYERS (20), DC_T (1088), DC_NB (2), DC_PF (1: GroupNorm-apply / attention touch the next GEMM's weights), DC_RANDOM (0; 1 = hashed operands instead of zeros)
+//   -DTTK_CLOCK_STAMPS (with -DTTK_STAMPS=2): s_memtime / s_memrealtime around the GEMMs' k-loop and the attention's key loop -> in-kernel clock per kernel (round 6)
 //   DC_SIDE=k   (round 5) the timed loop runs TWO streams: step j+1's conditioning_timestep_integrator (3 of these layers, own weights and
 //               activations) beside the 13 layers of step j's body (csrc/diff.hip).  With DC_SIDE=k a second stream replays k layers (own buffers, own weights) with
 //               every replay of the main chain, so the stamps and the per-layer time are taken under the contention the bench has (k = 5 beside 20 main layers ~ 3 : 13).
@@ -32,6 +33,20 @@ using namespace ttk;
 #endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e), __LINE__); return 1; } } while (0)
 static int envi(const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; }
+// DC_RANDOM=1: operands from a hash instead of zeros (the clock a chip holds under load depends on the data: MI355X_MICROARCH.md, DVFS give-back items 1 and 7)
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, float scale) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+	const float v = ((int)(h & 0xffff) - 32768) * (scale / 32768.f);
+	p[i] = (unsigned short)(__float_as_uint(v) >> 16);
+}
+__global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
+	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+	p[i] = ((int)(h & 0xffff) - 32768) * (scale / 32768.f);
+}
 
 constexpr int MAXWG = 1200;
 constexpr size_t SLOTS = (size_t)MAXWG * 16 * 8;
@@ -74,6 +89,17 @@ int main(int argc, char** argv) {
 		std::vector<float> h((size_t)nb * 32 * nch * 3);
 		for (size_t i = 0; i < h.size(); i += 3) { h[i] = 2048.f; h[i + 1] = 0.f; h[i + 2] = 2048.f; }
 		CK(hipMemcpy(B.ms, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+	}
+	const int RANDOM = envi("DC_RANDOM", 0);
+	if (RANDOM) {      // weights ~ U(-0.03, 0.03) (1 / sqrt(1024)), residual stream ~ U(-1, 1), GroupNorm gamma = 1: activations of order one through every layer
+		auto fb = [&](void* q, size_t n, unsigned seed, float sc) { fill_bf16<<<(unsigned)((n + 255) / 256), 256>>>((unsigned short*)q, n, seed, sc); };
+		auto ff = [&](float* q, size_t n, unsigned seed, float sc) { fill_f32<<<(unsigned)((n + 255) / 256), 256>>>(q, n, seed, sc); };
+		for (int i = 0; i < NL; ++i) { fb(L[i].w1, (size_t)C * C, 11 + i, 0.03f); fb(L[i].w3, (size_t)3 * C * C, 211 + i, 0.03f); fb(L[i].wqkv, (size_t)3 * C * C, 411 + i, 0.03f); fb(L[i].wproj, (size_t)C * C, 611 + i, 0.03f); }
+		for (int i = 0; i < NSIDE; ++i) { fb(LS[i].w1, (size_t)C * C, 1011 + i, 0.03f); fb(LS[i].w3, (size_t)3 * C * C, 1211 + i, 0.03f); fb(LS[i].wqkv, (size_t)3 * C * C, 1411 + i, 0.03f); fb(LS[i].wproj, (size_t)C * C, 1611 + i, 0.03f); }
+		for (int b = 0; b < (NSIDE ? 2 : 1); ++b) { ff(BF[b].x, (size_t)M * C, 5 + b, 1.f); ff(BF[b].hf, (size_t)M * C, 7 + b, 1.f); fb(BF[b].a, (size_t)M * C, 9 + b, 1.f); fb(BF[b].qkv, (size_t)M * 3 * C, 13 + b, 1.f); fb(BF[b].ao, (size_t)M * C, 15 + b, 1.f); }
+		std::vector<float> one(C, 1.f); CK(hipMemcpy(gam, one.data(), C * 4, hipMemcpyHostToDevice));
+		ff(relb, (size_t)H * 129, 3, 0.5f);
+		CK(hipDeviceSynchronize());
 	}
 	hipStream_t s, s2; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
 	hipStream_t cur = s; Bufs* CB = &BF[0];      // the lane the helpers below enqueue into
@@ -163,6 +189,7 @@ int main(int argc, char** argv) {
 	const bool is_gemm[8] = {false, true, false, true, false, true, false, true};
 	std::vector<unsigned long long> hs(8 * SLOTS);
 	std::vector<double> stat[8][10];
+	std::vector<double> clk[8], kcyc[8];      // -DTTK_CLOCK_STAMPS: per wave, shader cycles / 100 MHz ticks of the k-loop (slot 6)
 	for (int rep = 0; rep < 9; ++rep) {
 		CK(hipMemsetAsync(stamps, 0, 8 * SLOTS * 8, s));
 		CK(launch_main(ge)); CK(launch_main(ges)); CK(launch_main(ge));
@@ -192,6 +219,7 @@ int main(int argc, char** argv) {
 					const unsigned long long* p = st + ((size_t)w * 16 + v) * 8;
 					if (!p[0]) continue;
 					starts.push_back((double)p[0] - t0);
+					if (p[6] && (p[6] & 0xffffffffull)) { clk[k].push_back((double)(p[6] >> 32) / (double)(p[6] & 0xffffffffull) * 0.1); kcyc[k].push_back((double)(p[6] >> 32)); }
 					if (is_gemm[k]) {
 						if (p[1]) ph[0].push_back((double)p[1] - p[0]);
 						if (p[1] && p[2]) ph[1].push_back((double)p[2] - p[1]);
@@ -227,5 +255,7 @@ int main(int argc, char** argv) {
 		sum += med(stat[k][0]) + med(stat[k][9]);
 	}
 	printf("sum of boundaries + spans of the stamped layer: %.2f us\n", sum);
+	for (int k = 0; k < 8; ++k)
+		if (!clk[k].empty()) printf("in-kernel clock, %-18s: %.3f GHz median over %zu wave stamps (p10 %.3f, p90 %.3f); main loop %.0f shader cycles median\n", names[k], q(clk[k], 0.5), clk[k].size(), q(clk[k], 0.1), q(clk[k], 0.9), q(kcyc[k], 0.5));
 	return 0;
 }

@@ -195,6 +195,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	};
 
 	load_kv(0);
+#ifdef TTK_CLOCK_STAMPS
+	const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
 	for (int kt = 0; kt < nkt; ++kt) {
 		// (TTK_DIAG_ATTN, diagnostic builds of tests/diag/ddim_chain.cpp only, results wrong on purpose: 1 = no workgroup barriers in the key loop, 2 = K / V staged once and
 		// never again: profiles/r05_ddim_chain_attn_ablation.log)
@@ -339,6 +342,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 		}
 	}
 
+#ifdef TTK_CLOCK_STAMPS
+	if (p.stamps && lane == 0) {      // shader cycles and 100 MHz ticks of this wave's key loop (diagnostic build: MI355X_MICROARCH.md, DVFS give-back item 6)
+		unsigned long long* st_ = p.stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8;
+		st_[6] = ((__builtin_amdgcn_s_memtime() - clk0_) << 32) | ((__builtin_amdgcn_s_memrealtime() - rt0_) & 0xffffffffull);
+	}
+#endif
 	// ---- normalise and store: lane holds d = 16dt + 4g + r of query column li
 #pragma unroll
 	for (int qt = 0; qt < QT; ++qt) {

@@ -41,6 +41,60 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ------------------------------------------------------------------------------------------------ hand-ordered k-loop (16-bit operands, 3-stage ring)
+// What the compiler made of the C++ ping-pong (profiles/r06_gemm_kloop_isa_*_before.txt): `cur` and `nxt` in the SAME registers, the next tile's 12 ds_read_b128
+// sunk behind MFMA 9-16 and drained by lgkmcnt(0) in front of every barrier, all six DMA issues in front of MFMA 1 -- the measured "sum, not maximum" (VERDICT r05
+// weak #3).  Here the fragment reads, the DMA pieces and the waits are `asm volatile` statements (invisible to the waitcnt pass, like glds16), the MFMAs stay
+// builtins (the compiler knows the matrix pipe's write-back hazards: an all-asm first version let it copy accumulators between two loop bodies with no wait
+// states -- 5e-2 errors), and a full scheduling fence (`sched_barrier(0)`) behind every statement pins the order written below: the source order IS the
+// instruction stream.  The compiler still allocates the registers (two real fragment sets).  What stays ours: a read's data is used only behind the
+// `s_waitcnt lgkmcnt(0)` that ends the step it was issued in (any copy the register allocator might add at a loop edge lands behind that wait too); M0 is
+// written by the DMA statements only (saved in front of the loop, restored behind it; the compiler has no M0 use of its own in this kernel).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#define TTK_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int OFF> __device__ __forceinline__ void pipe_read16(u32x4& d, unsigned addr) {
+	static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+	asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+	TTK_FENCE();
+}
+template <typename T> __device__ __forceinline__ void pipe_mfma(f32x4& c, const u32x4& a, const u32x4& b) {
+	union U { u32x4 q; typename Frag<T>::type v; __device__ U() {} } ua, ub;
+	ua.q = a; ub.q = b;
+	c = mma16<T>(ua.v, ub.v, c);
+	TTK_FENCE();
+}
+__device__ __forceinline__ void pipe_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TTK_FENCE(); }
+__device__ __forceinline__ void pipe_glds16(unsigned voff, __amdgpu_buffer_rsrc_t srd, unsigned soff, unsigned lds_dst /* wave-uniform */) {
+	asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_dst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+	TTK_FENCE();
+}
+__device__ __forceinline__ unsigned pipe_m0_save() { unsigned k; asm volatile("s_mov_b32 %0, m0" : "=s"(k)); TTK_FENCE(); return k; }
+__device__ __forceinline__ void pipe_m0_restore(unsigned k) { asm volatile("s_mov_b32 m0, %0" :: "s"(k)); TTK_FENCE(); }
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+	if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// placement knobs of the hand-ordered k-step (tuning builds: -DTTK_PIPE_...=n); gaps are counted in MFMAs of the step, 0 = behind the first one
+#ifndef TTK_GEMM_PIPE
+#define TTK_GEMM_PIPE 1
+#endif
+#ifndef TTK_PIPE_RPG
+#define TTK_PIPE_RPG 2      // fragment reads per MFMA gap
+#endif
+#ifndef TTK_PIPE_PREB
+#define TTK_PIPE_PREB 0     // MFMAs issued in front of the step's barrier (reads start behind it)
+#endif
+#ifndef TTK_PIPE_DPG
+#define TTK_PIPE_DPG 1      // DMA pieces per MFMA gap
+#endif
+#ifndef TTK_PIPE_DLATE
+#define TTK_PIPE_DLATE 0    // 1: the DMA pieces fill the LAST gaps of the step; 0: they start TTK_PIPE_D0 gaps behind the barrier (or as late as still fits)
+#endif
+#ifndef TTK_PIPE_D0
+#define TTK_PIPE_D0 6
+#endif
+// (profiles/r06_chain_pipe_knobs.log, per layer of the replayed chain on hashed operands: 1 read per gap + pieces last 113.1 us; pieces first 113.9; 2 reads per gap 111.1;
+//  2 reads per gap + pieces from gap 6 111.6 with the shortest launch spans; 2 MFMAs in front of the barrier 112.8; 2 pieces per gap 114.2 -- the compiler-ordered loop 117.3)
+
 // Fused GroupNorm32 statistics of a wave's 64-row block (the values just written: the next op on this tensor is always a GroupNorm): NI/2 whole groups of 32
 // channels; exact two-pass (mean, then centred squares) in registers, two DPP wave reductions per group, one (count, mean, M2) triple per (batch, group,
 // 64-row chunk) for k_gn_apply to merge.  ONE function for the generic and the role epilogues, with the contraction written out (the squares accumulate
@@ -364,58 +418,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #pragma unroll
 		for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-	// Fragment registers of one k-tile (all k-steps), two sets used ping-pong: the ds_reads of tile k+1 are in flight under the
-	// MFMAs of tile k (with one wave per SIMD nothing else hides the ~130-cycle LDS latency; measured 735 cycles per k-tile for
-	// 256 cycles of MFMA before this).  Named structs + a 2x unrolled loop: an indexed array of register sets would go to scratch.
-	struct Frags { uint4 a[KSTEPS][MI][FCH]; uint4 b[KSTEPS][NI][FCH]; };
-	auto read_frags = [&](Frags& fr, int stage) {
-		const char* As = smem + stage * STAGE;
-		const char* Bs = As + BM * 128;
-#pragma unroll
-		for (int ks = 0; ks < KSTEPS; ++ks) {
-			const int c0 = F8 ? 4 * ks + (lane >> 4) : (ks * 32 + 8 * (lane >> 4)) / EPC;
-#pragma unroll
-			for (int i = 0; i < MI; ++i) {
-				const int row = wm * WM + 16 * i + (lane & 15);
-#pragma unroll
-				for (int f = 0; f < FCH; ++f) fr.a[ks][i][f] = *(const uint4*)(As + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
-			}
-#pragma unroll
-			for (int j = 0; j < NI; ++j) {
-				const int row = wn * WN + 16 * j + (lane & 15);
-#pragma unroll
-				for (int f = 0; f < FCH; ++f) fr.b[ks][j][f] = *(const uint4*)(Bs + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
-			}
-		}
-	};
-	auto mfma_tile = [&](const Frags& fr) {
-#pragma unroll
-		for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-			for (int i = 0; i < MI; ++i)
-#pragma unroll
-				for (int j = 0; j < NI; ++j) {
-					if constexpr (F8) {
-						union { uint4 q; long l[2]; } ua, ub;
-						ua.q = fr.a[ks][i][0]; ub.q = fr.b[ks][j][0];
-						acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.l[0], ub.l[0], acc[i][j], 0, 0, 0);
-						acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.l[1], ub.l[1], acc[i][j], 0, 0, 0);
-					} else {
-						union { FragT v; uint4 q[FCH]; } ua, ub;
-#pragma unroll
-						for (int f = 0; f < FCH; ++f) { ua.q[f] = fr.a[ks][i][f]; ub.q[f] = fr.b[ks][j][f]; }
-						acc[i][j] = mma16<typename std::conditional<F8, bf16, T>::type>(ua.v, ub.v, acc[i][j]);
-					}
-				}
-	};
-	// One pipeline step for tile kt (not the last) whose fragments are already in `cur`:
-	//   wait until tile kt+1 has landed for this wave (tile kt+2 may stay in flight) and this wave's reads of tile kt are done;
-	//   barrier: now tile kt+1 has landed for every wave and stage kt%NSTAGE is free everywhere;
-	//   request tile kt+NSTAGE into stage kt%NSTAGE, start reading tile kt+1's fragments, multiply tile kt.
-	// The fragment reads must NOT sit under a condition: the compiler does not see the hand-written waits, so it protects the
-	// MFMAs' operands itself, and with the reads of the next tile in a conditional block it can only do that with lgkmcnt(0) --
-	// i.e. the MFMAs of tile kt waited for the reads of tile kt+1 and nothing overlapped (what the first version of this loop
-	// did: ~1050 cycles per k-tile for 256 cycles of MFMA and 384 of LDS reads).  Hence the peeled last tile below.
+	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
+	float res_pre[MI][4][NI];
+	constexpr int RESN = MI * 4 * NI;
+	constexpr bool PRE_RES = R::on && R::RES && NSTAGE == 3 && PER_TILE + RESN <= 63;
 	// wait until at most `tiles` of this wave's requested tiles are still in flight (vmcnt takes an immediate: uniform branch chain)
 	auto wait_tiles = [&](int tiles) {
 		if (tiles <= 0) wait_vmcnt<0>();
@@ -424,78 +430,273 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 		else if (tiles == 3 || NSTAGE <= 5) wait_vmcnt<3 * PER_TILE>();
 		else wait_vmcnt<4 * PER_TILE>();
 	};
-	auto step = [&](int kt, const Frags& cur, Frags& nxt) {
-		wait_tiles(min(NSTAGE - 2, NTILES - 2 - kt));          // tile kt+1 has landed; up to NSTAGE-2 younger ones stay in flight
-#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 32))         // diagnostic 32: what the drain of this wave's fragment reads in front of the barrier costs (only meaningful with 3: no DMA overwrites anything)
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 64))         // diagnostic 64: no workgroup barrier in the k-loop (with 3)
-		__builtin_amdgcn_s_barrier();
-#endif
-		asm volatile("" ::: "memory");
-#ifdef TTK_DIAG_SKIP
-		if ((TTK_DIAG_SKIP & 4) && kt > 0) { if (kt + NSTAGE < NTILES) issue(kt % NSTAGE); mfma_tile(cur); return; }   // diagnostic: no LDS fragment reads (stale registers)
-		if ((TTK_DIAG_SKIP & 8) && kt > 0) { if (kt + NSTAGE < NTILES) issue(kt % NSTAGE); read_frags(nxt, (kt + 1) % NSTAGE); return; }   // diagnostic: no MFMAs
-#endif
-		// (Pinning the order with sched_barriers -- all reads first, DMA issue between the two k-steps' MFMAs -- won 10% in an L2-hot
-		// microbenchmark and LOST 2% in the diffusion loop, where activations and weights arrive cold: tests/diag/ddim_ab.py.)
-		if (kt + NSTAGE < NTILES) issue(kt % NSTAGE);
-		read_frags(nxt, (kt + 1) % NSTAGE);
-		mfma_tile(cur);
-	};
-
+	// the hand-ordered k-step (see pipe_read16 above) for wave blocks up to 64 x 32: two fragment sets of a 64 x 64 block (128 registers) beside its 64 accumulators do not fit
+	// 256 registers -- the allocator spills, and a spill between two asm statements may move a fragment before its data has landed; f32 / fp8 operands and the other ring
+	// depths keep the compiler's order as well
+	constexpr bool PIPE = TTK_GEMM_PIPE && ES == 2 && NSTAGE == 3 && MI * NI <= 8;
+	if constexpr (PIPE) {
+		constexpr int NM = KSTEPS * MI * NI, NR = KSTEPS * (MI + NI);
+		constexpr int PREB = TTK_PIPE_PREB, DPG = TTK_PIPE_DPG;
+		constexpr int RPG_MIN = (NR + (NM - PREB) - 1) / (NM - PREB), RPG = TTK_PIPE_RPG > RPG_MIN ? TTK_PIPE_RPG : RPG_MIN;      // (narrow wave blocks have more reads than gaps)
+		constexpr int RGAPS = (NR + RPG - 1) / RPG, DGAPS = (PER_TILE + DPG - 1) / DPG;
+		constexpr int D0 = TTK_PIPE_DLATE || PREB + TTK_PIPE_D0 > NM - DGAPS ? NM - DGAPS : PREB + TTK_PIPE_D0;
+		static_assert(PREB + RGAPS <= NM && D0 >= PREB && D0 + DGAPS <= NM, "reads and DMA pieces must fit the gaps behind the barrier");
+		struct PFrags { u32x4 a[KSTEPS][MI], b[KSTEPS][NI]; };
+		// this lane's chunk of fragment row (lane & 15) in stage 0, per k-step: chunk (4 ks + (lane >> 4)) ^ (row & 7); sub-tile i / j adds 2048 i (an immediate)
+		unsigned fa[KSTEPS], fb[KSTEPS];
 #pragma unroll
-	for (int st = 0; st < NSTAGE; ++st)
-		if (st < NTILES) issue(st);
-	TTK_WSTAMP(stamps_, blockIdx.x, 1);
-	wait_tiles(min(NSTAGE, NTILES) - 1);                       // tile 0 has landed
-	__builtin_amdgcn_s_barrier();
-	asm volatile("" ::: "memory");
-	TTK_WSTAMP(stamps_, blockIdx.x, 2);
-	Frags f0, f1;
-	read_frags(f0, 0);
-	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
-	float res_pre[MI][4][NI];
-	// Roles with a residual (the k = 3 conv and proj_out of the DDIM loop, C aliasing the residual): its tile is requested UNDER the last two k-tiles instead of
-	// in the epilogue, where its round trip was the longest single item (1.9 us of epilogue against 1.0 without a residual, profiles/r04_ddim_chain_roles.log).
-	// The requests leave right behind the LAST DMA request, so they are younger than every piece of the ring: vmcnt retires in order, and the two counted waits
-	// that follow simply allow RESN more loads in flight.  (Round 3 requested the tile at the top of the kernel: 32 loads in front of the first DMA request cost more
-	// than the epilogue gained.)  Same values into the same additions: same bits.
-	constexpr int RESN = MI * 4 * NI;
-	constexpr bool PRE_RES = R::on && R::RES && NSTAGE == 3 && PER_TILE + RESN <= 63;
-	if constexpr (PRE_RES) {
-		constexpr int NT = R::NSEG * (GR_K / BKE);
-		static_assert(!PRE_RES || (NT % 2 == 0 && NT >= 8), "the peeled tail assumes an even tile count");
-		auto tail_step = [&](auto wtag, int stage_next, const Frags& cur, Frags& nxt) {
-			wait_vmcnt<decltype(wtag)::value>();
-#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 32))
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		for (int ks = 0; ks < KSTEPS; ++ks) {
+			const int c0 = 4 * ks + (lane >> 4), rowa = wm * WM + (lane & 15), rowb = wn * WN + (lane & 15);
+			fa[ks] = smem_base + rowa * 128 + ((c0 ^ (rowa & 7)) << 4);
+			fb[ks] = smem_base + BM * 128 + rowb * 128 + ((c0 ^ (rowb & 7)) << 4);
+		}
+		unsigned pA_dst = 0, pB_dst = 0, p_soffA = 0, p_soffB = 0;      // the tile being requested in this step
+#ifdef TTK_DIAG_SKIP
+		bool p_skipA = false, p_skipB = false;
 #endif
-			__builtin_amdgcn_s_barrier();
+		auto issue_prep = [&](unsigned stage_off) {   // the next tile in (segment, k) order goes to the stage at byte offset stage_off
+			if (kk_i == 0) set_segment(seg_i);
+#ifdef TTK_DIAG_SKIP
+			p_skipA = ((TTK_DIAG_SKIP & 1) && (seg_i > 0 || kk_i > 1)) || ((TTK_DIAG_SKIP & 16) && seg_i > 0);
+			p_skipB = (TTK_DIAG_SKIP & 2) && (seg_i > 0 || kk_i > 1);
+#endif
+			pA_dst = smem_base + stage_off; pB_dst = pA_dst + BM * 128;
+			p_soffA = (unsigned)kk_i * 128u; p_soffB = b_seg_off + (unsigned)kk_i * 128u;
+			if (++kk_i == KT) { kk_i = 0; ++seg_i; }
+		};
+		auto issue_piece = [&](auto d_) {
+			constexpr int d = decltype(d_)::value;
+			if constexpr (d < A_PC) {
+#ifdef TTK_DIAG_SKIP
+				if (p_skipA) return;
+#endif
+				pipe_glds16(va[d], srdA, p_soffA, pA_dst + (wave + NW * d) * 1024);
+			} else {
+#ifdef TTK_DIAG_SKIP
+				if (p_skipB) return;
+#endif
+				pipe_glds16(vb[d - A_PC], srdB, p_soffB, pB_dst + (wave + NW * (d - A_PC)) * 1024);
+			}
+		};
+		auto read_one = [&](auto r_, PFrags& fr, const unsigned (&ra)[KSTEPS], const unsigned (&rb)[KSTEPS]) {
+			constexpr int r = decltype(r_)::value, ks = r / (MI + NI), q = r % (MI + NI);
+			if constexpr (q < MI) pipe_read16<q * 2048>(fr.a[ks][q], ra[ks]);
+			else pipe_read16<(q - MI) * 2048>(fr.b[ks][q - MI], rb[ks]);
+		};
+		// One k-step: the MFMAs of tile kt (`cur`) in (ks, i, j) order; behind MFMA number PREB the caller's wait + barrier (tile kt+1 has landed for everyone, and
+		// everyone's reads of tile kt ended with the lgkmcnt(0) of the step before, so its stage may be refilled); from there on RPG reads of tile kt+1 into `nxt` per
+		// MFMA gap, the DMA pieces of tile kt+3 one per gap in the last gaps; the step ends with this wave's reads drained.
+		auto trip = [&](auto issue_, auto&& pre, const PFrags& cur, PFrags& nxt, unsigned rd_off) {
+			constexpr bool ISSUE = decltype(issue_)::value;
+			unsigned ra[KSTEPS], rb[KSTEPS];
+#pragma unroll
+			for (int ks = 0; ks < KSTEPS; ++ks) { ra[ks] = fa[ks] + rd_off; rb[ks] = fb[ks] + rd_off; }
+			static_for<0, NM>([&](auto m_) {
+				constexpr int m = decltype(m_)::value, ks = m / (MI * NI), i = (m % (MI * NI)) / NI, j = m % NI;
+				if constexpr (m == PREB) pre();
+#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 8))
+				pipe_mfma<T>(acc[i][j], cur.a[ks][i], cur.b[ks][j]);
+#endif
+#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 4))
+				static_for<0, RPG>([&](auto q_) {
+					constexpr int r = (m - PREB) * RPG + decltype(q_)::value;
+					if constexpr (m >= PREB && r < NR) read_one(std::integral_constant<int, r>{}, nxt, ra, rb);
+				});
+#endif
+				if constexpr (ISSUE) static_for<0, DPG>([&](auto q_) {
+					constexpr int d = (m - D0) * DPG + decltype(q_)::value;
+					if constexpr (m >= D0 && d < PER_TILE) issue_piece(std::integral_constant<int, d>{});
+				});
+			});
+			pipe_lgkm0();
+		};
+		auto barrier = [&] { TTK_FENCE(); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); TTK_FENCE(); };
+
+		const unsigned m0_keep = pipe_m0_save();
+#pragma unroll
+		for (int st = 0; st < NSTAGE; ++st)
+			if (st < NTILES) { issue_prep(st * STAGE); static_for<0, PER_TILE>(issue_piece); }
+		TTK_WSTAMP(stamps_, blockIdx.x, 1);
+		wait_tiles(min(NSTAGE, NTILES) - 1);                       // tile 0 has landed
+		barrier();
+		TTK_WSTAMP(stamps_, blockIdx.x, 2);
+		PFrags f0, f1;
+		static_for<0, NR>([&](auto r_) { read_one(r_, f0, fa, fb); });
+		pipe_lgkm0();
+#ifdef TTK_CLOCK_STAMPS
+		const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+		unsigned rd_off = STAGE, wr_off = 0;      // stages of tile kt+1 (read in step kt) and of tile kt (refilled in step kt)
+		auto advance = [&] { rd_off = rd_off == (NSTAGE - 1) * STAGE ? 0u : rd_off + STAGE; wr_off = wr_off == (NSTAGE - 1) * STAGE ? 0u : wr_off + STAGE; };
+		auto mfma_last = [&](const PFrags& cur) {
+			static_for<0, NM>([&](auto m_) {
+				constexpr int m = decltype(m_)::value, ks = m / (MI * NI), i = (m % (MI * NI)) / NI, j = m % NI;
+				pipe_mfma<T>(acc[i][j], cur.a[ks][i], cur.b[ks][j]);
+			});
+		};
+		// the three kinds of step: one that requests a tile (two younger tiles exist and one of them stays in flight: vmcnt(PER_TILE)), and the two of the tail, which
+		// request nothing and wait with a constant as well.  ONE body per kind: a run-time "request or not" would give the loop two bodies with their own register
+		// assignment and accumulator copies between them.
+		auto pstep_i = [&](const PFrags& cur, PFrags& nxt) {
+			auto pre = [&] { wait_vmcnt<PER_TILE>(); barrier(); };
+			issue_prep(wr_off); trip(std::true_type{}, pre, cur, nxt, rd_off);
+			advance();
+		};
+		auto ptail = [&](auto wtag, const PFrags& cur, PFrags& nxt) {
+			auto pre = [&] { wait_vmcnt<decltype(wtag)::value>(); barrier(); };
+			trip(std::false_type{}, pre, cur, nxt, rd_off);
+			advance();
+		};
+		if constexpr (PRE_RES) {      // (the residual tile is requested under the last two k-tiles: see the compiler-ordered branch below)
+			constexpr int NT = R::NSEG * (GR_K / BKE);
+			static_assert(!PRE_RES || (NT % 2 == 0 && NT >= 8), "the peeled tail assumes an even tile count");
+			for (int kt = 0; kt < NT - 4; kt += 2) { pstep_i(f0, f1); pstep_i(f1, f0); }
+			pstep_i(f0, f1);                     // requests the last tile (NT - 1)
+			if (m0 + BM <= p.M) load_residual_role<ROLE, MI, NI, false>(p, res_pre, row0, col0, lane);
+			else load_residual_role<ROLE, MI, NI, true>(p, res_pre, row0, col0, lane);
 			asm volatile("" ::: "memory");
-			read_frags(nxt, stage_next);
+			TTK_FENCE();
+			ptail(std::integral_constant<int, PER_TILE + RESN>{}, f1, f0);      // tile NT-2 has landed; tile NT-1 and the residual may be in flight
+			ptail(std::integral_constant<int, RESN>{}, f0, f1);                 // tile NT-1 has landed
+			mfma_last(f1);
+		} else {
+			const int nmain = NTILES > NSTAGE ? NTILES - NSTAGE : 0;      // steps that request a tile
+			int kt = 0;
+			for (; kt + 2 <= nmain; kt += 2) { pstep_i(f0, f1); pstep_i(f1, f0); }
+			if (kt < nmain) { pstep_i(f0, f1); f0 = f1; ++kt; }          // (an odd count: tile kt's fragments move to f0 -- 48 register copies behind the step's lgkmcnt(0))
+			if (NTILES - kt >= 3) { ptail(std::integral_constant<int, PER_TILE>{}, f0, f1); ptail(std::integral_constant<int, 0>{}, f1, f0); mfma_last(f0); }
+			else if (NTILES - kt == 2) { ptail(std::integral_constant<int, 0>{}, f0, f1); mfma_last(f1); }
+			else mfma_last(f0);
+		}
+		pipe_m0_restore(m0_keep);
+#ifdef TTK_CLOCK_STAMPS
+		if (stamps_ && lane == 0) {      // shader cycles and 100 MHz ticks of this wave's k-loop (diagnostic build: MI355X_MICROARCH.md, DVFS give-back item 6)
+			unsigned long long* st_ = stamps_ + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
+			st_[6] = ((__builtin_amdgcn_s_memtime() - clk0_) << 32) | ((__builtin_amdgcn_s_memrealtime() - rt0_) & 0xffffffffull);
+		}
+#endif
+	} else {
+		// Fragment registers of one k-tile (all k-steps), two sets used ping-pong: the ds_reads of tile k+1 are in flight under the
+		// MFMAs of tile k (with one wave per SIMD nothing else hides the ~130-cycle LDS latency; measured 735 cycles per k-tile for
+		// 256 cycles of MFMA before this).  Named structs + a 2x unrolled loop: an indexed array of register sets would go to scratch.
+		struct Frags { uint4 a[KSTEPS][MI][FCH]; uint4 b[KSTEPS][NI][FCH]; };
+		auto read_frags = [&](Frags& fr, int stage) {
+			const char* As = smem + stage * STAGE;
+			const char* Bs = As + BM * 128;
+	#pragma unroll
+			for (int ks = 0; ks < KSTEPS; ++ks) {
+				const int c0 = F8 ? 4 * ks + (lane >> 4) : (ks * 32 + 8 * (lane >> 4)) / EPC;
+	#pragma unroll
+				for (int i = 0; i < MI; ++i) {
+					const int row = wm * WM + 16 * i + (lane & 15);
+	#pragma unroll
+					for (int f = 0; f < FCH; ++f) fr.a[ks][i][f] = *(const uint4*)(As + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
+				}
+	#pragma unroll
+				for (int j = 0; j < NI; ++j) {
+					const int row = wn * WN + 16 * j + (lane & 15);
+	#pragma unroll
+					for (int f = 0; f < FCH; ++f) fr.b[ks][j][f] = *(const uint4*)(Bs + row * 128 + (((c0 + f) ^ (row & 7)) << 4));
+				}
+			}
+		};
+		auto mfma_tile = [&](const Frags& fr) {
+	#pragma unroll
+			for (int ks = 0; ks < KSTEPS; ++ks)
+	#pragma unroll
+				for (int i = 0; i < MI; ++i)
+	#pragma unroll
+					for (int j = 0; j < NI; ++j) {
+						if constexpr (F8) {
+							union { uint4 q; long l[2]; } ua, ub;
+							ua.q = fr.a[ks][i][0]; ub.q = fr.b[ks][j][0];
+							acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.l[0], ub.l[0], acc[i][j], 0, 0, 0);
+							acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.l[1], ub.l[1], acc[i][j], 0, 0, 0);
+						} else {
+							union { FragT v; uint4 q[FCH]; } ua, ub;
+	#pragma unroll
+							for (int f = 0; f < FCH; ++f) { ua.q[f] = fr.a[ks][i][f]; ub.q[f] = fr.b[ks][j][f]; }
+							acc[i][j] = mma16<typename std::conditional<F8, bf16, T>::type>(ua.v, ub.v, acc[i][j]);
+						}
+					}
+		};
+		// One pipeline step for tile kt (not the last) whose fragments are already in `cur`:
+		//   wait until tile kt+1 has landed for this wave (tile kt+2 may stay in flight) and this wave's reads of tile kt are done;
+		//   barrier: now tile kt+1 has landed for every wave and stage kt%NSTAGE is free everywhere;
+		//   request tile kt+NSTAGE into stage kt%NSTAGE, start reading tile kt+1's fragments, multiply tile kt.
+		// The fragment reads must NOT sit under a condition: the compiler does not see the hand-written waits, so it protects the
+		// MFMAs' operands itself, and with the reads of the next tile in a conditional block it can only do that with lgkmcnt(0) --
+		// i.e. the MFMAs of tile kt waited for the reads of tile kt+1 and nothing overlapped (what the first version of this loop
+		// did: ~1050 cycles per k-tile for 256 cycles of MFMA and 384 of LDS reads).  Hence the peeled last tile below.
+		auto step = [&](int kt, const Frags& cur, Frags& nxt) {
+			wait_tiles(min(NSTAGE - 2, NTILES - 2 - kt));          // tile kt+1 has landed; up to NSTAGE-2 younger ones stay in flight
+	#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 32))         // diagnostic 32: what the drain of this wave's fragment reads in front of the barrier costs (only meaningful with 3: no DMA overwrites anything)
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	#endif
+	#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 64))         // diagnostic 64: no workgroup barrier in the k-loop (with 3)
+			__builtin_amdgcn_s_barrier();
+	#endif
+			asm volatile("" ::: "memory");
+	#ifdef TTK_DIAG_SKIP
+			if ((TTK_DIAG_SKIP & 4) && kt > 0) { if (kt + NSTAGE < NTILES) issue(kt % NSTAGE); mfma_tile(cur); return; }   // diagnostic: no LDS fragment reads (stale registers)
+			if ((TTK_DIAG_SKIP & 8) && kt > 0) { if (kt + NSTAGE < NTILES) issue(kt % NSTAGE); read_frags(nxt, (kt + 1) % NSTAGE); return; }   // diagnostic: no MFMAs
+	#endif
+			// (Pinning the order with sched_barriers -- all reads first, DMA issue between the two k-steps' MFMAs -- won 10% in an L2-hot
+			// microbenchmark and LOST 2% in the diffusion loop, where activations and weights arrive cold: tests/diag/ddim_ab.py.)
+			if (kt + NSTAGE < NTILES) issue(kt % NSTAGE);
+			read_frags(nxt, (kt + 1) % NSTAGE);
 			mfma_tile(cur);
 		};
-		int kt = 0;
-		for (; kt < NT - 4; kt += 2) {      // every one of these steps requests a tile
-			step(kt, f0, f1);
-			step(kt + 1, f1, f0);
-		}
-		step(NT - 4, f0, f1);                // requests the last tile (NT - 1)
-		if (m0 + BM <= p.M) load_residual_role<ROLE, MI, NI, false>(p, res_pre, row0, col0, lane);      // (straight-line: 32 requests back to back)
-		else load_residual_role<ROLE, MI, NI, true>(p, res_pre, row0, col0, lane);
+
+	#pragma unroll
+		for (int st = 0; st < NSTAGE; ++st)
+			if (st < NTILES) issue(st);
+		TTK_WSTAMP(stamps_, blockIdx.x, 1);
+		wait_tiles(min(NSTAGE, NTILES) - 1);                       // tile 0 has landed
+		__builtin_amdgcn_s_barrier();
 		asm volatile("" ::: "memory");
-		tail_step(std::integral_constant<int, PER_TILE + RESN>{}, (NT - 2) % NSTAGE, f1, f0);      // tile NT-2 has landed; tile NT-1 and the residual may be in flight
-		tail_step(std::integral_constant<int, RESN>{}, (NT - 1) % NSTAGE, f0, f1);                 // tile NT-1 has landed
-		mfma_tile(f1);
-	} else {
-		int kt = 0;
-		for (; kt + 2 < NTILES; kt += 2) {      // both tiles of a round have a successor
-			step(kt, f0, f1);
-			step(kt + 1, f1, f0);
+		TTK_WSTAMP(stamps_, blockIdx.x, 2);
+		Frags f0, f1;
+		read_frags(f0, 0);
+		// Roles with a residual (the k = 3 conv and proj_out of the DDIM loop, C aliasing the residual): its tile is requested UNDER the last two k-tiles instead of
+		// in the epilogue, where its round trip was the longest single item (1.9 us of epilogue against 1.0 without a residual, profiles/r04_ddim_chain_roles.log).
+		// The requests leave right behind the LAST DMA request, so they are younger than every piece of the ring: vmcnt retires in order, and the two counted waits
+		// that follow simply allow RESN more loads in flight.  (Round 3 requested the tile at the top of the kernel: 32 loads in front of the first DMA request cost more
+		// than the epilogue gained.)  Same values into the same additions: same bits.
+		if constexpr (PRE_RES) {
+			constexpr int NT = R::NSEG * (GR_K / BKE);
+			static_assert(!PRE_RES || (NT % 2 == 0 && NT >= 8), "the peeled tail assumes an even tile count");
+			auto tail_step = [&](auto wtag, int stage_next, const Frags& cur, Frags& nxt) {
+				wait_vmcnt<decltype(wtag)::value>();
+	#if !(defined(TTK_DIAG_SKIP) && (TTK_DIAG_SKIP & 32))
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	#endif
+				__builtin_amdgcn_s_barrier();
+				asm volatile("" ::: "memory");
+				read_frags(nxt, stage_next);
+				mfma_tile(cur);
+			};
+			int kt = 0;
+			for (; kt < NT - 4; kt += 2) {      // every one of these steps requests a tile
+				step(kt, f0, f1);
+				step(kt + 1, f1, f0);
+			}
+			step(NT - 4, f0, f1);                // requests the last tile (NT - 1)
+			if (m0 + BM <= p.M) load_residual_role<ROLE, MI, NI, false>(p, res_pre, row0, col0, lane);      // (straight-line: 32 requests back to back)
+			else load_residual_role<ROLE, MI, NI, true>(p, res_pre, row0, col0, lane);
+			asm volatile("" ::: "memory");
+			tail_step(std::integral_constant<int, PER_TILE + RESN>{}, (NT - 2) % NSTAGE, f1, f0);      // tile NT-2 has landed; tile NT-1 and the residual may be in flight
+			tail_step(std::integral_constant<int, RESN>{}, (NT - 1) % NSTAGE, f0, f1);                 // tile NT-1 has landed
+			mfma_tile(f1);
+		} else {
+			int kt = 0;
+			for (; kt + 2 < NTILES; kt += 2) {      // both tiles of a round have a successor
+				step(kt, f0, f1);
+				step(kt + 1, f1, f0);
+			}
+			if (kt + 2 == NTILES) { step(kt, f0, f1); mfma_tile(f1); }
+			else mfma_tile(f0);
 		}
-		if (kt + 2 == NTILES) { step(kt, f0, f1); mfma_tile(f1); }
-		else mfma_tile(f0);
 	}
 	TTK_WSTAMPD(stamps_, blockIdx.x, 3, acc[0][0][0]);
 
