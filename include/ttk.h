@@ -32,7 +32,9 @@ enum { TTK_OK = 0, TTK_E_ARG = -1, TTK_E_HIP = -2, TTK_E_WEIGHT = -3, TTK_E_STAT
  * power-of-two per-tensor scale; the KV-cached decode streams them as fp8 bytes, the dense GEMMs hold the same values in bf16.
  * TTK_FP8 (diffusion handle only) = TTK_FP8W with the ACTIVATION operand of the ResBlock / AttentionBlock GEMMs rounded to fp8-e4m3 as well
  * (scale 1: they are GroupNorm outputs and attention outputs), those GEMMs running on the fp8 MFMA with f32 accumulation: the result is
- * the TTK_BF16 arithmetic applied to operands rounded that way, up to f32 summation order.
+ * the TTK_BF16 arithmetic applied to operands rounded that way, up to f32 summation order.  Diffusion handle, both fp8 modes (round 6): the
+ * AttentionBlocks' q / k / v projection keeps its weights and its activation operand in bf16 -- e4m3 on q and k moves peaked attention scores
+ * by whole units -- so "block GEMMs" there means in_layers.2, out_layers.3 and proj_out.
  * TTK_F16 (autoregressive and diffusion handles) = the TTK_BF16 design with IEEE half operands on v_mfma_f32_16x16x32_f16 -- the other dtype the
  * reference's `torch.autocast("cuda", dtype)` at inference.py:331 can be given (config.py:625-637); f32 accumulation, residual streams,
  * norms and softmax as in every mode, so unlike autocast nothing but an operand above 65504 can overflow. */

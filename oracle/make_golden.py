@@ -657,6 +657,38 @@ def stress_diff_cfg1_case(d_mod):
 				y_uncond_sub=yu[:, :, ::8].numpy(), mel=xm.numpy(), **amp)
 
 
+def stress_diff_cfg1_loop_case(d_mod):
+	"""The WHOLE 80-step diffusion in the trained-checkpoint regime through the REFERENCE: stress_diff_cfg1's model (full-size
+	`stress_diffusion` weights), latents and conditioning at T = 1088, `ddim_sample_loop_progressive` (diffusion.py:765-810) from seeded start noise, once in
+	f32 (the reference's default, data/config.yaml:88-93) and once in the reference's OWN 16-bit mode (`enable_fp16`, diffusion.py:1559-1561; bf16 is the CPU
+	autocast type) as the yardstick a 16-bit product mode is held against.  Stored: x after 8 / 16 / 40 / 72 steps on every 8th frame and the final mel whole,
+	for both loops.  tests/test_gpu_stress.py regenerates the inputs from the same seeds."""
+	cfg = W.DIFF_FULL
+	sd = W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), 2), cfg)
+	m = d_mod.DiffusionTTS(model_channels=cfg.model_channels, num_layers=cfg.num_layers, in_channels=cfg.in_channels,
+						   in_latent_channels=cfg.in_latent_channels, out_channels=cfg.out_channels, num_heads=cfg.num_heads)
+	load_into(m, sd)
+	M, T = 250, 250 * 4 * 24000 // 22050
+	lat = torch.randn(1, M, 1024, generator=gen(31))
+	dcond = torch.randn(1, 2048, generator=gen(32))
+	noise = torch.randn(1, 100, T, generator=gen(34))
+	with torch.inference_mode():
+		E = m.timestep_independent(lat, dcond, T, False)
+		keep = _ddim_loop_with_checkpoints(d_mod, m, noise, E)
+		m.enable_fp16 = True
+		keep_amp = _ddim_loop_with_checkpoints(d_mod, m, noise, E)
+		m.enable_fp16 = False
+	out = dict(T=np.int64(T), M=np.int64(M), stride=np.int64(8), steps=np.int64(80), checkpoints=np.array(LOOP_CHECKPOINTS, dtype=np.int64),
+			   mel=keep[80].numpy(), mel_ref_fp16mode=keep_amp[80].float().numpy())
+	for n in LOOP_CHECKPOINTS:
+		d = float((keep_amp[n].float() - keep[n]).norm() / keep[n].norm())
+		print(f"  after {n} steps: the reference's 16-bit loop vs its f32 loop, rel L2 {d:.3e}", flush=True)
+	for n in LOOP_CHECKPOINTS[:-1]:
+		out[f"x_after_{n}_sub"] = keep[n][:, :, ::8].numpy()
+		out[f"x_after_{n}_ref_fp16mode_sub"] = keep_amp[n][:, :, ::8].float().numpy()
+	return out
+
+
 def vocoder_case(cfg, seed, T):
 	"""The reference BigVGAN generator (models/bigvgan.py) on synthetic weights: the anti-aliasing filter it builds, the weight-normed
 	state_dict key names, one AMP block, `forward` internals and `inference` (waveform)."""
@@ -836,6 +868,7 @@ def main():
 		("stress_ar_full", lambda: stress_ar_full_case(uv_mod)),
 		("stress_diff", lambda: stress_diff_case(d_mod)),
 		("stress_diff_cfg1", lambda: stress_diff_cfg1_case(d_mod)),
+		("stress_diff_cfg1_loop", lambda: stress_diff_cfg1_loop_case(d_mod)),
 		("vocoder_small", lambda: vocoder_case(W.VOC_SMALL, 51, T=13)),
 		("clvp_small", lambda: clvp_case(W.CLVP_SMALL, 61)),
 		("tokenizer", tokenizer_case),

@@ -441,7 +441,7 @@ def rel_pos_bias(table: Tensor, i: int, j: int, scale: float) -> Tensor:
 
 
 # Operand rounding of the build's fp8 mode (include/ttk.h TTK_FP8), for tests that pin "fp8 mode == the same arithmetic on operands rounded to
-# fp8-e4m3": when set, the activation entering each ResBlock / AttentionBlock convolution passes through it.  None = the reference's arithmetic.
+# fp8-e4m3": when set, the activation entering each ResBlock convolution and each AttentionBlock's proj_out passes through it (the qkv projection keeps 16-bit operands).  None = the reference's arithmetic.
 BLOCK_OPERAND_ROUNDING = None
 
 
@@ -458,7 +458,7 @@ def attention_block(w: W, p: str, x: Tensor, heads: int) -> Tensor:
 	"""arch_utils.py:136-190 AttentionBlock._forward + :59-94 QKVAttentionLegacy (head-major [H,3,ch]
 	channel split, q*s and k*s with s = ch^-1/4, softmax in float)."""
 	b, c, T = x.shape
-	qkv = F.conv1d(_q(group_norm32(x, w[p + "norm.weight"], w[p + "norm.bias"])), w[p + "qkv.weight"], w[p + "qkv.bias"])
+	qkv = F.conv1d(group_norm32(x, w[p + "norm.weight"], w[p + "norm.bias"]), w[p + "qkv.weight"], w[p + "qkv.bias"])      # (never rounded: the build's fp8 modes keep this projection 16-bit)
 	ch = c // heads
 	q, k, v = qkv.reshape(b * heads, ch * 3, T).split(ch, dim=1)
 	s = 1 / math.sqrt(math.sqrt(ch))

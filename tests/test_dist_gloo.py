@@ -179,6 +179,38 @@ def _body_ancestral_lines_stay_home(rank, world):
 	return dict(res=[dict(mel=m, ids=i, scores=s, best=b) for m, i, s, b in res], batches=batches)
 
 
+class _RngStages(_FakeStages):
+	"""draws from torch's generator where HotPathStages does with sampler="p": `sample` reseeds (every `generate` does, stream_generator.py:296) and consumes a
+	line-dependent amount, `prepare_diffusion` draws the start noise, `run_diffusion` draws the per-step noise WHILE IT RUNS"""
+	diffusion_draws_while_running = True
+
+	def __init__(self, salt):
+		super().__init__(False)
+		self.salt = salt
+
+	def sample(self, lo, hi, n_candidates):
+		torch.manual_seed(0)
+		torch.randn(3 + 2 * self.salt)
+		return super().sample(lo, hi, n_candidates)
+
+	def prepare_diffusion(self, codes, latents):
+		return latents, torch.randn(1, 3, 4)
+
+	def run_diffusion(self, prepared):
+		return [lat.sum().view(1, 1, 1) + noise + sum(torch.randn(1, 3, 4) for _ in range(2)) for lat, noise in prepared]
+
+	def diffuse(self, codes, latents):
+		return self.run_diffusion([self.prepare_diffusion(codes, latents)])[0]
+
+
+def _body_ancestral_lines_draw_their_own_noise(rank, world):
+	"""with a sampler that draws inside the loop, every line of `sharded_candidates_lines` must see the generator state its OWN `sharded_candidates`
+	call sees (start noise, then the per-step draws, in front of the next line's reseed) -- three lines, each compared with its own call"""
+	alone = [D.sharded_candidates(_RngStages(k), 7)[0] for k in range(3)]
+	lines = [r[0] for r in D.sharded_candidates_lines([_RngStages(k) for k in range(3)], 7)]
+	return dict(alone=alone, lines=lines)
+
+
 def _body_subgroups(rank, world):
 	"""a 4-rank world cut into two 2-rank sub-groups (2 utterances x 2-way candidate shards, as configs[2] x configs[3] would combine on 8 GPUs),
 	and a 2-rank sub-group of a 3-rank world: every collective of the sharded path must stay inside the group it was given"""
@@ -346,10 +378,19 @@ def test_lines_of_an_ancestral_sampler_are_diffused_on_their_owner():
 	Lmax = max(3 + (c * 5) % 4 for c in range(7))
 	want_ids = torch.stack([_FakeStages.row(c, Lmax) for c in range(7)])
 	want_mel = (want_ids[0].float().sum() * 1.5).view(1, 1, 1) + torch.arange(12.0).view(1, 3, 4)
-	assert got[0]["batches"] == [2] and got[1]["batches"] == []          # both lines on rank 0, nothing moved
+	assert got[0]["batches"] == [1, 1] and got[1]["batches"] == []       # both lines on rank 0, nothing moved: the marked line at once, the other in the batch behind the loop
 	for r in (0, 1):
 		for k in range(2):
 			assert torch.equal(got[r]["res"][k]["mel"], want_mel) and got[r]["res"][k]["best"] == 0
+
+
+def test_lines_of_an_ancestral_sampler_draw_the_noise_of_their_own_call():
+	got = _run_ranks(_body_ancestral_lines_draw_their_own_noise)
+	for r in (0, 1):
+		for k in range(3):
+			assert torch.equal(got[r]["lines"][k], got[r]["alone"][k]), (r, k)
+		assert torch.equal(got[r]["lines"][0], got[0]["lines"][0])
+	assert not torch.equal(got[0]["lines"][0] - got[0]["lines"][0].mean(), got[0]["lines"][1] - got[0]["lines"][1].mean())      # (the lines' noise differs: the salt moves the generator)
 
 
 @pytest.mark.parametrize("world", [2, 4])

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 AR_FP8_KEYS = ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")
-DIFF_FP8_KEYS = ("qkv.weight", "proj_out.weight", "in_layers.2.weight", "out_layers.3.weight")
+DIFF_FP8_KEYS = ("proj_out.weight", "in_layers.2.weight", "out_layers.3.weight")      # (the q / k / v projection keeps 16-bit operands in the fp8 modes)
 
 
 def fp8_round(t):
@@ -95,7 +95,7 @@ def test_fp8w_diffusion_is_bf16_on_rounded_weights(golden):
 	sd_r = {k: (fp8_round(v)[0] if k.endswith(DIFF_FP8_KEYS) else v) for k, v in sd.items()}
 	n_blocks = 4 + 3 + cfg.num_layers                     # attention blocks: latent_conditioner + integrator + layers
 	n_res = 3 + cfg.num_layers + 3
-	assert sum(not torch.equal(sd[k], sd_r[k]) for k in sd) == 2 * n_blocks + 2 * n_res
+	assert sum(not torch.equal(sd[k], sd_r[k]) for k in sd) == n_blocks + 2 * n_res
 	T, M = 43, 10
 	lat = torch.randn(1, M, cfg.in_latent_channels, generator=torch.Generator().manual_seed(1)).to(DEV)
 	dcond = torch.randn(1, 2 * cfg.model_channels, generator=torch.Generator().manual_seed(2)).to(DEV)

@@ -219,7 +219,10 @@ static int load_attn(ttk_diff* h, const WeightMap& wm, const std::string& p, Att
 	const int C = h->cfg.model_channels;
 	TTK_TRY(upload_f32(h->arena, wm, p + "norm.weight", C, &A->gn_g));
 	TTK_TRY(upload_f32(h->arena, wm, p + "norm.bias", C, &A->gn_b));
-	TTK_TRY(upload_mat(h->arena, wm, h->wdt, p + "qkv.weight", p + "qkv.bias", PK_NK, 3 * C, C, false, &A->qkv));
+	// The q / k / v projection stays in the handle's 16-bit type in the fp8 modes, weights and activation operand alike (round 6): e4m3's three significand bits
+	// on q and k move scores of +-100 by whole units -- the peaked-attention regime of a trained checkpoint lost 37-42 % of an evaluation to it, against
+	// 12 % for bf16 (profiles/r05_stress_errors.json) -- while this GEMM is a seventh of a block's flops.
+	TTK_TRY(upload_mat(h->arena, wm, h->dt, p + "qkv.weight", p + "qkv.bias", PK_NK, 3 * C, C, false, &A->qkv));
 	TTK_TRY(upload_mat(h->arena, wm, h->wdt, p + "proj_out.weight", p + "proj_out.bias", PK_NK, C, C, false, &A->proj));
 	TTK_TRY(upload_f32(h->arena, wm, p + "__relbias", (int64_t)h->cfg.num_heads * 129, &A->relbias));
 	return TTK_OK;

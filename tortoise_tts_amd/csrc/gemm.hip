@@ -92,6 +92,9 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 #ifndef TTK_PIPE_D0
 #define TTK_PIPE_D0 6
 #endif
+#ifndef TTK_ROLE_STAGES
+#define TTK_ROLE_STAGES 3      // ring depth of the 128 x 64 role tiles
+#endif
 // (profiles/r06_chain_pipe_knobs.log, per layer of the replayed chain on hashed operands: 1 read per gap + pieces last 113.1 us; pieces first 113.9; 2 reads per gap 111.1;
 //  2 reads per gap + pieces from gap 6 111.6 with the shortest launch spans; 2 MFMAs in front of the barrier 112.8; 2 pieces per gap 114.2 -- the compiler-ordered loop 117.3)
 
@@ -421,7 +424,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
 	float res_pre[MI][4][NI];
 	constexpr int RESN = MI * 4 * NI;
-	constexpr bool PRE_RES = R::on && R::RES && NSTAGE == 3 && PER_TILE + RESN <= 63;
+	constexpr bool PRE_RES = R::on && R::RES && NSTAGE >= 3 && (NSTAGE - 2) * PER_TILE + RESN <= 63 && (NSTAGE == 3 || (TTK_GEMM_PIPE && ES == 2 && MI * NI <= 8));
 	// wait until at most `tiles` of this wave's requested tiles are still in flight (vmcnt takes an immediate: uniform branch chain)
 	auto wait_tiles = [&](int tiles) {
 		if (tiles <= 0) wait_vmcnt<0>();
@@ -433,7 +436,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	// the hand-ordered k-step (see pipe_read16 above) for wave blocks up to 64 x 32: two fragment sets of a 64 x 64 block (128 registers) beside its 64 accumulators do not fit
 	// 256 registers -- the allocator spills, and a spill between two asm statements may move a fragment before its data has landed; f32 / fp8 operands and the other ring
 	// depths keep the compiler's order as well
-	constexpr bool PIPE = TTK_GEMM_PIPE && ES == 2 && NSTAGE == 3 && MI * NI <= 8;
+	constexpr bool PIPE = TTK_GEMM_PIPE && ES == 2 && (NSTAGE == 3 || (R::on && NSTAGE > 3 && NSTAGE <= 6)) && MI * NI <= 8;
 	if constexpr (PIPE) {
 		constexpr int NM = KSTEPS * MI * NI, NR = KSTEPS * (MI + NI);
 		constexpr int PREB = TTK_PIPE_PREB, DPG = TTK_PIPE_DPG;
@@ -538,7 +541,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 		// request nothing and wait with a constant as well.  ONE body per kind: a run-time "request or not" would give the loop two bodies with their own register
 		// assignment and accumulator copies between them.
 		auto pstep_i = [&](const PFrags& cur, PFrags& nxt) {
-			auto pre = [&] { wait_vmcnt<PER_TILE>(); barrier(); };
+			auto pre = [&] { wait_vmcnt<(NSTAGE - 2) * PER_TILE>(); barrier(); };
 			issue_prep(wr_off); trip(std::true_type{}, pre, cur, nxt, rd_off);
 			advance();
 		};
@@ -547,19 +550,25 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 			trip(std::false_type{}, pre, cur, nxt, rd_off);
 			advance();
 		};
-		if constexpr (PRE_RES) {      // (the residual tile is requested under the last two k-tiles: see the compiler-ordered branch below)
-			constexpr int NT = R::NSEG * (GR_K / BKE);
-			static_assert(!PRE_RES || (NT % 2 == 0 && NT >= 8), "the peeled tail assumes an even tile count");
-			for (int kt = 0; kt < NT - 4; kt += 2) { pstep_i(f0, f1); pstep_i(f1, f0); }
-			pstep_i(f0, f1);                     // requests the last tile (NT - 1)
-			if (m0 + BM <= p.M) load_residual_role<ROLE, MI, NI, false>(p, res_pre, row0, col0, lane);
-			else load_residual_role<ROLE, MI, NI, true>(p, res_pre, row0, col0, lane);
-			asm volatile("" ::: "memory");
-			TTK_FENCE();
-			ptail(std::integral_constant<int, PER_TILE + RESN>{}, f1, f0);      // tile NT-2 has landed; tile NT-1 and the residual may be in flight
-			ptail(std::integral_constant<int, RESN>{}, f0, f1);                 // tile NT-1 has landed
-			mfma_last(f1);
+		if constexpr (R::on) {      // tile count known at compile time: NT - NSTAGE steps that request a tile, NSTAGE - 1 that do not, the last tile's MFMAs; tile kt lives in f[kt & 1]
+			constexpr int NT = R::NSEG * (GR_K / BKE), NMAIN = NT - NSTAGE;
+			static_assert(NMAIN >= 2, "the ring is deeper than the k-loop");
+			for (int kt = 0; kt + 2 <= NMAIN; kt += 2) { pstep_i(f0, f1); pstep_i(f1, f0); }
+			if constexpr (NMAIN & 1) pstep_i(f0, f1);      // requests the last tile (NT - 1)
+			if constexpr (PRE_RES) {      // (the residual tile is requested right behind the last DMA request: see the compiler-ordered branch below)
+				if (m0 + BM <= p.M) load_residual_role<ROLE, MI, NI, false>(p, res_pre, row0, col0, lane);
+				else load_residual_role<ROLE, MI, NI, true>(p, res_pre, row0, col0, lane);
+				asm volatile("" ::: "memory");
+				TTK_FENCE();
+			}
+			static_for<0, NSTAGE - 1>([&](auto t_) {      // step NMAIN + t: tile NMAIN + t + 1 has landed; the NSTAGE - 2 - t younger ones and the residual may be in flight
+				constexpr int t = decltype(t_)::value, W = (NSTAGE - 2 - t) * PER_TILE + (PRE_RES ? RESN : 0);
+				if constexpr (((NMAIN + t) & 1) == 0) ptail(std::integral_constant<int, W>{}, f0, f1);
+				else ptail(std::integral_constant<int, W>{}, f1, f0);
+			});
+			if constexpr (((NT - 1) & 1) == 0) mfma_last(f0); else mfma_last(f1);
 		} else {
+			static_assert(R::on || NSTAGE == 3, "run-time tile counts: 3-stage ring only");
 			const int nmain = NTILES > NSTAGE ? NTILES - NSTAGE : 0;      // steps that request a tile
 			int kt = 0;
 			for (; kt + 2 <= nmain; kt += 2) { pstep_i(f0, f1); pstep_i(f1, f0); }
@@ -784,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmParams p) {
 		const int nwg = p.mix_full, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
 		const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 		const int tn = div_recip(tile_id, p.mix_fm, p.inv_tiles_m);
-		gemm_tile<T, 128, 64, 2, 2, 3, ROLE>(p, (tile_id - tn * p.mix_fm) * 128, tn * 64, wave);
+		gemm_tile<T, 128, 64, 2, 2, TTK_ROLE_STAGES, ROLE>(p, (tile_id - tn * p.mix_fm) * 128, tn * 64, wave);
 	} else {                   // half-height tiles of the remaining rows: j = row block * 16 + (n-tile & 1) * 8 + XCD, n-tile = 2 * XCD + (n-tile & 1) -- the XCD whose L2 holds that weight slice
 		// (64 x 32 tiles on ONE wave each, over 64 CUs, were tried as well: a lone wave's k-loop is slower than the full tile beside it -- 116.0 against 114.5 us per
 		// layer, 130.0 against 128.3 ms per loop; profiles/r04_ddim_chain_mixed_quarter.log)
@@ -794,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmParams p) {
 		// the generic kernel) and by every T = 1088 test of the DDIM loop (16 half tiles per launch).  A port to another target must keep the surplus waves alive instead.
 		if (wave >= 2) return;
 		const int j = b - p.mix_full;
-		gemm_tile<T, 64, 64, 1, 2, 3, ROLE>(p, p.mix_fm * 128 + (j >> 4) * 64, (2 * (j & 7) + ((j >> 3) & 1)) * 64, wave);
+		gemm_tile<T, 64, 64, 1, 2, TTK_ROLE_STAGES, ROLE>(p, p.mix_fm * 128 + (j >> 4) * 64, (2 * (j & 7) + ((j >> 3) & 1)) * 64, wave);
 	}
 }
 
@@ -825,7 +834,7 @@ static bool mixed_grid_applies(const GemmParams& p) {
 }
 template <typename T, int ROLE>
 static void launch_mixed(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
-	constexpr int LDS = 3 * (128 + 64) * 128;
+	constexpr int LDS = TTK_ROLE_STAGES * (128 + 64) * 128;
 	static bool attr_set = false;
 	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_mixed<T, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
 	GemmParams p = p_in;
@@ -874,12 +883,13 @@ static void launch_tile_role(int role, const GemmParams& p, hipStream_t s, hipEv
 				return launch_mixed<T, GR_PROJ_RES>(p, s, ea, eb);
 			}
 		}
+		constexpr int NS = (BM == 128 && BN == 64 && sizeof(T) == 2) ? TTK_ROLE_STAGES : NSTAGE;
 		if constexpr (BN <= 128) {      // the 1024-wide roles run 128 x 64 (one utterance), 128 x 128 or 256 x 128 tiles (longer utterances, line batches)
-			if (role == GR_IN1x1) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_IN1x1>(p, s, ea, eb);
-			if (role == GR_CONV3_RES) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_CONV3_RES>(p, s, ea, eb);
-			if (role == GR_PROJ_RES) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_PROJ_RES>(p, s, ea, eb);
+			if (role == GR_IN1x1) return launch_tile<T, BM, BN, NWM, NWN, NS, GR_IN1x1>(p, s, ea, eb);
+			if (role == GR_CONV3_RES) return launch_tile<T, BM, BN, NWM, NWN, NS, GR_CONV3_RES>(p, s, ea, eb);
+			if (role == GR_PROJ_RES) return launch_tile<T, BM, BN, NWM, NWN, NS, GR_PROJ_RES>(p, s, ea, eb);
 		}
-		if (role == GR_QKV) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, GR_QKV>(p, s, ea, eb);
+		if (role == GR_QKV) return launch_tile<T, BM, BN, NWM, NWN, NS, GR_QKV>(p, s, ea, eb);
 	}
 	launch_tile<T, BM, BN, NWM, NWN, NSTAGE>(p, s, ea, eb);
 }

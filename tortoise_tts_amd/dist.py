@@ -212,8 +212,8 @@ def sharded_candidates_lines(stages_list, n_candidates: int, group=None, spread:
 	"""`sharded_candidates` for the lines of one text: per line the same exchange (shard sampling, id all-gather, RNG alignment, latent pass and
 	scores on every shard, first maximum wins), with the winner's owner making that line's random draws at once (`prepare_diffusion`: the next
 	line's `generate` reseeds, so the start noise is drawn where the single-GPU run draws it and TRAVELS with the item) -- then the lines'
-	diffusions are spread over the ranks (`assign_diffusers`; spread=False, or any stage with `diffusion_draws_while_running` -- the ancestral sampler --
-	keeps every line on its winner's owner): a line assigned to another rank
+	diffusions are spread over the ranks (`assign_diffusers`; spread=False keeps every line on its winner's owner; a stage with `diffusion_draws_while_running` -- the ancestral sampler --
+	is diffused on its winner's owner AT ONCE, behind its own start noise, and takes no part in the spreading): a line assigned to another rank
 	than its owner has its prepared item (latents + start noise, <= 2 MB) broadcast inside the group, every rank runs ONE diffusion over the lines
 	assigned to it (`run_diffusion`: a ragged batch on libttk), and the mels are broadcast line by line from where they were made.
 	Returns [(mel, ids, scores, best)] per line, each equal to that line's own `sharded_candidates` result."""
@@ -235,18 +235,29 @@ def sharded_candidates_lines(stages_list, n_candidates: int, group=None, spread:
 			owner, idx, scores = pick_best_candidate(sc, n_candidates, group)
 			best = candidate_shard(n_candidates, owner, world)[0] + idx
 		prep = st.prepare_diffusion(codes[idx:idx + 1], lat[idx:idx + 1]) if rank == owner else None
-		picked.append(dict(owner=owner, ids=ids, scores=scores, best=best, prep=prep))
+		home = bool(getattr(st, "diffusion_draws_while_running", False))
+		mel_now = None
+		if home and rank == owner:
+			# A sampler that draws per-step noise inside the loop (sampler="p") consumes the generator WHILE it runs: its loop must run here, right behind this line's
+			# start noise and in front of the next line's reseed / sampling / start noise -- the generator state its own `sharded_candidates` call (and the single-GPU
+			# per-line path) runs it in -- not in the batch behind the last line's prepare (every line but the last drew different noise there).
+			mel_now = st.run_diffusion([prep])[0].to(torch.float32).contiguous()
+			prep = None
+		picked.append(dict(owner=owner, ids=ids, scores=scores, best=best, prep=prep, mel_now=mel_now, home=home))
 	owners = [p["owner"] for p in picked]
-	# a sampler that draws per-step noise inside the loop (sampler="p") keeps every line on its winner's owner: the moved item carries the start noise only
-	spread = spread and not any(getattr(st, "diffusion_draws_while_running", False) for st in stages_list)
-	diffusers = assign_diffusers(owners, world) if spread else owners
+	# such lines stay on their winner's owner (already diffused above); the others are spread with their prepared item (latents + start noise)
+	movable = [k for k, p in enumerate(picked) if not p["home"]]
+	spread_to = assign_diffusers([owners[k] for k in movable], world) if spread and movable else [owners[k] for k in movable]
+	diffusers = list(owners)
+	for k, d in zip(movable, spread_to):
+		diffusers[k] = d
 	for k, (p, st) in enumerate(zip(picked, stages_list)):
 		p["diffuser"] = diffusers[k]
 		if diffusers[k] != p["owner"]:      # every rank takes part in the broadcast; only the assigned rank keeps the item
 			moved = _move_item(st.pack_prepared(p["prep"]) if rank == p["owner"] else None, p["owner"], p["ids"].device, group)
 			p["prep"] = st.unpack_prepared(moved) if rank == diffusers[k] else None
-	mine = [k for k, p in enumerate(picked) if p["diffuser"] == rank]
-	mels = {}
+	mine = [k for k, p in enumerate(picked) if p["diffuser"] == rank and not p["home"]]
+	mels = {k: p["mel_now"] for k, p in enumerate(picked) if p["mel_now"] is not None}
 	if mine:
 		# (the LAST assigned line's stages run the batch: their phase marks then end with the shared diffusion, right behind that line's own stages)
 		for k, m in zip(mine, stages_list[mine[-1]].run_diffusion([picked[k]["prep"] for k in mine])):
