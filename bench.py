@@ -179,11 +179,18 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 	}
 	out["ar_decode"]["floor_ms"] = ar_floor
 	eff = effective_floor(dtype_name, n_text, n_cand, n_mel, n_ddim, L, L_ddim)
+	chain = effective_floor(dtype_name, n_text, n_cand, n_mel, n_ddim, L, L_ddim, model="launch_chain")
 	for key, name in (("ar_decode", "ar_decode_ms"), ("latent_pass", "latent_pass_ms"), ("ddim", "ddim_ms")):
 		out[key]["effective_floor_ms"] = eff[name]
 		out[key]["frac_of_effective_floor"] = eff[name] / out[key]["ms"] if out[key].get("ms") else None
-	out["effective_floor"] = {"formula": "sum over dependent launches of [boundary + max(hbm_bytes / hbm_stream, bytes_per_CU / cu_l2_intake, flop / peak)] (bench.py, DESIGN.md section 6)",
-							  "constants": eff["constants"], "launches": eff["launches"], "ddim_step_us": eff["ddim_step_us"], "decode_token_us": eff["decode_token_us_at_mean_ctx"]}
+		out[key]["launch_chain_model_ms"] = chain[name]          # round 5's "effective floor": calibrated on this implementation, kept one round for comparison, NOT a bound
+		out[key]["frac_of_launch_chain_model"] = chain[name] / out[key]["ms"] if out[key].get("ms") else None
+	out["effective_floor"] = {"formula": "sum over dependent launches of [boundary + max(hbm_bytes / hbm_stream, flop / peak; GEMMs: MFMA phase of the tile at the in-kernel clock, "
+										 "bytes_per_CU / (cu_l2_intake x clock), staged bytes / l2_chip)] (bench.py, DESIGN.md section 6); every constant is a hardware rate from "
+										 "MI355X_MICROARCH.md or from a microbenchmark that does not run csrc/gemm.hip",
+							  "constants": eff["constants"], "launches": eff["launches"], "ddim_step_us": eff["ddim_step_us"], "decode_token_us": eff["decode_token_us_at_mean_ctx"],
+							  "launch_chain_model": {"note": "round 5's pricing: GEMM k-loops at the 68 GB/s per CU this implementation's trip chain was measured at -- a model of the launch chain, not a floor",
+													 "constants": chain["constants"], "ddim_step_us": chain["ddim_step_us"]}}
 	if L > 1:
 		out["lines"] = L
 	out["whole_step_floor_ms"] = out["ar_decode"]["floor_ms"] + out["latent_pass"]["floor_ms"] + out["ddim"]["floor_ms"]
@@ -191,6 +198,7 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 	out["whole_step_frac_of_floor"] = out["whole_step_floor_ms"] / out["whole_step_ms"] if out["whole_step_ms"] else None
 	out["whole_step_effective_floor_ms"] = eff["ar_decode_ms"] + eff["latent_pass_ms"] + eff["ddim_ms"]
 	out["whole_step_frac_of_effective_floor"] = out["whole_step_effective_floor_ms"] / out["whole_step_ms"] if out["whole_step_ms"] else None
+	out["whole_step_launch_chain_model_ms"] = chain["ar_decode_ms"] + chain["latent_pass_ms"] + chain["ddim_ms"]
 	return out
 
 
@@ -221,25 +229,43 @@ def rank_file(rank):
 # cond-free batch = 16 ResBlocks x (2 GroupNorm-apply + 1x1 conv + k=3 conv) + 13 AttentionBlocks x (GroupNorm-apply + qkv + attention + proj_out) + 8 others
 # (layout changes, input / integrating / output convs, out norm, the sampler update) = 124 launches.  Reported NEXT TO `frac`, never instead of it.
 BOUNDARY_US, HBM_STREAM, CU_L2_INTAKE = 1.45, 6.4e12, 68e9
+# Round 6: a GEMM k-loop is no longer priced with CU_L2_INTAKE -- that constant reproduced the measured k-loops because it was READ OFF them.
+# Its floor is now the largest of three hardware rates, none of them taken from csrc/gemm.hip:
+#   the MFMA phase of the tile at the clock the chip holds INSIDE these kernels: rounds x 2 BM BN K taps / (peak / 256 CUs) x (2.4 GHz / CLOCK_HZ); CLOCK_HZ 2.3e9 from s_memtime / s_memrealtime
+#       around the k-loops of the replayed chain on hashed operands (profiles/r06_clock.log: 2.26-2.36 GHz in the GEMMs, 2.34-2.41 in the attention -- the spec arithmetic's 2.4 GHz was 4 % high)
+#   the L2 -> LDS intake of one CU: 59 B/clk with 4 waves, 72 B/clk with 8 (tests/diag/l2_intake.cpp on an L2-resident region, profiles/r06_l2_intake.log: LDS-DMA, loads to registers and
+#       loads + ds_write all reach the same rate, so it is the texture path's, not an instruction's)
+#   the chip's L2 bandwidth: 34.5 TB/s over the bytes ALL tiles stage in the launch (MI355X_MICROARCH.md, L2)
+# and nothing for staging latency or the barrier per trip (what a perfect ring hides).  The old pricing stays in the line for one round as `launch_chain_model_ms`: a MODEL of this
+# implementation's launch chain (its constants are measured on it), not a bound -- it is what the round-5 lines called effective_floor.
+CLOCK_HZ, CU_INTAKE_BPC, L2_CHIP = 2.3e9, {4: 59.0, 8: 72.0}, 34.5e12
 
 
-def _gemm_floor_us(M, N, K, taps, e, peak):
+def _gemm_floor_us(M, N, K, taps, e, peak, model="hardware"):
 	t128, t12864 = -(-M // 128) * -(-N // 128), -(-M // 128) * -(-N // 64)
+	waves = 8
 	if t128 >= 256:
 		bm, bn, tiles = 128, 128, t128
 		t256 = -(-M // 256) * -(-N // 128)
 		if e <= 2 and t128 > 256 and 15 * -(-t256 // 256) < 9 * -(-t128 // 256):
 			bm, bn, tiles = 256, 128, t256
 	elif t12864 >= 128:
-		bm, bn, tiles = 128, 64, t12864
+		bm, bn, tiles, waves = 128, 64, t12864, 4
 	else:
-		bm, bn, tiles = 64, 64, -(-M // 64) * -(-N // 64)
+		bm, bn, tiles, waves = 64, 64, -(-M // 64) * -(-N // 64), 4
 	rounds = max(1.0, tiles / 256)        # a floor: surplus tiles spread evenly (the mixed grid of csrc/gemm.hip approaches this), never a whole second round
-	return max(rounds * (bm + bn) * K * taps * e / CU_L2_INTAKE, 2.0 * M * N * K * taps / peak) * 1e6
+	cu_bytes = rounds * (bm + bn) * K * taps * e
+	if model == "launch_chain":
+		return max(cu_bytes / CU_L2_INTAKE, 2.0 * M * N * K * taps / peak) * 1e6
+	mfma = rounds * 2.0 * bm * bn * K * taps / (peak / 256) * (2.4e9 / CLOCK_HZ)
+	intake = cu_bytes / (CU_INTAKE_BPC[waves] * CLOCK_HZ)
+	l2 = tiles * (bm + bn) * K * taps * e / L2_CHIP
+	return max(mfma, intake, l2) * 1e6
 
 
-def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL_TOKENS, n_ddim=DDIM_STEPS, lines=1, lines_ddim=1):
-	"""{phase: effective_floor_ms, ...} by the formula above; `ar_bytes` etc. as phase_roofline counts them"""
+def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL_TOKENS, n_ddim=DDIM_STEPS, lines=1, lines_ddim=1, model="hardware"):
+	"""{phase: effective_floor_ms, ...} by the formula above; `ar_bytes` etc. as phase_roofline counts them.  model="launch_chain": round 5's pricing of the GEMM k-loops (see CLOCK_HZ)"""
+	_g = lambda M_, N_, K_, taps_, e_, peak_: _gemm_floor_us(M_, N_, K_, taps_, e_, peak_, model)
 	e = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 2, "fp8": 2}[dtype_name]      # operand bytes staged per element by the dense GEMMs (fp8w widens at load; fp8 block GEMMs: 1, below)
 	e_w = {"bf16": 2, "f16": 2, "f32": 4, "fp8w": 1, "fp8": 1}[dtype_name]
 	e_kv = 4 if dtype_name == "f32" else 2
@@ -255,7 +281,7 @@ def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL
 		ar_us += tok_launches * BOUNDARY_US + hbm / HBM_STREAM * 1e6
 	def dense_pass_us(rows_per_seq, seqs):
 		M = rows_per_seq * seqs
-		g = sum(_gemm_floor_us(M, n, k, 1, e, peak) for n, k in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d)))
+		g = sum(_g(M, n, k, 1, e, peak) for n, k in ((3 * d, d), (d, d), (4 * d, d), (d, 4 * d)))
 		attn = 2.0 * 2 * rows_per_seq * rows_per_seq * d * seqs / peak * 1e6 / 2      # causal: half the score matrix
 		ln = 2 * (M * d * (4 + e) / 256 / CU_L2_INTAKE) * 1e6
 		return 30 * (7 * BOUNDARY_US + g + attn + ln) + 4 * BOUNDARY_US
@@ -268,13 +294,16 @@ def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL
 	e_blk = 1 if dtype_name == "fp8" else e
 	peak_blk = 5.0e15 if dtype_name == "fp8" else peak
 	gn = M * d * (4 + e_blk) / 256 / CU_L2_INTAKE * 1e6
-	res = 2 * gn + _gemm_floor_us(M, d, d, 1, e_blk, peak_blk) + _gemm_floor_us(M, d, d, 3, e_blk, peak_blk) + 4 * BOUNDARY_US
-	att = gn + _gemm_floor_us(M, 3 * d, d, 1, e_blk, peak_blk) + 2.0 * 2 * T * T * d * 2 / peak * 1e6 + _gemm_floor_us(M, d, d, 1, e_blk, peak_blk) + 4 * BOUNDARY_US
-	other = 8 * BOUNDARY_US + _gemm_floor_us(M, d, 100, 3, e, peak) + _gemm_floor_us(M, d, 2 * d, 1, e, peak) + _gemm_floor_us(M, 200, d, 3, e, peak) + gn
+	res = 2 * gn + _g(M, d, d, 1, e_blk, peak_blk) + _g(M, d, d, 3, e_blk, peak_blk) + 4 * BOUNDARY_US
+	att = gn + _g(M, 3 * d, d, 1, e_blk, peak_blk) + 2.0 * 2 * T * T * d * 2 / peak * 1e6 + _g(M, d, d, 1, e_blk, peak_blk) + 4 * BOUNDARY_US
+	other = 8 * BOUNDARY_US + _g(M, d, 100, 3, e, peak) + _g(M, d, 2 * d, 1, e, peak) + _g(M, 200, d, 3, e, peak) + gn
 	step_us = 16 * res + 13 * att + other
 	step_launches = 16 * 4 + 13 * 4 + 8
 	pre_us = 4 * (att - gn) + 8 * BOUNDARY_US                          # timestep_independent: 4 AttentionBlocks on the M latent rows (small), conv, norm, interpolate
-	return {"constants": {"boundary_us": BOUNDARY_US, "hbm_stream_Bps": HBM_STREAM, "cu_l2_intake_Bps": CU_L2_INTAKE},
+	consts = {"boundary_us": BOUNDARY_US, "hbm_stream_Bps": HBM_STREAM, "cu_stream_Bps (LayerNorm / GroupNorm-apply launches)": CU_L2_INTAKE}
+	consts.update({"gemm_kloop_Bps_per_CU (measured on this implementation)": CU_L2_INTAKE} if model == "launch_chain" else
+				  {"in_kernel_clock_Hz": CLOCK_HZ, "cu_l2_intake_B_per_clk": CU_INTAKE_BPC, "l2_chip_Bps": L2_CHIP})
+	return {"constants": consts,
 			"launches": {"decode_token": tok_launches, "ddim_step": step_launches},
 			"ar_decode_ms": lines * ar_us * 1e-3, "latent_pass_ms": lines * lat_us * 1e-3, "ddim_ms": lines_ddim * (n_ddim * step_us + pre_us) * 1e-3,
 			"ddim_step_us": step_us, "decode_token_us_at_mean_ctx": tok_us}
@@ -298,9 +327,17 @@ PARENT_GRACE_S = float(os.environ.get("TTK_BENCH_PARENT_GRACE", "20"))
 EXIT_STAGE_OVERRUN, EXIT_PREFLIGHT = 75, 76
 
 
-def stage_budgets():
+def stage_budgets(a=None):
+	"""the budgets for THIS run: the two stages that execute steps grow with what was asked for (a healthy --steps 100 run must not be ended by a constant) --
+	warm-up + graph capture / the timed steps at a generous per-step time (2 s per utterance step, 10 s per configs[3] shard step: 6-7x what one GPU measures)"""
 	o = os.environ.get("TTK_BENCH_STAGE_BUDGET")
-	return tuple((n, float(o)) for n, _ in STAGE_BUDGET_S) if o else STAGE_BUDGET_S
+	if o:
+		return tuple((n, float(o)) for n, _ in STAGE_BUDGET_S)
+	if a is None:
+		return STAGE_BUDGET_S
+	per = 10.0 if getattr(a, "shard", "") == "candidates" else 2.0
+	grow = {"timed region": per * max(0, getattr(a, "warmup", 0)), "timed done": per * max(0, getattr(a, "steps", 0))}
+	return tuple((n, b + grow.get(n, 0.0)) for n, b in STAGE_BUDGET_S)
 
 
 def tail_of(path, n=25):
@@ -316,10 +353,12 @@ class StageWatchdog:
 	is overdue, after writing where every thread stands (faulthandler) and the tail of RCCL's log -- a rank stuck in a rendezvous, a collective or a kernel
 	becomes a message and an exit status instead of a run killed at the driver's limit with nothing to read."""
 
-	def __init__(self, rank, world):
+	def __init__(self, rank, world, a=None):
 		import threading
 		self.rank, self.world = rank, world
-		self.budgets = list(stage_budgets())
+		self.budgets = list(stage_budgets(a))
+		self.elapsed = {}                      # marker -> seconds from the previous marker (goes into the result line: the first real N > 1 run calibrates the budgets)
+		self.last = time.monotonic()
 		self.i = 0
 		self.lock = threading.Lock()
 		self.deadline = time.monotonic() + self.budgets[0][1]
@@ -330,6 +369,9 @@ class StageWatchdog:
 	def reached(self, marker):
 		with self.lock:
 			names = [n for n, _ in self.budgets]
+			now = time.monotonic()
+			self.elapsed[marker] = round(now - self.last, 2)
+			self.last = now
 			if marker in names:
 				self.i = names.index(marker) + 1
 				self.deadline = time.monotonic() + self.budgets[self.i][1] if self.i < len(self.budgets) else None
@@ -402,17 +444,85 @@ def preflight(rank, world):
 		env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=val, MASTER_PORT=str(base + 17 * (attempt + 1)))
 		env.pop("TORCHELASTIC_USE_AGENT_STORE", None)          # the child rendezvouses on its own TCP store (rank 0 of the attempt hosts it), not the agent's
 		t0 = time.monotonic()
+		child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--preflight"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+		log(f"[pid] rank {rank} preflight child pid {child.pid}")
 		try:
-			r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--preflight"], env=env, capture_output=True, text=True, timeout=400)
-			rc, err = r.returncode, r.stderr
-		except subprocess.TimeoutExpired as e:
-			rc, err = -9, (e.stderr or b"").decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+			_, err = child.communicate(timeout=400)
+			rc = child.returncode
+		except subprocess.TimeoutExpired:
+			child.kill()
+			_, err = child.communicate()
+			rc = -9
 		log(f"[preflight] rank {rank} attempt {attempt} (HSA_ENABLE_IPC_MODE_LEGACY={val}): exit {rc} after {time.monotonic() - t0:.1f}s")
 		if rc == 0:
 			return val
 		log(f"[preflight] child output (last lines):\n" + "\n".join(err.splitlines()[-15:]))
 	log(f"[preflight] rank {rank}: the one-collective pre-flight failed under both IPC settings {order}; not building models")
 	sys.exit(EXIT_PREFLIGHT)
+
+
+def recorded_pids(gpus):
+	"""the pids the ranks (and their pre-flight children) logged to their rank files ("[pid] ... pid P"): only processes this run started"""
+	import re
+	pids = []
+	for r in range(gpus):
+		try:
+			with open(rank_file(r), errors="replace") as f:
+				pids += [int(m.group(1)) for ln in f if "[pid] " in ln for m in [re.search(r" pid (\d+)", ln)] if m]
+		except OSError:
+			pass
+	return pids
+
+
+def alive(pid):
+	try:
+		os.kill(pid, 0)
+	except ProcessLookupError:
+		return False
+	except PermissionError:
+		return True
+	try:      # a zombie (exited, not yet reaped by its parent) no longer holds anything
+		with open(f"/proc/{pid}/stat") as f:
+			return f.read().rsplit(")", 1)[1].split()[0] != "Z"
+	except OSError:
+		return False
+
+
+def teardown(proc, gpus, term_wait=None):
+	"""End the launcher AND the ranks.  `os.killpg(proc.pid)` reaches only the torch.distributed.run agent: the elastic agent starts every worker with
+	start_new_session=True, so the ranks and their pre-flight children live in other process groups; on SIGTERM the agent forwards the signal and waits up to 30 s
+	before it kills its workers.  So: SIGTERM to the agent's group and to every pid the ranks recorded; wait longer than the agent's 30 s; SIGKILL whatever recorded
+	pid is still alive (a rank wedged in the driver ignores SIGTERM), then the agent; report any pid that survives even that."""
+	import signal
+	term_wait = float(os.environ.get("TTK_BENCH_TERM_WAIT", "35")) if term_wait is None else term_wait
+	pids = recorded_pids(gpus)
+
+	def send(pid, sig, group=False):
+		try:
+			(os.killpg if group else os.kill)(pid, sig)
+		except (ProcessLookupError, PermissionError):
+			pass
+	send(proc.pid, signal.SIGTERM, group=True)               # the process group this function started (start_new_session), nothing else
+	for pid in pids:
+		send(pid, signal.SIGTERM)
+	t0 = time.monotonic()
+	while time.monotonic() - t0 < term_wait and (proc.poll() is None or any(alive(p) for p in pids)):
+		time.sleep(0.25)
+	left = [p for p in pids if alive(p)]
+	for pid in left:
+		log(f"[parent watchdog] pid {pid} ignored SIGTERM for {term_wait:.0f}s: SIGKILL")
+		send(pid, signal.SIGKILL)
+	if proc.poll() is None:
+		send(proc.pid, signal.SIGKILL, group=True)
+		try:
+			proc.wait(timeout=10)
+		except subprocess.TimeoutExpired:
+			pass
+	time.sleep(0.5)
+	still = [p for p in pids if alive(p)]
+	if still:
+		log(f"[parent watchdog] pids still alive after SIGKILL (they may hold a GPU): {still}")
+	return still
 
 
 def launcher_command(gpus, argv, port):
@@ -455,7 +565,7 @@ def self_launch(a):
 				print(line, file=sys.stderr, flush=True)      # anything else the ranks print is not the result line
 	th = threading.Thread(target=relay, daemon=True)
 	th.start()
-	budgets = stage_budgets()
+	budgets = stage_budgets(a)
 	names = [n for n, _ in budgets]
 	reached = [0] * a.gpus                 # markers seen per rank
 	since = [time.monotonic()] * a.gpus    # when the last one was seen
@@ -476,16 +586,7 @@ def self_launch(a):
 	if overdue is not None:
 		r, marker, budget = overdue
 		log(f"[parent watchdog] rank {r} has not logged '{marker}' within {budget:.0f}s (+{PARENT_GRACE_S:.0f}s grace) of its previous marker: terminating the {a.gpus} child ranks")
-		for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
-			try:
-				os.killpg(proc.pid, sig)               # the process group this function started (start_new_session), nothing else
-			except ProcessLookupError:
-				break
-			try:
-				proc.wait(timeout=wait)
-				break
-			except subprocess.TimeoutExpired:
-				continue
+		teardown(proc, a.gpus)
 	rc = proc.wait()
 	th.join(timeout=5)
 	if overdue is not None:
@@ -540,11 +641,13 @@ def main():
 		global _RANK_FILE
 		_RANK_FILE = rank_file(rank)
 		open(_RANK_FILE, "w").close()
+		log(f"[pid] rank {rank} pid {os.getpid()} pgid {os.getpgid(0)}")      # the parent's teardown signals these itself: the elastic agent starts its workers in sessions of their own
 		os.environ.setdefault("NCCL_DEBUG", "WARN")
 		os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(out_dir(), f"rccl.rank{rank}.log"))       # RCCL's own messages: a file per rank, never stdout (ONE JSON line goes there)
 		if os.environ.get("TTK_BENCH_NO_RANK_WATCHDOG") != "1":      # (the parent-side watchdog's test switches the ranks' own off)
-			wd = StageWatchdog(rank, world)
+			wd = StageWatchdog(rank, world, a)
 		os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = preflight(rank, world)
+		log(f"[ipc] rank {rank} will rendezvous with HSA_ENABLE_IPC_MODE_LEGACY={os.environ['HSA_ENABLE_IPC_MODE_LEGACY']}")      # a disagreement between ranks is readable in the rank files, not inferred from a rendezvous timeout
 
 	def mark(name):
 		"""a stage marker: logged (stderr + the rank's file), and the budget of the next one armed.  TTK_BENCH_STALL_RANK / TTK_BENCH_STALL_AT make one rank

@@ -317,14 +317,18 @@ def test_ar_full_size_outlier_weights_logits_and_ids(golden):
 # Bounds = 2.5-4x the measurement (full size: FULL_K x the small model's bound for f32).  Independent criterion for the 16-bit modes: the REFERENCE'S OWN 16-bit mode
 # (DiffusionTTS(use_fp16=True): layers >= 1 under autocast, diffusion.py:1559-1561) deviates from its f32 evaluation by 5.5e-2 (small) / 2.2e-1 (full size) here -- scores of
 # +-100 through 8-bit significands move softmax weights by tens of percent whoever computes them -- and the product's bf16 evaluation must not be further away than that
-# (measured 0.29x / 0.55x).  The fp8 modes lose the evaluation at 12-42 % in this regime (1.9-2.4x the reference's own 16-bit deviation): reported, bounded loosely, and
-# said in DESIGN.md section 2 -- config 5's e4m3 operands are not usable on peaked attention without keeping q / k in 16 bits.
+# (measured 0.29x / 0.55x).
+# fp8 / fp8w, round 6: the q / k / v projection keeps 16-bit operands in both modes (csrc/diff.hip load_attn) -- round 5's evaluations lost 37-42 % (full
+# size) / 12-17 % (small) to e4m3 on q and k; now measured (profiles/r06_stress_errors.json), small model / full size:
+#   fp8w E 5.6e-2 / 9.6e-2, evaluation 4.9e-2 .. 8.2e-2 / 1.2e-1 .. 2.7e-1, x 1.1e-1 / 4.4e-2        fp8 E 9.4e-2 / 1.2e-1, evaluation 7.2e-2 .. 1.3e-1 / 1.7e-1 .. 3.2e-1, x 1.2e-1 / 5.3e-2
+# Bounds = 1.5 x the larger of the two sizes' measurements (a 2 x regression fails), AND the independent criterion: the conditioned evaluation no further from the reference's
+# f32 one than 2 x the reference's own 16-bit mode is (1.1e-1 small / 4.4e-1 full size; measured 1.3 x / 1.45 x for fp8).
 DIFF_BOUNDS = {
 	"f32": dict(kind="abs", E=5e-4, y=1e-3, x=1e-3),
 	"f16": dict(kind="rel", E=2.5e-2, y=5e-2, x=1e-2),
 	"bf16": dict(kind="rel", E=1.5e-1, y=3e-1, x=6e-2),
-	"fp8w": dict(kind="rel", E=6e-1, y=8e-1, x=4e-1),
-	"fp8": dict(kind="rel", E=6e-1, y=8e-1, x=4e-1),
+	"fp8w": dict(kind="rel", E=1.45e-1, y=4.0e-1, x=1.6e-1),
+	"fp8": dict(kind="rel", E=1.8e-1, y=4.8e-1, x=1.75e-1),
 }
 FULL_K = 4.0
 
@@ -369,14 +373,14 @@ def test_diffusion_small_against_the_reference(golden, dtype):
 	record(f"diff_small_{dtype}", dict(kind=b["kind"], E=e_E, y_cond=e_yc, y_uncond=e_yu, **{f"x_after_{n}": v for n, v in e_x.items()}))
 	assert e_E < b["E"] and e_yc < b["y"] and e_yu < b["y"], (dtype, e_E, e_yc, e_yu)
 	assert all(v < b["x"] for v in e_x.values()), (dtype, e_x)
-	if dtype in ("bf16", "f16"):      # no further from the reference's f32 evaluation than the reference's own 16-bit mode is
+	if dtype != "f32":      # 16-bit modes: no further from the reference's f32 evaluation than the reference's own 16-bit mode is; the fp8 modes: within twice that
 		r = relerr(g["y_cond_ref_fp16mode"], g["y_cond"])
 		record("diff_small_reference_fp16mode", dict(kind="rel", y_cond=r))
-		assert e_yc < r, (dtype, e_yc, r)
+		assert e_yc < (r if dtype in ("bf16", "f16") else 2 * r), (dtype, e_yc, r)
 	assert torch.isfinite(xs[-1]).all() and xs[-1].abs().max() <= 1.0 + 1e-5
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"] + (["f16", "fp8w", "fp8"] if ALL_MODES else []))
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"] + (["f16", "fp8w"] if ALL_MODES else []))
 def test_diffusion_full_size_at_T1088_against_the_reference(golden, dtype):
 	"""configs[1]'s shape on the stress weights: E, one evaluation pair and the last 4 of the 80 DDIM steps, every 8th frame / the final mel whole"""
 	g = golden("stress_diff_cfg1")
@@ -402,7 +406,66 @@ def test_diffusion_full_size_at_T1088_against_the_reference(golden, dtype):
 	record(f"diff_full_{dtype}", dict(kind=b["kind"], E=e_E, y_cond=e_yc, y_uncond=e_yu, mel_last4=e_x))
 	k = FULL_K if dtype == "f32" else 1.0
 	assert e_E < k * b["E"] and e_yc < k * b["y"] and e_yu < k * b["y"] and e_x < k * b["x"], (dtype, e_E, e_yc, e_yu, e_x)
-	if dtype in ("bf16", "f16"):
+	if dtype != "f32":
 		r = relerr(g["y_cond_ref_fp16mode_sub"], g["y_cond_sub"])
 		record("diff_full_reference_fp16mode", dict(kind="rel", y_cond=r))
-		assert e_yc < r, (dtype, e_yc, r)
+		assert e_yc < (r if dtype in ("bf16", "f16") else 2 * r), (dtype, e_yc, r)
+
+
+# ------------------------------------------------------------------------------------------------ the WHOLE loop in the trained-checkpoint regime
+# stress_diff_cfg1_loop.npz: the reference's `ddim_sample_loop_progressive` (diffusion.py:765-810) on the full-size stress weights at T = 1088, all 80 steps from seeded noise,
+# in f32 AND in the reference's own 16-bit mode (`enable_fp16`, :1559-1561); x after 8 / 16 / 40 / 72 steps on every 8th frame, the final mel whole.
+# Criterion for the 16-bit product modes (independent of this build's own measurements): at every checkpoint, no further from the reference's f32 x than the reference's own
+# 16-bit loop is.  f32: absolute.  fp8 modes: STRESS_LOOP_BOUNDS below (1.5 x the measurement, stated next to it).
+STRESS_LOOP_CHECKPOINTS = (8, 16, 40, 72, 80)
+# Measured on MI355X (round 6, profiles/r06_stress_errors.json) after 8 / 16 / 40 / 72 / 80 steps:
+#   f32  abs 1.3e-4 / 2.0e-4 / 5.2e-4 / 2.6e-3 / 3.9e-3 (x in [-1, 1] at the end; the peaked regime amplifies rounding-level differences between two f32 implementations step by step)
+#   f16  rel 3.2e-4 / 6.0e-4 / 2.5e-3 / 1.3e-2 / 1.9e-2        bf16 rel 1.1e-3 / 2.5e-3 / 1.2e-2 / 4.2e-2 / 5.6e-2
+#   fp8w rel 1.7e-3 / 4.0e-3 / 2.3e-2 / 7.6e-2 / 1.0e-1        fp8  rel 1.8e-3 / 4.4e-3 / 2.5e-2 / 8.4e-2 / 1.1e-1
+#   the reference's OWN 16-bit loop vs its f32 loop: 1.5e-3 / 3.7e-3 / 2.1e-2 / 7.1e-2 / 9.6e-2 -- bf16 ends at 0.58 x of it, f16 at 0.20 x, fp8 at 1.15 x
+# Bounds: f32 / f16 2.5 x the measurement; bf16 1.5 x (and the criterion above, which is the tighter one); fp8 modes 1.5 x, and the final mel within 2 x the reference's own 16-bit loop.
+STRESS_LOOP_BOUNDS = {
+	"f32": dict(kind="abs", at={8: 4e-4, 16: 5e-4, 40: 1.5e-3, 72: 7e-3, 80: 1e-2}),
+	"f16": dict(kind="rel", at={8: 8e-4, 16: 1.5e-3, 40: 6.5e-3, 72: 3.2e-2, 80: 4.8e-2}),
+	"bf16": dict(kind="rel", at={8: 1.7e-3, 16: 3.7e-3, 40: 1.9e-2, 72: 6.3e-2, 80: 8.4e-2}),
+	"fp8w": dict(kind="rel", at={8: 2.5e-3, 16: 6e-3, 40: 3.4e-2, 72: 1.15e-1, 80: 1.5e-1}),
+	"fp8": dict(kind="rel", at={8: 2.7e-3, 16: 6.7e-3, 40: 3.7e-2, 72: 1.26e-1, 80: 1.67e-1}),
+}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"] + (["f16", "fp8w"] if ALL_MODES else []))
+def test_whole_80_step_loop_full_size_in_the_peaked_regime_against_the_reference(golden, dtype):
+	g = golden("stress_diff_cfg1_loop")
+	cfg = W.DIFF_FULL
+	sd = W.stress_diffusion(W.synth_state_dict(W.diffusion_shapes(cfg), 2), cfg)
+	model = build_diff(sd, cfg, dtype)
+	M, T, st = int(g["M"]), int(g["T"]), int(g["stride"])
+	assert T == 1088 and int(g["steps"]) == 80 and tuple(g["checkpoints"]) == STRESS_LOOP_CHECKPOINTS
+	lat = torch.randn(1, M, 1024, generator=gen(31))
+	dcond = torch.randn(1, 2048, generator=gen(32))
+	noise = torch.randn(1, 100, T, generator=gen(34))
+	with torch.inference_mode():      # every mode starts from the oracle's f32 E (equal to the reference's: tests/test_oracle_stress.py), so the LOOP is what is compared
+		Eo = O.DiffusionOracle(sd, cfg).timestep_independent(lat, dcond, T)
+	lo_hi, done = [], 0
+	for n in STRESS_LOOP_CHECKPOINTS:
+		lo_hi.append((80 - n, 80 - done))
+		done = n
+	xs = ddim_chunks(model, noise, Eo, T, 80, lo_hi)
+	b = STRESS_LOOP_BOUNDS[dtype]
+	fn = maxerr if b["kind"] == "abs" else relerr
+	errs, ref16 = {}, {}
+	for n, x in zip(STRESS_LOOP_CHECKPOINTS, xs):
+		want = g["mel"] if n == 80 else g[f"x_after_{n}_sub"]
+		amp = g["mel_ref_fp16mode"] if n == 80 else g[f"x_after_{n}_ref_fp16mode_sub"]
+		errs[n] = fn(x if n == 80 else x[:, :, ::st], want)
+		ref16[n] = relerr(amp, want)
+	record(f"stress_loop_{dtype}", dict(kind=b["kind"], **{str(n): errs[n] for n in STRESS_LOOP_CHECKPOINTS}))
+	record("stress_loop_reference_fp16mode", dict(kind="rel", **{str(n): ref16[n] for n in STRESS_LOOP_CHECKPOINTS}))
+	for n in STRESS_LOOP_CHECKPOINTS:
+		assert errs[n] < b["at"][n], (dtype, n, errs)
+		if dtype in ("bf16", "f16"):
+			assert errs[n] < ref16[n], (dtype, n, errs, ref16)
+	if dtype in ("fp8", "fp8w"):
+		assert errs[80] < 2 * ref16[80], (dtype, errs, ref16)
+	assert torch.isfinite(xs[-1]).all() and xs[-1].abs().max() <= 1.0 + 1e-5
+

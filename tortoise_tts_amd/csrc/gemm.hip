@@ -92,6 +92,9 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 #ifndef TTK_PIPE_D0
 #define TTK_PIPE_D0 6
 #endif
+#ifndef TTK_FP8_SCALED_MFMA
+#define TTK_FP8_SCALED_MFMA 1      // 0: the non-scaled 16x16x32 fp8 MFMA (A/B builds)
+#endif
 #ifndef TTK_ROLE_STAGES
 #define TTK_ROLE_STAGES 3      // ring depth of the 128 x 64 role tiles
 #endif
@@ -310,11 +313,229 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ k = 3 convolution on a SHARED activation image (round 6)
+// The three taps of out_layers.3 multiply the SAME activation rows shifted by -1 / 0 / +1.  The ring kernel stages a 128-row A tile per (tap, k-chunk): 3 x 16 KiB of a
+// k-chunk's 72 KiB are the same bytes.  With the hand-ordered loop the k-loop is bound by what a CU takes in from L2 (no-traffic trip 145 ns, with traffic 315: profiles/
+// r06_ddim_chain_pipe_ablation.log; fetching A for tap 0 only -- TTK_DIAG_SKIP=16 -- took 2.3 us off a launch), so the bytes are worth removing: here a k-chunk's activation
+// rows m0 - 1 .. m0 + BM are staged ONCE as an image of BM + 2 rows (padded to whole 8-row DMA pieces), the taps read their fragments from it at row offsets 0 / 1 / 2 (the
+// swizzle is a function of the image row, so each tap has its own lane address), and only the 8 KiB weight tile changes per trip: 40.6 KiB per k-chunk instead of 72.
+//   LDS: two image slots (k-chunk parity) + a ring of four weight tiles + a 1-KiB dump for the null pieces = 67 KiB for BM = 128 (two workgroups per CU still fit).
+//   Trip t = 3 kc + tap (tap-inner order: see gemm_tile) multiplies tile t from registers, reads tile t + 1's fragments (RPG per MFMA gap), requests weight tile t + 3
+//   and, on tap 2, the image of k-chunk kc + 2 into the slot whose last reads ended with the previous trip.  vmcnt retires in order; behind weight tile t + 1 (what the
+//   reads of trip t need; the image they need is older) the wave has requested, by tap of t: {image, W} / {W, image} / {W} -> the counted waits B_PC + A_PC, A_PC + B_PC, B_PC.
+//   Batch edges: a row whose frame is the first (last) of its batch element must see zeros on tap -1 (+1) although the image holds the neighbouring element's row there
+//   (another row's tap 0 needs it) -- those lanes' A fragments are cleared in registers behind the step's lgkmcnt(0), under a wave-uniform branch only waves with such a row take.
+#ifndef TTK_CONV_IMAGE
+#define TTK_CONV_IMAGE 1
+#endif
+template <typename T, int BM, int NWM, int NWN, int ROLE>
+__device__ __forceinline__ void conv3_image_tile(const GemmParams& p, const int m0, const int n0, const int wave) {
+	typedef GRole<ROLE> R;
+	static_assert(R::on && R::CONV && R::RES && sizeof(T) == 2, "the k = 3 residual role on 16-bit operands");
+	constexpr int ES = 2, BN = 64, KSTEPS = 2, NW = NWM * NWN;
+	constexpr int WM = BM / NWM, WN = BN / NWN, MI = WM / 16, NI = WN / 16;
+	static_assert(MI == 4 && NI == 2, "64 x 32 wave blocks");
+	constexpr int IMG_ROWS = BM + 8, IMG = IMG_ROWS * 128, NPA = IMG_ROWS / 8;      // image row r = activation row m0 - 1 + r; rows 0 .. BM + 1 are read
+	constexpr int A_PC = (NPA + NW - 1) / NW, B_PC = 8 / NW;                         // DMA pieces per wave: per image (the surplus ones are null pieces) / per weight tile
+	constexpr int NB = 4, BT = BN * 128, OFF_B = 2 * IMG, OFF_DUMP = OFF_B + NB * BT;
+	constexpr int KC = GR_K / 64, NM = KSTEPS * MI * NI, NR = KSTEPS * (MI + NI), RPG = TTK_PIPE_RPG, D0 = TTK_PIPE_D0;
+	static_assert(KC % 2 == 0 && (NR + RPG - 1) / RPG <= NM && D0 + B_PC + A_PC <= NM, "reads and DMA pieces must fit the MFMA gaps");
+	constexpr unsigned TAPB = (unsigned)(R::N * GR_K * ES);
+	constexpr int RESN = MI * 4 * NI;
+	constexpr unsigned OOR = 0x80000000u;
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	const int lane = threadIdx.x & 63, g = lane >> 4, l15 = lane & 15;
+#ifdef TTK_STAMPS
+	unsigned long long* const stamps_ = p.stamps;
+#endif
+	const int wm = wave / NWN, wn = wave % NWN;
+	const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+	const int Tb = p.rows_per_batch;
+
+	// fragment addresses: tap s reads image row (row in tile) + s; sub-tile i adds 16 rows = 2048 bytes (an immediate), the image slot IMG bytes (an immediate too)
+	unsigned fa[3][KSTEPS], fb[KSTEPS];
+#pragma unroll
+	for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+		for (int sg = 0; sg < 3; ++sg) {
+			const int r = wm * WM + l15 + sg;
+			fa[sg][ks] = smem_base + r * 128 + (((4 * ks + g) ^ (r & 7)) << 4);
+		}
+		const int rowb = wn * WN + l15;
+		fb[ks] = smem_base + OFF_B + rowb * 128 + (((4 * ks + g) ^ (rowb & 7)) << 4);
+	}
+	// staging offsets
+	const int prow = lane >> 3, pslot = lane & 7;
+	unsigned va[A_PC], vb[B_PC];
+#pragma unroll
+	for (int i = 0; i < A_PC; ++i) {
+		const int q = wave + NW * i, r = 8 * q + prow, gr = m0 - 1 + r;
+		const bool ok = q < NPA && r < BM + 2 && gr >= 0 && gr < p.M;
+		va[i] = ok ? (unsigned)(gr * (GR_K * ES) + ((pslot ^ (r & 7)) << 4)) : OOR;
+	}
+#pragma unroll
+	for (int i = 0; i < B_PC; ++i) {
+		const int row = 8 * (wave + NW * i) + prow;
+		vb[i] = (unsigned)((n0 + row) * (GR_K * ES) + ((pslot ^ (row & 7)) << 4));
+	}
+	const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].A, 0, (unsigned)p.M * (unsigned)(GR_K * ES), 0x00020000);
+	// batch-edge rows of this lane, one bit per sub-tile i
+	int mlo = 0, mhi = 0;
+#pragma unroll
+	for (int i = 0; i < MI; ++i) {
+		const int x = m0 + wm * WM + 16 * i + l15;
+		const int t = x - div_recip(x, Tb, p.inv_rpb) * Tb;
+		mlo |= (t == 0 ? 1 : 0) << i;
+		mhi |= (t == Tb - 1 ? 1 : 0) << i;
+	}
+	const bool any_lo = __builtin_amdgcn_ballot_w64(mlo != 0) != 0, any_hi = __builtin_amdgcn_ballot_w64(mhi != 0) != 0;
+
+	struct PFrags { u32x4 a[KSTEPS][MI], b[KSTEPS][NI]; };
+	f32x4 acc[MI][NI];
+#pragma unroll
+	for (int i = 0; i < MI; ++i)
+#pragma unroll
+		for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+	auto barrier = [&] { TTK_FENCE(); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); TTK_FENCE(); };
+	auto issue_image = [&](auto i_, auto slot_, unsigned kc) {
+		constexpr int i = decltype(i_)::value, slot = decltype(slot_)::value;
+		const int q = wave + NW * i;
+		pipe_glds16(va[i], srdA, kc * 128u, q < NPA ? smem_base + slot * IMG + q * 1024 : smem_base + OFF_DUMP);
+	};
+	auto issue_w = [&](auto i_, unsigned soff, unsigned slot_off) {
+		constexpr int i = decltype(i_)::value;
+		pipe_glds16(vb[i], srdB, soff, smem_base + OFF_B + slot_off + (wave + NW * i) * 1024);
+	};
+	// the fragments of one tile: image slot SLOT, tap S, weight ring slot at byte offset wslot
+	auto read_one = [&](auto r_, auto slot_, auto s_, PFrags& fr, const unsigned (&rb)[KSTEPS]) {
+		constexpr int r = decltype(r_)::value, ks = r / (MI + NI), q = r % (MI + NI), SLOT = decltype(slot_)::value, S = decltype(s_)::value;
+		if constexpr (q < MI) pipe_read16<q * 2048 + SLOT * IMG>(fr.a[ks][q], fa[S][ks]);
+		else pipe_read16<(q - MI) * 2048>(fr.b[ks][q - MI], rb[ks]);
+	};
+	auto clear_edges = [&](auto s_, PFrags& fr) {      // behind the lgkmcnt(0) that landed fr
+		constexpr int S = decltype(s_)::value;
+		if constexpr (S == 0 || S == 2) {
+			if (S == 0 ? any_lo : any_hi) {
+				const int m = S == 0 ? mlo : mhi;
+#pragma unroll
+				for (int i = 0; i < MI; ++i) {
+					const bool z = (m >> i) & 1;
+#pragma unroll
+					for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+						for (int e = 0; e < 4; ++e) fr.a[ks][i][e] = z ? 0u : fr.a[ks][i][e];
+				}
+			}
+			TTK_FENCE();
+		}
+	};
+	int tb = 0;      // (trip index) & 3: the weight ring position
+	// One trip: MFMAs of `cur`; wait + barrier in front (W loads may stay in flight); reads of the next tile (image slot SLOT_RD, tap S_RD) into `nxt`; weight tile t + 3
+	// (tap S_CUR, k-chunk kc_w) and, when IMGI, the image of k-chunk kc_i into slot SLOT_W.
+	auto trip = [&](auto w_, auto rd_, auto slot_rd_, auto s_rd_, auto isw_, auto s_cur_, auto isi_, auto slot_w_, const PFrags& cur, PFrags& nxt, unsigned kc_w, unsigned kc_i) {
+		constexpr int W = decltype(w_)::value, S_CUR = decltype(s_cur_)::value;
+		constexpr bool RD = decltype(rd_)::value, ISW = decltype(isw_)::value, ISI = decltype(isi_)::value;
+		constexpr int PER = (ISW ? B_PC : 0) + (ISI ? A_PC : 0);
+		const unsigned rd_slot = (unsigned)((tb + 1) & 3) * BT, wr_slot = (unsigned)((tb + 3) & 3) * BT;
+		unsigned rb[KSTEPS];
+#pragma unroll
+		for (int ks = 0; ks < KSTEPS; ++ks) rb[ks] = fb[ks] + rd_slot;
+		const unsigned soffW = (unsigned)S_CUR * TAPB + kc_w * 128u;
+		if constexpr (RD || PER > 0) { wait_vmcnt<W>(); barrier(); }
+		static_for<0, NM>([&](auto m_) {
+			constexpr int m = decltype(m_)::value, ks = m / (MI * NI), i = (m % (MI * NI)) / NI, j = m % NI;
+			pipe_mfma<T>(acc[i][j], cur.a[ks][i], cur.b[ks][j]);
+			if constexpr (RD) static_for<0, RPG>([&](auto q_) {
+				constexpr int r = m * RPG + decltype(q_)::value;
+				if constexpr (r < NR) read_one(std::integral_constant<int, r>{}, slot_rd_, s_rd_, nxt, rb);
+			});
+			if constexpr (PER > 0 && m >= D0 && m - D0 < PER) {
+				constexpr int d = m - D0;
+				if constexpr (ISW && d < B_PC) issue_w(std::integral_constant<int, d>{}, soffW, wr_slot);
+				else issue_image(std::integral_constant<int, d - (ISW ? B_PC : 0)>{}, slot_w_, kc_i);
+			}
+		});
+		if constexpr (RD) { pipe_lgkm0(); clear_edges(s_rd_, nxt); }
+		tb = (tb + 1) & 3;
+	};
+	typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2;
+	typedef std::true_type Y; typedef std::false_type N;
+
+	const unsigned m0_keep = pipe_m0_save();
+	// prologue, in the steady state's request order: image 0, weight tiles 0 .. 2, image 1
+	static_for<0, A_PC>([&](auto i_) { issue_image(i_, I0{}, 0u); });
+	static_for<0, 3>([&](auto t_) { static_for<0, B_PC>([&](auto i_) { issue_w(i_, (unsigned)decltype(t_)::value * TAPB, (unsigned)decltype(t_)::value * BT); }); });
+	static_for<0, A_PC>([&](auto i_) { issue_image(i_, I1{}, 1u); });
+	TTK_WSTAMP(stamps_, blockIdx.x, 1);
+	wait_vmcnt<2 * B_PC + A_PC>();      // image 0 and weight tile 0 have landed
+	barrier();
+	TTK_WSTAMP(stamps_, blockIdx.x, 2);
+	PFrags f0, f1;
+	{
+		unsigned rb0[KSTEPS];
+#pragma unroll
+		for (int ks = 0; ks < KSTEPS; ++ks) rb0[ks] = fb[ks];
+		static_for<0, NR>([&](auto r_) { read_one(r_, I0{}, I0{}, f0, rb0); });
+	}
+	pipe_lgkm0();
+	clear_edges(I0{}, f0);
+#ifdef TTK_CLOCK_STAMPS
+	const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+	typedef std::integral_constant<int, B_PC + A_PC> W01; typedef std::integral_constant<int, B_PC> W2;
+	// six trips per round: k-chunks kc (image slot 0) and kc + 1 (slot 1); tile t lives in f[t & 1]
+	// arguments of trip: wait count, reads?, image slot / tap of the tile read, weight tile requested?, tap of the current tile (= of the weight tile requested), image requested?, its slot
+	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
+	float res_pre[MI][4][NI];
+	for (int kc = 0; kc < KC - 2; kc += 2) {
+		trip(W01{}, Y{}, I0{}, I1{}, Y{}, I0{}, N{}, I0{}, f0, f1, (unsigned)kc + 1, 0u);
+		trip(W01{}, Y{}, I0{}, I2{}, Y{}, I1{}, N{}, I0{}, f1, f0, (unsigned)kc + 1, 0u);
+		trip(W2{}, Y{}, I1{}, I0{}, Y{}, I2{}, Y{}, I0{}, f0, f1, (unsigned)kc + 1, (unsigned)kc + 2);
+		trip(W01{}, Y{}, I1{}, I1{}, Y{}, I0{}, N{}, I1{}, f1, f0, (unsigned)kc + 2, 0u);
+		trip(W01{}, Y{}, I1{}, I2{}, Y{}, I1{}, N{}, I1{}, f0, f1, (unsigned)kc + 2, 0u);
+		trip(W2{}, Y{}, I0{}, I0{}, Y{}, I2{}, Y{}, I1{}, f1, f0, (unsigned)kc + 2, (unsigned)kc + 3);
+	}
+	{	// the last two k-chunks (KC - 2, KC - 1): no image left to request, weight tiles up to NT - 1 = (KC - 1, tap 2); the residual tile is requested behind the last of them
+		constexpr unsigned kc = KC - 2;
+		trip(W01{}, Y{}, I0{}, I1{}, Y{}, I0{}, N{}, I0{}, f0, f1, kc + 1, 0u);
+		trip(W01{}, Y{}, I0{}, I2{}, Y{}, I1{}, N{}, I0{}, f1, f0, kc + 1, 0u);
+		trip(W2{}, Y{}, I1{}, I0{}, Y{}, I2{}, N{}, I0{}, f0, f1, kc + 1, 0u);
+		if (m0 + BM <= p.M) load_residual_role<ROLE, MI, NI, false>(p, res_pre, row0, col0, lane);
+		else load_residual_role<ROLE, MI, NI, true>(p, res_pre, row0, col0, lane);
+		asm volatile("" ::: "memory");
+		TTK_FENCE();
+		trip(std::integral_constant<int, B_PC + RESN>{}, Y{}, I1{}, I1{}, N{}, I0{}, N{}, I1{}, f1, f0, 0u, 0u);      // weight tile NT - 2 has landed; NT - 1 and the residual may be in flight
+		trip(std::integral_constant<int, RESN>{}, Y{}, I1{}, I2{}, N{}, I1{}, N{}, I1{}, f0, f1, 0u, 0u);              // weight tile NT - 1 has landed
+		trip(I0{}, N{}, I0{}, I0{}, N{}, I2{}, N{}, I0{}, f1, f0, 0u, 0u);                                            // the last tile's MFMAs
+	}
+	pipe_m0_restore(m0_keep);
+#ifdef TTK_CLOCK_STAMPS
+	if (stamps_ && lane == 0) {
+		unsigned long long* st_ = stamps_ + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
+		st_[6] = ((__builtin_amdgcn_s_memtime() - clk0_) << 32) | ((__builtin_amdgcn_s_memrealtime() - rt0_) & 0xffffffffull);
+	}
+#endif
+	TTK_WSTAMPD(stamps_, blockIdx.x, 3, acc[0][0][0]);
+	if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI, true>(p, acc, res_pre, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI, true>(p, acc, res_pre, row0, col0, lane);
+	TTK_WSTAMP(stamps_, blockIdx.x, 4);
+#if defined(TTK_STAMPS) && TTK_STAMPS == 2
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	TTK_WSTAMP(stamps_, blockIdx.x, 5);
+#endif
+}
+
 // One output tile [m0, m0 + BM) x [n0, n0 + BN): operand staging, the k-loop and the epilogue.  `wave` = this wave's index among the NWM x NWN waves of the tile.
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, const int wave) {
 	typedef GRole<ROLE> R;
 	static_assert(!R::on || (sizeof(T) <= 2 && R::N % BN == 0), "roles are 16-bit or fp8, N a multiple of the tile width");
+	constexpr int LDS_AVAIL = NSTAGE * ((BM == 64 && NWM == 1 ? 128 : BM) + BN) * 128;      // (the 64-row half tiles exist only inside k_gemm_mixed, whose launch is sized for its 128-row tiles)
+	if constexpr (TTK_CONV_IMAGE && R::on && R::CONV && sizeof(T) == 2 && BN == 64 && NWN == 2 && BM / NWM == 64 && LDS_AVAIL >= 2 * (BM + 8) * 128 + 4 * 8192 + 1024) {
+		conv3_image_tile<T, BM, NWM, NWN, ROLE>(p, m0, n0, wave);      // the k = 3 residual convolution on 128 x 64 / 64 x 64 tiles: shared activation image
+		return;
+	}
 	constexpr int ES = sizeof(T);
 	constexpr bool F8 = ES == 1;       // fp8 operands: a lane's 16-byte read feeds two 16x16x32 MFMAs (k order is free as long as A and W agree)
 	constexpr int BKE = 128 / ES;      // K elements per tile row
@@ -364,18 +585,41 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	__amdgpu_buffer_rsrc_t srdA = srdB;
 	unsigned b_seg_off = 0;
 	int seg_i = 0, kk_i = 0;
-	auto set_segment = [&](int sg) {
-		if constexpr (R::on) {      // one activation tensor; a convolution's taps are its rows shifted by -1 / 0 / +1 against consecutive [N][K] matrices
-			const int shift = R::CONV ? sg - 1 : 0;
-			if (sg == 0) srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].A, 0, (unsigned)p.M * (unsigned)(GR_K * ES), 0x00020000);
-			b_seg_off = (unsigned)sg * (unsigned)(R::N * GR_K * ES);
+	// Tile order of a multi-segment GEMM.  The k = 3 convolutions of the DDIM loop (the CONV role and the generic kernel on the same shape, p.seg_inner) run TAP-INNER since
+	// round 6: k-chunk 0 of taps -1 / 0 / +1, then k-chunk 1 of the three taps, ... -- the order in which a staged activation image serves all three taps (conv3_image_tile
+	// below), and every other tiling of the same convolution must add its products in that order too (a sequence gives the same bits whatever tile shape its batch selects).
+	// Everything else keeps segment-major order (all of segment 0's k, then segment 1's ...).
+	const bool seg_in = R::on ? R::CONV : (p.seg_inner != 0);
+	const int NSEG = R::on ? R::NSEG : p.nseg;
+	unsigned va3[R::CONV ? 3 : 1][A_PC];      // the CONV role: the three taps' staging offsets, computed once
+	if constexpr (R::on && R::CONV) {
+#pragma unroll
+		for (int sg = 0; sg < 3; ++sg)
 #pragma unroll
 			for (int i = 0; i < A_PC; ++i) {
 				const int row = 8 * (wave + NW * i) + prow;
 				const int c = pslot ^ (row & 7);
-				const int t = a_t[i] + shift;
-				const bool ok = a_gm[i] < p.M && (!R::CONV || (t >= 0 && t < p.rows_per_batch));
-				va[i] = ok ? (unsigned)((a_gm[i] + shift) * (GR_K * ES) + c * 16) : OOR;
+				const int t = a_t[i] + sg - 1;
+				const bool ok = a_gm[i] < p.M && t >= 0 && t < p.rows_per_batch;
+				va3[sg][i] = ok ? (unsigned)((a_gm[i] + sg - 1) * (GR_K * ES) + c * 16) : OOR;
+			}
+		srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].A, 0, (unsigned)p.M * (unsigned)(GR_K * ES), 0x00020000);
+	}
+	auto set_segment = [&](int sg) {
+		if constexpr (R::on && R::CONV) {      // one activation tensor, its rows shifted by -1 / 0 / +1 against consecutive [N][K] matrices
+			b_seg_off = (unsigned)sg * (unsigned)(R::N * GR_K * ES);
+#pragma unroll
+			for (int i = 0; i < A_PC; ++i) va[i] = sg == 0 ? va3[0][i] : (sg == 1 ? va3[1][i] : va3[2][i]);
+			return;
+		}
+		if constexpr (R::on) {
+			srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].A, 0, (unsigned)p.M * (unsigned)(GR_K * ES), 0x00020000);
+			b_seg_off = 0;
+#pragma unroll
+			for (int i = 0; i < A_PC; ++i) {
+				const int row = 8 * (wave + NW * i) + prow;
+				const int c = pslot ^ (row & 7);
+				va[i] = a_gm[i] < p.M ? (unsigned)(a_gm[i] * (GR_K * ES) + c * 16) : OOR;
 			}
 			return;
 		}
@@ -392,8 +636,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 			va[i] = ok ? (unsigned)(((int64_t)(a_gm[i] + shift) * lda + c * EPC) * ES) : OOR;
 		}
 	};
-	auto issue = [&](int stage) {   // requests the next tile in (segment, k) order
-		if (kk_i == 0) set_segment(seg_i);
+	auto next_tile = [&] {
+		if (seg_in) { if (++seg_i == NSEG) { seg_i = 0; ++kk_i; } }
+		else if (++kk_i == KT) { kk_i = 0; ++seg_i; }
+	};
+	auto issue = [&](int stage) {   // requests the next tile of the order above
+		if (seg_in || kk_i == 0) set_segment(seg_i);
 		const unsigned As = smem_base + stage * STAGE;
 		const unsigned Bs = As + BM * 128;
 		const unsigned soffA = (unsigned)kk_i * 128u, soffB = b_seg_off + (unsigned)kk_i * 128u;
@@ -412,7 +660,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 #endif
 			glds16(vb[i], srdB, soffB, Bs + (wave + NW * i) * 1024);
 		}
-		if (++kk_i == KT) { kk_i = 0; ++seg_i; }
+		next_tile();
 	};
 
 	f32x4 acc[MI][NI];
@@ -458,14 +706,14 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 		bool p_skipA = false, p_skipB = false;
 #endif
 		auto issue_prep = [&](unsigned stage_off) {   // the next tile in (segment, k) order goes to the stage at byte offset stage_off
-			if (kk_i == 0) set_segment(seg_i);
+			if (seg_in || kk_i == 0) set_segment(seg_i);
 #ifdef TTK_DIAG_SKIP
 			p_skipA = ((TTK_DIAG_SKIP & 1) && (seg_i > 0 || kk_i > 1)) || ((TTK_DIAG_SKIP & 16) && seg_i > 0);
 			p_skipB = (TTK_DIAG_SKIP & 2) && (seg_i > 0 || kk_i > 1);
 #endif
 			pA_dst = smem_base + stage_off; pB_dst = pA_dst + BM * 128;
 			p_soffA = (unsigned)kk_i * 128u; p_soffB = b_seg_off + (unsigned)kk_i * 128u;
-			if (++kk_i == KT) { kk_i = 0; ++seg_i; }
+			next_tile();
 		};
 		auto issue_piece = [&](auto d_) {
 			constexpr int d = decltype(d_)::value;
@@ -588,10 +836,28 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 		// Fragment registers of one k-tile (all k-steps), two sets used ping-pong: the ds_reads of tile k+1 are in flight under the
 		// MFMAs of tile k (with one wave per SIMD nothing else hides the ~130-cycle LDS latency; measured 735 cycles per k-tile for
 		// 256 cycles of MFMA before this).  Named structs + a 2x unrolled loop: an indexed array of register sets would go to scratch.
-		struct Frags { uint4 a[KSTEPS][MI][FCH]; uint4 b[KSTEPS][NI][FCH]; };
+		typedef int i32x4 __attribute__((ext_vector_type(4)));
+		typedef int i32x8 __attribute__((ext_vector_type(8)));
+		struct Frags { uint4 a[F8 ? 1 : KSTEPS][F8 ? 1 : MI][FCH]; uint4 b[F8 ? 1 : KSTEPS][F8 ? 1 : NI][FCH]; i32x8 a8[F8 ? MI : 1], b8[F8 ? NI : 1]; };
 		auto read_frags = [&](Frags& fr, int stage) {
 			const char* As = smem + stage * STAGE;
 			const char* Bs = As + BM * 128;
+			if constexpr (F8) {      // a lane's 32 operand bytes of the 128-deep k-tile: chunks g and 4 + g of its row, joined into the instruction's 8-dword operand
+				const int g = lane >> 4;
+	#pragma unroll
+				for (int i = 0; i < MI; ++i) {
+					const int row = wm * WM + 16 * i + (lane & 15);
+					const i32x4 lo = *(const i32x4*)(As + row * 128 + ((g ^ (row & 7)) << 4)), hi = *(const i32x4*)(As + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+					fr.a8[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+				}
+	#pragma unroll
+				for (int j = 0; j < NI; ++j) {
+					const int row = wn * WN + 16 * j + (lane & 15);
+					const i32x4 lo = *(const i32x4*)(Bs + row * 128 + ((g ^ (row & 7)) << 4)), hi = *(const i32x4*)(Bs + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+					fr.b8[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+				}
+				return;
+			}
 	#pragma unroll
 			for (int ks = 0; ks < KSTEPS; ++ks) {
 				const int c0 = F8 ? 4 * ks + (lane >> 4) : (ks * 32 + 8 * (lane >> 4)) / EPC;
@@ -610,6 +876,26 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 			}
 		};
 		auto mfma_tile = [&](const Frags& fr) {
+			if constexpr (F8) {
+				// fp8 operands: ONE block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 per sub-tile and 128-deep k-tile (round 6; unit E8M0 scales: the weights' power-of-two tensor
+				// scale stays in the epilogue).  It takes twice the cycles of a 16x16x32 instruction for four times the K: the non-scaled fp8 form this loop ran before runs at
+				// the BF16 rate, so the MFMA phase of a trip halves (MI355X_MICROARCH.md, matrix-core table).  A lane's 32 operand bytes are its two 16-byte reads (chunks g and
+				// 4 + g of the row); the instruction's own k position of each byte does not matter as long as A and W use the same one, which the identical staging guarantees.
+	#pragma unroll
+				for (int i = 0; i < MI; ++i)
+	#pragma unroll
+					for (int j = 0; j < NI; ++j) {
+	#if TTK_FP8_SCALED_MFMA
+						acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fr.a8[i], fr.b8[j], acc[i][j], 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+	#else
+						typedef long l64x4 __attribute__((ext_vector_type(4)));
+						const l64x4 la = (l64x4)fr.a8[i], lb = (l64x4)fr.b8[j];
+	#pragma unroll
+						for (int q = 0; q < 4; ++q) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(la[q], lb[q], acc[i][j], 0, 0, 0);
+	#endif
+					}
+				return;
+			}
 	#pragma unroll
 			for (int ks = 0; ks < KSTEPS; ++ks)
 	#pragma unroll
@@ -954,6 +1240,7 @@ void launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
 	if (order == 1) p.m_major = p.nseg == 1 && (int64_t)p.N < p.M;
 	else if (order == 2) p.m_major = (int64_t)p.N * p.nseg < p.M;
 	else if (order == 3) p.m_major = 1;
+	p.seg_inner = gemm_role_of_unmasked(p, dt == DT_FP8 ? 1 : (dt == DT_F32 ? 4 : 2)) == GR_CONV3_RES;      // (whether or not the role kernels are switched on: same order, same bits)
 	hipEvent_t ea = nullptr, eb = nullptr;      // kernel start / stop timestamps when profiling (prof_pair)
 	if (g_prof_on) prof_pair(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, &ea, &eb);
 	if (dt == DT_FP8) launch_gemm_t<f8>(p, s, ea, eb);          // A and W are fp8-e4m3 bytes, K % 128 == 0
