@@ -623,6 +623,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 			}
 			return;
 		}
+		sg = __builtin_amdgcn_readfirstlane(sg);      // (wave-uniform by construction; said explicitly so that the descriptor is built in scalar registers -- the DMA instruction takes it from there only)
 		const int64_t lda = p.seg[sg].lda;
 		const int shift = p.seg[sg].shift;
 		srdA = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[sg].A, 0, (unsigned)((int64_t)p.M * lda * ES), 0x00020000);
@@ -639,6 +640,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	auto next_tile = [&] {
 		if (seg_in) { if (++seg_i == NSEG) { seg_i = 0; ++kk_i; } }
 		else if (++kk_i == KT) { kk_i = 0; ++seg_i; }
+		seg_i = __builtin_amdgcn_readfirstlane(seg_i); kk_i = __builtin_amdgcn_readfirstlane(kk_i);      // (wave-uniform by construction; said explicitly: the DMA instruction takes its k offset and descriptor from scalar registers only)
 	};
 	auto issue = [&](int stage) {   // requests the next tile of the order above
 		if (seg_in || kk_i == 0) set_segment(seg_i);
@@ -1145,7 +1147,7 @@ static int gemm_role_of(const GemmParams& p, int es) {
 static int gemm_role_of_unmasked(const GemmParams& p, int es) {
 	if (g_gemm_roles < 0) gemm_roles_refresh();
 	// (fp8 operands, es == 1: the same roles with the weights' tensor scale in the epilogue; 16-bit launches carry no scale)
-	if (!g_gemm_roles || (es != 2 && es != 1) || p.K != GR_K || p.ldw != GR_K || !p.bias || p.act != ACT_NONE || (es == 2) != (p.out_scale == 0.f) || p.transpose_out || p.m_major) return GR_NONE;
+	if ((es != 2 && es != 1) || p.K != GR_K || p.ldw != GR_K || !p.bias || p.act != ACT_NONE || (es == 2) != (p.out_scale == 0.f) || p.transpose_out || p.m_major) return GR_NONE;
 	if (p.M < 1 || p.M > (1 << 19) || p.seg[0].lda != GR_K || p.seg[0].w_off != 0) return GR_NONE;      // 32-bit byte offsets and M * N < 2^30 element indices
 	if (p.nseg == 1 && p.seg[0].shift == 0) {
 		if (p.N == 3072 && !p.out_f32 && p.ldc == 3072 && !p.residual && !p.gn_part) return GR_QKV;
@@ -1240,7 +1242,10 @@ void launch_gemm(int dt, const GemmParams& p_in, hipStream_t s) {
 	if (order == 1) p.m_major = p.nseg == 1 && (int64_t)p.N < p.M;
 	else if (order == 2) p.m_major = (int64_t)p.N * p.nseg < p.M;
 	else if (order == 3) p.m_major = 1;
-	p.seg_inner = gemm_role_of_unmasked(p, dt == DT_FP8 ? 1 : (dt == DT_F32 ? 4 : 2)) == GR_CONV3_RES;      // (whether or not the role kernels are switched on: same order, same bits)
+	// every k = 3 'same' convolution (taps -1 / 0 / +1 of ONE activation tensor) runs tap-inner, whatever its shape, epilogue or kernel: the order must be a property of the
+	// convolution, not of the launch -- a sequence alone (generic kernel, separate statistics launch) and inside a ragged batch (CONV role) has to give the same bits
+	p.seg_inner = p.nseg == 3 && p.seg[0].shift == -1 && p.seg[1].shift == 0 && p.seg[2].shift == 1 && p.seg[1].A == p.seg[0].A && p.seg[2].A == p.seg[0].A &&
+				  p.seg[1].lda == p.seg[0].lda && p.seg[2].lda == p.seg[0].lda;
 	hipEvent_t ea = nullptr, eb = nullptr;      // kernel start / stop timestamps when profiling (prof_pair)
 	if (g_prof_on) prof_pair(PROF_GEMM, 2.0 * p.M * p.N * (double)p.K * p.nseg, &ea, &eb);
 	if (dt == DT_FP8) launch_gemm_t<f8>(p, s, ea, eb);          // A and W are fp8-e4m3 bytes, K % 128 == 0

@@ -64,7 +64,7 @@ struct GemmParams {
 	int transpose_out;  // C is f32 [M / rows_per_batch][N][rows_per_batch]
 	// optional fused GroupNorm32 statistics of the f32 output (see gemm_fuses_gn_stats): part[b][32][gn_T / 64][3]
 	int gn_T; float* gn_part;
-	int seg_inner;      // set by launch_gemm: the segments are the taps of a k = 3 convolution of a role shape -- tile order tap-inner (k-chunk 0 of every tap, k-chunk 1 ...), as the CONV role runs it
+	int seg_inner;      // set by launch_gemm: the segments are the taps -1 / 0 / +1 of a k = 3 convolution over one tensor -- tile order tap-inner (k-chunk 0 of every tap, k-chunk 1 ...), as the CONV role runs it
 	int m_major;        // XCD-aware tile order: 0 = each XCD gets a few n-tiles x all m-tiles (its L2 keeps a weight slice), 1 = a few m-tiles x all n-tiles
 	// filled by launch_gemm for the role-specialised instantiations (GemmRole): reciprocals that replace the kernel's run-time integer divisions
 	// (x / d as an f32 product + one correction step, exact for x < 2^23) -- by the m-tile count, rows_per_batch and gn_T
