@@ -127,7 +127,7 @@ def test_free_running_ids_f32_under_the_cli_warpers(golden, variant, hf_exact):
 	free-running f32 ids equal the oracle's own loop bit for bit -- the oracle's CPU-generator ids are the reference's (tests/test_oracle_stress.py), here it
 	samples on the device so both sides consume the same Philox stream.  With `hf_exact_top_p` the cumulative-mass warpers run as HF's torch ops in front of the
 	kernel, without it inside the kernel (exact fixed-point masses): both must give the oracle's ids.  The folded LayerNorm's health word stays silent: outlier
-	channels inflate the row's std with them (|mean| / std <= sqrt(2 / d)), which the fold carries."""
+	channels inflate the row's std with them (|mean| / std <= sqrt(2 / d)), which the fold carries (docs/history/r03.md)."""
 	g = golden("stress_ar")
 	cfg = W.AR_SMALL
 	sd = ar_sd(variant)
