@@ -135,8 +135,8 @@ def phase_roofline(marks_per_line, dtype_name, n_text=TEXT_TOKENS, n_cand=CANDID
 	token + the KV cache read), the latent pass and the DDIM loop are MFMA-bound.  `marks_per_line`: one list of (name, event) pairs per text
 	line, from TTSHotPath.inference(phase_marks=...) / inference_sharded(phase_marks=...) of one step run exactly as the timed ones (captured
 	graph, no instrumentation); n_cand = candidates decoded on THIS GPU.  Peaks: 8 TB/s HBM; dense MFMA 2.5 PFLOP/s bf16 / f16, 157.3 TFLOP/s
-	f32; dtype fp8: the DDIM loop is graded against the 5 PFLOP/s fp8 peak (its ResBlock / AttentionBlock projection GEMMs run the fp8 MFMA; QK^T, PV
-	and the remaining convs run bf16 -- the stricter denominator is used for the whole phase), the latent pass against 2.5 (the AR handle's fp8 is
+	f32; dtype fp8: the DDIM loop is graded against the 5 PFLOP/s fp8 peak (its ResBlock convolutions and proj_out run the block-scaled 16x16x128 fp8 MFMA, the instruction that
+	reaches that peak; q / k / v, QK^T, PV and the remaining convs run bf16 -- the stricter denominator is used for the whole phase), the latent pass against 2.5 (the AR handle's fp8 is
 	fp8 WEIGHTS on the bf16 MFMA)."""
 	ms = {}
 	for marks in marks_per_line:
@@ -295,7 +295,7 @@ def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL
 	peak_blk = 5.0e15 if dtype_name == "fp8" else peak
 	gn = M * d * (4 + e_blk) / 256 / CU_L2_INTAKE * 1e6
 	res = 2 * gn + _g(M, d, d, 1, e_blk, peak_blk) + _g(M, d, d, 3, e_blk, peak_blk) + 4 * BOUNDARY_US
-	att = gn + _g(M, 3 * d, d, 1, e_blk, peak_blk) + 2.0 * 2 * T * T * d * 2 / peak * 1e6 + _g(M, d, d, 1, e_blk, peak_blk) + 4 * BOUNDARY_US
+	att = gn + _g(M, 3 * d, d, 1, e, peak) + 2.0 * 2 * T * T * d * 2 / peak * 1e6 + _g(M, d, d, 1, e_blk, peak_blk) + 4 * BOUNDARY_US      # (the q / k / v projection keeps 16-bit operands in the fp8 modes)
 	other = 8 * BOUNDARY_US + _g(M, d, 100, 3, e, peak) + _g(M, d, 2 * d, 1, e, peak) + _g(M, 200, d, 3, e, peak) + gn
 	step_us = 16 * res + 13 * att + other
 	step_launches = 16 * 4 + 13 * 4 + 8
@@ -842,11 +842,11 @@ def main():
 					"small_models": bool(a.small), "vocoder_in_step": bool(a.with_vocoder)}
 		if a.dtype in ("fp8", "fp8w"):      # BASELINE config 5: say exactly which contractions are fp8
 			cfg_line["workload"] += ("; config 5 arithmetic: " + (
-				"diffusion ResBlock / AttentionBlock projection GEMMs on v_mfma_f32_16x16x32_fp8_fp8 (e4m3 weights x power-of-two tensor scale, e4m3 activations); "
-				"QK^T / PV, the k=3 input/output convs and the time-embedding linears on the bf16 MFMA; autoregressive side: fp8 WEIGHT bytes widened next to the bf16 MFMA "
-				"(16-row GEMVs), bf16 KV cache" if a.dtype == "fp8" else
-				"fp8-e4m3 block-GEMM WEIGHTS in both networks (power-of-two tensor scale), every contraction on the bf16 MFMA"))
-			cfg_line["fp8_contractions"] = "diffusion block projection GEMMs" if a.dtype == "fp8" else "none (weights only)"
+				"diffusion ResBlock convolutions (in_layers.2, out_layers.3) and AttentionBlock proj_out on the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 scales "
+				"(e4m3 weights x power-of-two tensor scale in the epilogue, e4m3 activations); the q / k / v projection, QK^T / PV, the k=3 input/output convs and the time-embedding "
+				"linears on the bf16 MFMA; autoregressive side: fp8 WEIGHT bytes widened next to the bf16 MFMA (16-row GEMVs), bf16 KV cache" if a.dtype == "fp8" else
+				"fp8-e4m3 block-GEMM WEIGHTS in both networks (power-of-two tensor scale; the diffusion q / k / v projection keeps bf16 weights), every contraction on the bf16 MFMA"))
+			cfg_line["fp8_contractions"] = "diffusion ResBlock convolutions + proj_out (scaled 16x16x128 MFMA)" if a.dtype == "fp8" else "none (weights only)"
 			cfg_line["ar_handle_dtype"] = "fp8w"
 		if by_cand:
 			cfg_line = {"workload": f"configs[3]: one long-form utterance = 2 lines x 256 text tokens, {n_cand * world} AR candidates ({n_cand} per GPU) x 500 mel "

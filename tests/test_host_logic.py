@@ -202,26 +202,36 @@ def test_bench_phase_roofline_counts_the_work_of_the_configuration_it_is_given()
 
 
 def test_bench_effective_floor_follows_its_stated_formula():
-	"""`roofline.phases.*.effective_floor_ms` = sum over dependent launches of [boundary + max(hbm bytes / 6.4 TB/s, bytes per CU / 68 GB/s, flop / peak)]
-	from the guide's constants; reported next to the spec-peak fractions.  The launch lists and a few hand-computed terms are pinned here."""
+	"""`roofline.phases.*.effective_floor_ms` = sum over dependent launches of [boundary + max(hbm bytes / 6.4 TB/s, flop / peak; a GEMM: the MFMA
+	phase of its tile at the in-kernel clock, bytes per CU / (L2 intake per clock x clock), staged bytes / the chip's L2 bandwidth)] -- hardware rates only since round 6; round 5's
+	pricing of the k-loops (68 GB/s per CU, read off this implementation) stays one round as `launch_chain_model`.  The launch lists and a few hand-computed terms are pinned here."""
 	import bench
 	assert (bench.BOUNDARY_US, bench.HBM_STREAM, bench.CU_L2_INTAKE) == (1.45, 6.4e12, 68e9)
+	assert (bench.CLOCK_HZ, bench.CU_INTAKE_BPC, bench.L2_CHIP) == (2.3e9, {4: 59.0, 8: 72.0}, 34.5e12)
 	e = bench.effective_floor("bf16")
-	assert e["launches"] == {"decode_token": 152, "ddim_step": 124}
+	c = bench.effective_floor("bf16", model="launch_chain")
+	assert e["launches"] == c["launches"] == {"decode_token": 152, "ddim_step": 124}
 	# one decode token at context c: 152 boundaries + (block weights + head + KV cache of 16 candidates + logits) / 6.4 TB/s
 	P1 = 68
 	want = 0.0
 	for k in range(1, 250):
 		hbm = 377_886_720 * 2 + (8_398_850 + 4_096) * 2 + 16 * 30 * 2 * (P1 + k) * 1024 * 2 + 16 * 8194 * 4
 		want += 152 * 1.45 + hbm / 6.4e12 * 1e6
-	assert want * 1e-3 + 0.5 < e["ar_decode_ms"] < want * 1e-3 + 1.5                     # + the prefill's dense pass over 68 rows
-	# the 1x1 conv of a DDIM step: 2176 x 1024 x 1024 -> 272 tiles of 128 x 64, 1.0625 rounds x 192 rows x 1024 x 2 B per CU at 68 GB/s
+	assert want * 1e-3 + 0.2 < e["ar_decode_ms"] < want * 1e-3 + 1.5                     # + the prefill's dense pass over 68 rows
+	# the 1x1 conv of a DDIM step: 2176 x 1024 x 1024 -> 272 tiles of 128 x 64 on 4 waves, 1.0625 rounds: intake 192 rows x 1024 x 2 B per CU at 59 B/clk x 2.3 GHz (the largest of the
+	# three terms: MFMA phase 1.0625 x 2 x 128 x 64 x 1024 / (2.5e15 / 256) x 2.4 / 2.3 = 1.9 us, chip L2 272 x 393216 B / 34.5 TB/s = 3.1 us)
 	g = bench._gemm_floor_us(2176, 1024, 1024, 1, 2, 2.5e15)
-	assert abs(g - (272 / 256) * 192 * 1024 * 2 / 68e9 * 1e6) < 1e-9 and 6.0 < g < 6.3
-	assert abs(bench._gemm_floor_us(2176, 1024, 1024, 3, 2, 2.5e15) - 3 * g) < 1e-9       # the k = 3 conv stages three taps
-	q = bench._gemm_floor_us(2176, 3072, 1024, 1, 2, 2.5e15)                              # QKV: 408 tiles of 128 x 128 -> 216 of 256 x 128, one round
-	assert abs(q - 384 * 1024 * 2 / 68e9 * 1e6) < 1e-9
-	assert 880 < e["ddim_step_us"] < 950 and abs(e["ddim_ms"] - (80 * e["ddim_step_us"]) * 1e-3) < 0.2
+	intake = (272 / 256) * 192 * 1024 * 2 / (59.0 * 2.3e9) * 1e6
+	l2 = 272 * 192 * 1024 * 2 / 34.5e12 * 1e6
+	assert abs(g - max(intake, l2)) < 1e-9 and 3.0 < g < 3.2
+	assert abs(bench._gemm_floor_us(2176, 1024, 1024, 3, 2, 2.5e15) - 3 * g) < 1e-9       # the k = 3 conv priced as three taps' bytes (the shared image of round 6 stages fewer: the floor is not lowered for it)
+	q = bench._gemm_floor_us(2176, 3072, 1024, 1, 2, 2.5e15)                              # QKV: 408 tiles of 128 x 128 -> 216 of 256 x 128, one round, MFMA-phase-bound
+	assert abs(q - 2.0 * 256 * 128 * 1024 / (2.5e15 / 256) * (2.4 / 2.3) * 1e6) < 1e-9 and 7.0 < q < 7.3
+	# the launch-chain model is round 5's formula, unchanged
+	gc = bench._gemm_floor_us(2176, 1024, 1024, 1, 2, 2.5e15, "launch_chain")
+	assert abs(gc - (272 / 256) * 192 * 1024 * 2 / 68e9 * 1e6) < 1e-9 and 6.0 < gc < 6.3
+	assert abs(bench._gemm_floor_us(2176, 3072, 1024, 1, 2, 2.5e15, "launch_chain") - 384 * 1024 * 2 / 68e9 * 1e6) < 1e-9
+	assert 880 < c["ddim_step_us"] < 950 and 560 < e["ddim_step_us"] < 660 and abs(e["ddim_ms"] - (80 * e["ddim_step_us"]) * 1e-3) < 0.2
 	f8 = bench.effective_floor("fp8")
 	assert f8["ddim_ms"] < e["ddim_ms"] and f8["ar_decode_ms"] < e["ar_decode_ms"] and f8["latent_pass_ms"] == e["latent_pass_ms"]
 	big = bench.effective_floor("bf16", 256, 32, 500, 200, 2, 1)
@@ -234,6 +244,7 @@ def test_bench_effective_floor_follows_its_stated_formula():
 	ph = bench.phase_roofline([marks], "bf16")
 	for k in ("ar_decode", "latent_pass", "ddim"):
 		assert 0 < ph[k]["frac"] < ph[k]["frac_of_effective_floor"] < 1 and ph[k]["effective_floor_ms"] > ph[k]["floor_ms"]
+		assert ph[k]["effective_floor_ms"] <= ph[k]["launch_chain_model_ms"] and "frac_of_launch_chain_model" in ph[k]
 	assert abs(ph["whole_step_effective_floor_ms"] - (e["ar_decode_ms"] + e["latent_pass_ms"] + e["ddim_ms"])) < 1e-9
 	assert ph["effective_floor"]["constants"]["boundary_us"] == 1.45 and "formula" in ph["effective_floor"]
 

@@ -95,6 +95,9 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 #ifndef TTK_FP8_SCALED_MFMA
 #define TTK_FP8_SCALED_MFMA 1      // 0: the non-scaled 16x16x32 fp8 MFMA (A/B builds)
 #endif
+#ifndef TTK_GEMM_PIPE_H
+#define TTK_GEMM_PIPE_H 1   // the half-tile form of the hand-ordered loop for 64 x 64 wave blocks
+#endif
 #ifndef TTK_ROLE_STAGES
 #define TTK_ROLE_STAGES 3      // ring depth of the 128 x 64 role tiles
 #endif
@@ -687,7 +690,91 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	// 256 registers -- the allocator spills, and a spill between two asm statements may move a fragment before its data has landed; f32 / fp8 operands and the other ring
 	// depths keep the compiler's order as well
 	constexpr bool PIPE = TTK_GEMM_PIPE && ES == 2 && (NSTAGE == 3 || (R::on && NSTAGE > 3 && NSTAGE <= 6)) && MI * NI <= 8;
-	if constexpr (PIPE) {
+	// 64 x 64 wave blocks (the 256 x 128 tile of the q / k / v projection): the same hand-ordered stream at HALF-tile granularity -- a fragment set holds ONE k-step (32 registers),
+	// so two sets fit beside the 64 accumulators.  Half-step H0 of tile kt multiplies its k-step 0 (set f0) while k-step 1 of the SAME tile is read into f1 (no barrier: the tile
+	// has landed); H1 waits for tile kt + 1, passes the barrier (every wave's reads of tile kt ended with H0), multiplies k-step 1 while k-step 0 of tile kt + 1 is read into f0,
+	// and requests tile kt + NSTAGE into the stage tile kt has left.  Same MFMA order per accumulator (k-step 0, then 1): same bits.
+	constexpr bool PIPE_H = TTK_GEMM_PIPE_H && ES == 2 && NSTAGE == 3 && R::on && !R::RES && MI * NI == 16 && KSTEPS == 2;      // (the residual roles keep the compiler-ordered loop at this tile: their epilogue needs 64 more registers and the allocator spills inside the hand-ordered stream)
+	if constexpr (PIPE_H) {
+		constexpr int NM = MI * NI, NR = MI + NI, D0 = NM - PER_TILE - 1;      // 16 MFMAs, 8 reads (one per gap from the first), the DMA pieces in the last gaps
+		static_assert(NR <= NM && D0 >= 0, "reads and DMA pieces must fit the gaps of a half-step");
+		constexpr int NT = R::NSEG * (GR_K / BKE);
+		static_assert(NT > NSTAGE, "the ring is deeper than the k-loop");
+		struct HFrags { u32x4 a[MI], b[NI]; };
+		unsigned fa[KSTEPS], fb[KSTEPS];
+#pragma unroll
+		for (int ks = 0; ks < KSTEPS; ++ks) {
+			const int c0 = 4 * ks + (lane >> 4), rowa = wm * WM + (lane & 15), rowb = wn * WN + (lane & 15);
+			fa[ks] = smem_base + rowa * 128 + ((c0 ^ (rowa & 7)) << 4);
+			fb[ks] = smem_base + BM * 128 + rowb * 128 + ((c0 ^ (rowb & 7)) << 4);
+		}
+		unsigned pA_dst = 0, pB_dst = 0, p_soffA = 0, p_soffB = 0;
+		auto issue_prep = [&](unsigned stage_off) {
+			if (seg_in || kk_i == 0) set_segment(seg_i);
+			pA_dst = smem_base + stage_off; pB_dst = pA_dst + BM * 128;
+			p_soffA = (unsigned)kk_i * 128u; p_soffB = b_seg_off + (unsigned)kk_i * 128u;
+			next_tile();
+		};
+		auto issue_piece = [&](auto d_) {
+			constexpr int d = decltype(d_)::value;
+			if constexpr (d < A_PC) pipe_glds16(va[d], srdA, p_soffA, pA_dst + (wave + NW * d) * 1024);
+			else pipe_glds16(vb[d - A_PC], srdB, p_soffB, pB_dst + (wave + NW * (d - A_PC)) * 1024);
+		};
+		auto read_one = [&](auto r_, HFrags& fr, unsigned ra, unsigned rb) {
+			constexpr int r = decltype(r_)::value;
+			if constexpr (r < MI) pipe_read16<r * 2048>(fr.a[r], ra);
+			else pipe_read16<(r - MI) * 2048>(fr.b[r - MI], rb);
+		};
+		auto barrier = [&] { TTK_FENCE(); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); TTK_FENCE(); };
+		// one half-step: [wait for W loads at most + barrier] 16 MFMAs of `cur`; RD: 8 reads into `nxt` (addresses ra / rb), one per gap; ISSUE: the next tile's pieces in the last gaps
+		auto htrip = [&](auto bar_, auto w_, auto rd_, auto issue_, const HFrags& cur, HFrags& nxt, unsigned ra, unsigned rb) {
+			constexpr bool BAR = decltype(bar_)::value, RD = decltype(rd_)::value, ISSUE = decltype(issue_)::value;
+			if constexpr (BAR) { wait_vmcnt<decltype(w_)::value>(); barrier(); }
+			static_for<0, NM>([&](auto m_) {
+				constexpr int m = decltype(m_)::value, i = m / NI, j = m % NI;
+				pipe_mfma<T>(acc[i][j], cur.a[i], cur.b[j]);
+				if constexpr (RD && m < NR) read_one(m_, nxt, ra, rb);
+				if constexpr (ISSUE && m >= D0 && m - D0 < PER_TILE) issue_piece(std::integral_constant<int, m - D0>{});
+			});
+			if constexpr (RD) pipe_lgkm0();
+		};
+		typedef std::true_type Y; typedef std::false_type N; typedef std::integral_constant<int, 0> W0;
+		const unsigned m0_keep = pipe_m0_save();
+#pragma unroll
+		for (int st = 0; st < NSTAGE; ++st) { issue_prep(st * STAGE); static_for<0, PER_TILE>(issue_piece); }
+		TTK_WSTAMP(stamps_, blockIdx.x, 1);
+		wait_vmcnt<(NSTAGE - 1) * PER_TILE>();      // tile 0 has landed
+		barrier();
+		TTK_WSTAMP(stamps_, blockIdx.x, 2);
+		HFrags f0, f1;
+		static_for<0, NR>([&](auto r_) { read_one(r_, f0, fa[0], fb[0]); });
+		pipe_lgkm0();
+#ifdef TTK_CLOCK_STAMPS
+		const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+		unsigned cur_off = 0, nxt_off = STAGE;      // stages of tile kt and tile kt + 1
+		auto advance = [&] { cur_off = nxt_off; nxt_off = nxt_off == (NSTAGE - 1) * STAGE ? 0u : nxt_off + STAGE; };
+		for (int kt = 0; kt < NT - NSTAGE; ++kt) {      // tiles whose second half-step requests a tile
+			htrip(N{}, W0{}, Y{}, N{}, f0, f1, fa[1] + cur_off, fb[1] + cur_off);
+			issue_prep(cur_off);
+			htrip(Y{}, std::integral_constant<int, (NSTAGE - 2) * PER_TILE>{}, Y{}, Y{}, f1, f0, fa[0] + nxt_off, fb[0] + nxt_off);
+			advance();
+		}
+		static_for<0, NSTAGE - 1>([&](auto t_) {      // tile NT - NSTAGE + t: nothing left to request; tile + 1 has landed, the NSTAGE - 2 - t younger ones may be in flight
+			htrip(N{}, W0{}, Y{}, N{}, f0, f1, fa[1] + cur_off, fb[1] + cur_off);
+			htrip(Y{}, std::integral_constant<int, (NSTAGE - 2 - decltype(t_)::value) * PER_TILE>{}, Y{}, N{}, f1, f0, fa[0] + nxt_off, fb[0] + nxt_off);
+			advance();
+		});
+		htrip(N{}, W0{}, Y{}, N{}, f0, f1, fa[1] + cur_off, fb[1] + cur_off);      // the last tile
+		htrip(N{}, W0{}, N{}, N{}, f1, f0, 0u, 0u);
+		pipe_m0_restore(m0_keep);
+#ifdef TTK_CLOCK_STAMPS
+		if (stamps_ && lane == 0) {
+			unsigned long long* st_ = stamps_ + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
+			st_[6] = ((__builtin_amdgcn_s_memtime() - clk0_) << 32) | ((__builtin_amdgcn_s_memrealtime() - rt0_) & 0xffffffffull);
+		}
+#endif
+	} else if constexpr (PIPE) {
 		constexpr int NM = KSTEPS * MI * NI, NR = KSTEPS * (MI + NI);
 		constexpr int PREB = TTK_PIPE_PREB, DPG = TTK_PIPE_DPG;
 		constexpr int RPG_MIN = (NR + (NM - PREB) - 1) / (NM - PREB), RPG = TTK_PIPE_RPG > RPG_MIN ? TTK_PIPE_RPG : RPG_MIN;      // (narrow wave blocks have more reads than gaps)
