@@ -654,6 +654,10 @@ def main():
 		hang in front of a marker -- the watchdogs' test (tests/test_host_logic.py), never set otherwise."""
 		if os.environ.get("TTK_BENCH_STALL_AT") == name and int(os.environ.get("TTK_BENCH_STALL_RANK", "-1")) == rank:
 			log(f"rank {rank}: stalling in front of '{name}' (TTK_BENCH_STALL_AT)")
+			if os.environ.get("TTK_BENCH_STALL_IGNORE_TERM") == "1":      # tests only: a rank wedged so that SIGTERM does not end it (the case the parent's SIGKILL pass exists for)
+				import signal
+				signal.signal(signal.SIGTERM, signal.SIG_IGN)
+				log(f"rank {rank}: ignoring SIGTERM")
 			while True:
 				time.sleep(1.0)
 		if wd is not None:

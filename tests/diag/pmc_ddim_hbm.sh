@@ -1,6 +1,7 @@
 #!/bin/bash
 set -eo pipefail
 ROOT=$(pwd); OUT=$ROOT/gpurun_out
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export DC_EAGER=1
 BIN=$ROOT/tests/diag/ddim_chain_plain.bin

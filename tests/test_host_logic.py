@@ -162,6 +162,38 @@ def test_bench_multi_rank_run_fails_fast_with_a_reason_when_a_rank_stalls():
 	assert "[parent watchdog] rank 1 has not logged 'models built'" in r.stderr and "terminating the 2 child ranks" in r.stderr
 
 
+def test_bench_parent_teardown_reaches_a_rank_that_ignores_sigterm():
+	"""the elastic agent starts its workers in sessions of their own, so killing the launcher's process group does not reach them, and a rank wedged in the driver
+	ignores the SIGTERM the agent forwards.  The ranks record their pids in their rank files; the parent signals those itself, SIGKILLs what is still alive after its wait and
+	checks that nothing survives.  Rank 1 stalls AND ignores SIGTERM here (wait cut to 3 s): the run ends 75, the log names the SIGKILL, and the recorded pid is gone."""
+	import re
+	import time
+	t0 = time.time()
+	r = _bench_probe(dict(TTK_BENCH_STALL_RANK="1", TTK_BENCH_STALL_AT="models built", TTK_BENCH_STALL_IGNORE_TERM="1", TTK_BENCH_STAGE_BUDGET="5",
+						  TTK_BENCH_NO_RANK_WATCHDOG="1", TTK_BENCH_PARENT_GRACE="2", TTK_BENCH_TERM_WAIT="3"))
+	assert r.returncode == 75 and time.time() - t0 < 120, r.stderr[-1500:]
+	err1 = open(os.path.join(ROOT, "gpurun_out", "rank1.err")).read()
+	m = re.search(r"\[pid\] rank 1 pid (\d+)", err1)
+	assert m and "ignoring SIGTERM" in err1
+	pid = int(m.group(1))
+	assert f"pid {pid} ignored SIGTERM" in r.stderr and "SIGKILL" in r.stderr and "still alive after SIGKILL" not in r.stderr
+	import bench
+	time.sleep(0.5)
+	assert not bench.alive(pid)
+
+
+def test_bench_stage_budgets_grow_with_the_steps_asked_for():
+	"""a healthy `--steps 100` run must not be ended by a constant budget"""
+	import argparse
+	import bench
+	base = dict(bench.stage_budgets(argparse.Namespace(steps=0, warmup=0, shard="utterances")))
+	big = dict(bench.stage_budgets(argparse.Namespace(steps=100, warmup=10, shard="utterances")))
+	cand = dict(bench.stage_budgets(argparse.Namespace(steps=100, warmup=10, shard="candidates")))
+	assert base == dict(bench.STAGE_BUDGET_S)
+	assert big["timed done"] == base["timed done"] + 200 and big["timed region"] == base["timed region"] + 20 and big["rendezvous ok"] == base["rendezvous ok"]
+	assert cand["timed done"] == base["timed done"] + 1000
+
+
 def test_bench_preflight_falls_back_to_the_other_ipc_setting_in_fresh_children():
 	"""the one-collective pre-flight runs in a fresh child per attempt; when the inherited HSA_ENABLE_IPC_MODE_LEGACY setting fails it, the other one is tried
 	and the run proceeds under the one that passed (stated order: inherited / 0 first); when both fail no model is built and the exit status is 76"""

@@ -454,7 +454,7 @@ __device__ __forceinline__ int64_t decode_out_index(const AttnDecodeParams& p, i
 // 64-byte line of this code object: its address is known at link time, so lane i asks for word i of the line with the wave's first instructions, beside the argument loads, and the
 // slot index (an argument) only selects the lane to read when both have arrived.  Writers (prefill, the head launch's bump) reach the words through the ordinary pointer.
 __device__ __attribute__((aligned(64))) int g_pos_line[16];
-static unsigned g_pos_slots_used = 0;
+static unsigned g_pos_slots_used = 0;      // slot mask of the ONE device this process drives (one process per GPU: a second device would have its own copy of g_pos_line but share this mask)
 static std::mutex g_pos_slots_mutex;
 int attn_pos_slot_acquire(int** words_out) {
 	std::lock_guard<std::mutex> lock(g_pos_slots_mutex);

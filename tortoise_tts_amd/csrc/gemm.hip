@@ -247,7 +247,7 @@ __device__ __forceinline__ int div_recip(int x, int d, float inv) {
 
 // The generic epilogue with the role's decisions taken at compile time: bias always, no activation, no scale; ldc = ldr = N; 32-bit element indices
 // (M * N < 2^30, checked by the dispatcher).  Same operations on every value in the same order: bit-identical results.
-// the residual values of a wave's block, one dword per accumulator register (rows beyond M read as zero)
+// the residual values of a wave's block, one dword per accumulator register (GUARD: a row beyond M reads the clamped LAST row -- the request must leave, see below -- and its value is dropped in the epilogue)
 template <int ROLE, int MI, int NI, bool GUARD>
 __device__ __forceinline__ void load_residual_role(const GemmParams& p, float (&res)[MI][4][NI], int row0, int col0, int lane) {
 	constexpr int N = GRole<ROLE>::N;
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmParams p) {
 template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
 static void launch_tile(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	constexpr int LDS = NSTAGE * (BM + BN) * 128;
-	static bool attr_set = false;
+	static bool attr_set = false;      // per instantiation, process-wide: assumes ONE device per process (this design: one process per GPU); a second device in the same process would need the attribute set again
 	if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
 		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_set = true;
@@ -1210,7 +1210,7 @@ static bool mixed_grid_applies(const GemmParams& p) {
 template <typename T, int ROLE>
 static void launch_mixed(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	constexpr int LDS = TTK_ROLE_STAGES * (128 + 64) * 128;
-	static bool attr_set = false;
+	static bool attr_set = false;      // (one device per process, as in launch_tile)
 	if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_mixed<T, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
 	GemmParams p = p_in;
 	p.mix_fm = 16; p.mix_full = 256;
