@@ -190,6 +190,7 @@ int main(int argc, char** argv) {
 	std::vector<unsigned long long> hs(8 * SLOTS);
 	std::vector<double> stat[8][10];
 	std::vector<double> clk[8], kcyc[8];      // -DTTK_CLOCK_STAMPS: per wave, shader cycles / 100 MHz ticks of the k-loop (slot 6)
+	std::vector<double> aph[2][4];            // -DTTK_ATTN_PHASES: attention key-loop phases (slots 1, 2), [SIMD 0 | SIMDs 1..3][phase]
 	for (int rep = 0; rep < 9; ++rep) {
 		CK(hipMemsetAsync(stamps, 0, 8 * SLOTS * 8, s));
 		CK(launch_main(ge)); CK(launch_main(ges)); CK(launch_main(ge));
@@ -227,6 +228,11 @@ int main(int argc, char** argv) {
 						if (p[3] && p[4]) ph[3].push_back((double)p[4] - p[3]);
 						if (p[4] && p[5]) ph[4].push_back((double)p[5] - p[4]);
 					} else if (k == 6) {
+						if (p[1] && p[2]) {      // -DTTK_ATTN_PHASES: per-wave cycle sums of the key loop's phases, waves of SIMD 0 (three per SIMD in a 9-tile workgroup) kept apart
+							const int grp = (v & 3) == 0 ? 0 : 1;
+							aph[grp][0].push_back((double)(p[1] >> 32)); aph[grp][1].push_back((double)(p[1] & 0xffffffffull));
+							aph[grp][2].push_back((double)(p[2] >> 32)); aph[grp][3].push_back((double)(p[2] & 0xffffffffull));
+						}
 						if (p[4]) ph[2].push_back((double)p[4] - p[0]);
 						if (p[4] && p[5]) ph[4].push_back((double)p[5] - p[4]);
 					} else {
@@ -247,6 +253,10 @@ int main(int argc, char** argv) {
 		}
 	}
 	auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+	for (int g = 0; g < 2; ++g)
+		if (!aph[g][0].empty())
+			printf("attention phases, waves on %s (%zu stamps), shader cycles per wave summed over the key loop, median: barriers + staging %.0f | K reads + QK^T %.0f | softmax %.0f | V reads + PV %.0f\n",
+				   g == 0 ? "SIMD 0    " : "SIMDs 1..3", aph[g][0].size(), med(aph[g][0]), med(aph[g][1]), med(aph[g][2]), med(aph[g][3]));
 	printf("%-20s | %8s | start p50 / max | issue   1st-tile  k-loop   epilogue  ack  (gn: loads, merge+barrier, -, apply+stores, ack) | WG dur p50 | first start..last ack\n", "kernel", "boundary");
 	double sum = 0;
 	for (int k = 0; k < 8; ++k) {

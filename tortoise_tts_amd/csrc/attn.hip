@@ -198,7 +198,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 #ifdef TTK_CLOCK_STAMPS
 	const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef TTK_ATTN_PHASES      // diagnostic builds (tests/diag/ddim_chain.cpp): shader cycles of this wave summed per phase of a key tile -- barriers + staging / K reads + QK^T / softmax / V reads + PV
+	unsigned long long ph_t_ = 0; unsigned ph_sync_ = 0, ph_qk_ = 0, ph_sm_ = 0, ph_pv_ = 0;
+#define TTK_PH_MARK(acc_, dep_) do { asm volatile("s_nop 0" :: "v"(dep_)); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += (unsigned)(n_ - ph_t_); ph_t_ = n_; } while (0)
+#else
+#define TTK_PH_MARK(acc_, dep_) do {} while (0)
+#endif
 	for (int kt = 0; kt < nkt; ++kt) {
+#ifdef TTK_ATTN_PHASES
+		ph_t_ = __builtin_amdgcn_s_memtime();
+#endif
 		// (TTK_DIAG_ATTN, diagnostic builds of tests/diag/ddim_chain.cpp only, results wrong on purpose: 1 = no workgroup barriers in the key loop, 2 = K / V staged once and
 		// never again: profiles/r05_ddim_chain_attn_ablation.log)
 #if !(defined(TTK_DIAG_ATTN) && (TTK_DIAG_ATTN & 1))
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 
 		const int k0 = kt * 64;
 		const bool wave_active = (!CAUSAL || k0 <= q0 + QW - 1) && (!BAL || wave < cnt);
+		TTK_PH_MARK(ph_sync_, k0);
 		if (wave_active) {
 			// ---- S^T tile: 4 key sub-tiles x 2 query tiles
 			f32x4 s[QT][4];
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 					if (QT > 1) s[QT - 1][nt] = mma16<T>(kf.v, ks == 0 ? q10 : q11, s[QT - 1][nt]);
 				}
 			}
+			TTK_PH_MARK(ph_qk_, s[0][3][3]);
 			// ---- bias, masks, online softmax in the log2 domain (lane owns query column li of each q tile; keys 16nt + 4g + r).
 			// Wave-uniform fast path: a tile with no sequence edge, no causal diagonal and every |key - q| >= 64 (the T5 bucket is
 			// saturated there) needs one fma per score; only the ~3 tiles around the diagonal take the per-element path.
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 				}
 				l_run[qt] += psum;
 			}
+			TTK_PH_MARK(ph_sm_, l_run[0]);
 			// ---- O^T += V^T P^T
 #pragma unroll
 			for (int sidx = 0; sidx < 2; ++sidx) {
@@ -339,8 +351,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 					for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mma16<T>(vf, pf[qt], o[qt][dt]);
 				}
 			}
+			TTK_PH_MARK(ph_pv_, o[0][3][3]);
 		}
 	}
+#ifdef TTK_ATTN_PHASES
+	if (p.stamps && lane == 0) {
+		unsigned long long* st_ = p.stamps + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8;
+		st_[1] = ((unsigned long long)ph_sync_ << 32) | ph_qk_; st_[2] = ((unsigned long long)ph_sm_ << 32) | ph_pv_;
+	}
+#endif
 
 #ifdef TTK_CLOCK_STAMPS
 	if (p.stamps && lane == 0) {      // shader cycles and 100 MHz ticks of this wave's key loop (diagnostic build: MI355X_MICROARCH.md, DVFS give-back item 6)
