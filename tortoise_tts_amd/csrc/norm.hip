@@ -292,7 +292,7 @@ __global__ __launch_bounds__(GN_TOUCH_WAVE ? 320 : 256) void k_gn_apply_c1024(Gn
 // The fixed 4-row strips make 544 workgroups there, 2.125 per CU: the 32 CUs that hold three set the launch (4.4 us against 3.7 us for the same launch at T = 1024,
 // where 512 workgroups are two per CU; profiles/r04_ddim_chain_T1024_vs_T1088.log).  Up to GN_MAXR rows per thread, every request up front; elementwise, same
 // arithmetic: bit-identical output.
-template <typename OT, int GN_MAXR>
+template <typename OT, int GN_MAXR, int NG = 8>      // NG: groups of eight statistics chunks a lane asks for (3 serves sequences up to 1536 frames: 9 dwords per lane instead of 24)
 __global__ __launch_bounds__(320) void k_gn_apply_c1024_even(GnApplyParams p, int q, int rem) {
 	constexpr int C = 1024;
 	__shared__ unsigned pf_sink[64 * 4];
@@ -308,20 +308,30 @@ __global__ __launch_bounds__(320) void k_gn_apply_c1024_even(GnApplyParams p, in
 	const int b = blockIdx.y, w = blockIdx.x;
 	const int t0 = w * q + (w < rem ? w : rem), nrows = q + (w < rem ? 1 : 0);
 	const int c = tid * 4;
+	// the statistics triples are requested FIRST (round 6): the merge then runs while the rows are still on their way (see gn_load_triples)
+	float cn[8], cm[8], c2[8];
+	gn_load_triples_n<NG>(p.ms + ((int64_t)b * 32 + (tid >> 3)) * p.nchunks * 3, p.nchunks, tid & 7, [](const float* qq) { return *qq; }, cn, cm, c2);
+	__builtin_amdgcn_sched_barrier(0);
 	float4 xv[GN_MAXR];
 #pragma unroll
-	for (int i = 0; i < GN_MAXR; ++i)
-		if (i < nrows) xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + t0 + i) * C + c);
+	for (int i = 0; i < GN_MAXR; ++i) {
+		// STRAIGHT (NG < 8 instantiations, GN_MAXR = the strip's row count or one more): every row request leaves unconditionally -- a strip one row short re-reads its last row --
+		// so that the requests form one straight line and the wait in front of the merge can be counted: under `if (i < nrows)` the compiler cannot know how many requests
+		// follow the triples and waits for (nearly) all of them
+		if (NG < 8) xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + t0 + (i < nrows ? i : nrows - 1)) * C + c);
+		else if (i < nrows) xv[i] = *(const float4*)(p.x + ((int64_t)b * p.T + t0 + i) * C + c);
+	}
 	const float4 ga = *(const float4*)(p.gamma + c), be = *(const float4*)(p.beta + c);
 	float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
-	if (p.scale) { sc = *(const float4*)(p.scale + (int64_t)b * p.ss_stride + c); sh = *(const float4*)(p.shift + (int64_t)b * p.ss_stride + c); }
+	if (NG < 8) {      // (straight line as well: without scale / shift the two requests re-read gamma / beta and the values are dropped)
+		const float4 s1 = *(const float4*)((p.scale ? p.scale + (int64_t)b * p.ss_stride : p.gamma) + c), s2 = *(const float4*)((p.scale ? p.shift + (int64_t)b * p.ss_stride : p.beta) + c);
+		if (p.scale) { sc = s1; sh = s2; }
+	} else if (p.scale) { sc = *(const float4*)(p.scale + (int64_t)b * p.ss_stride + c); sh = *(const float4*)(p.shift + (int64_t)b * p.ss_stride + c); }
+	__builtin_amdgcn_sched_barrier(0);
 	TTK_WSTAMP(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 1);
 	float mean, rstd;
-	{
-		const int g = tid >> 3, sub = tid & 7;
-		const float* part = p.ms + ((int64_t)b * 32 + g) * p.nchunks * 3;
-		gn_merge_triples(part, p.nchunks, sub, [](const float* qq) { return *qq; }, mean, rstd);
-	}
+	gn_merge_loaded(cn, cm, c2, mean, rstd);
+	__builtin_amdgcn_sched_barrier(0);      // (nothing of the fold -- it needs scale / shift, the youngest requests -- may be scheduled into the merge)
 	TTK_WSTAMPD(p.stamps, blockIdx.y * gridDim.x + blockIdx.x, 2, rstd);
 	float a0, a1, a2, a3, d0, d1, d2, d3;
 	gn_fold_coef(mean, rstd, ga.x, be.x, sc.x, sh.x, a0, d0); gn_fold_coef(mean, rstd, ga.y, be.y, sc.y, sh.y, a1, d1);
@@ -365,7 +375,10 @@ void launch_gn_apply(int dt, const GnApplyParams& p, hipStream_t s) {
 			const int strips = 256 / p.nb, q = p.T / strips, rem = p.T % strips;
 			if (q >= 4 && q + (rem ? 1 : 0) <= 18) {
 				const dim3 grid(strips, p.nb);
-#define GN_EVEN(OT) hipLaunchKernelGGL((k_gn_apply_c1024_even<OT, 18>), grid, dim3(320), 0, s, p, q, rem)
+#define GN_EVEN(OT) do { const int mr = q + (rem ? 1 : 0); \
+						if (p.nchunks <= 24 && mr <= 9) hipLaunchKernelGGL((k_gn_apply_c1024_even<OT, 9, 3>), grid, dim3(320), 0, s, p, q, rem); \
+						else if (p.nchunks <= 24 && mr <= 12) hipLaunchKernelGGL((k_gn_apply_c1024_even<OT, 12, 3>), grid, dim3(320), 0, s, p, q, rem); \
+						else hipLaunchKernelGGL((k_gn_apply_c1024_even<OT, 18, 8>), grid, dim3(320), 0, s, p, q, rem); } while (0)
 				if (p.out_f8) GN_EVEN(f8);
 				else if (p.out_f32 || dt == DT_F32) GN_EVEN(float);
 				else if (dt == DT_F16) GN_EVEN(f16);

@@ -137,20 +137,32 @@ __device__ __forceinline__ float silu_precise(float x) { return silu_f(x); }
 // per-channel fold y = x * a + d.  Contraction is written out (fmaf where a product feeds a sum, nothing else fused): left to the compiler, two instantiations
 // of one source line have rounded differently in the last bit (tests/diag/role_check.cpp), and a sequence must come out the same whichever kernel serves it.
 // LOAD(ptr) fetches one float of the triples (plain load, or an agent-scope load where the triples were written by this very launch).
-template <typename LoadF>
-__device__ __forceinline__ void gn_merge_triples(const float* part, int nch, int sub, LoadF load, float& mean, float& rstd) {
-#pragma clang fp contract(off)
-	float cn[8], cm[8], c2[8];
-	float nt = 0.f, wsum = 0.f;
+// Split in two since round 6: the REQUESTS of a lane's triples (gn_load_triples) and the arithmetic on them (gn_merge_loaded), so that a kernel can ask for the triples
+// FIRST -- vmcnt retires in order: requested behind the rows, the triples could not be used before every row had landed, and the merge (a chain of DPP sums, a
+// division and an rsqrt) started only then -- and so that chunk groups beyond nch are not requested at all (a lane asked for 24 dwords whatever nch was; at
+// T = 1088, nch = 17, nine are real).  A skipped group contributes exact zeros, as the clamped loads' `ok ? x : 0` did: same bits.
+template <int NG, typename LoadF>
+__device__ __forceinline__ void gn_load_triples_n(const float* part, int nch, int sub, LoadF load, float (&cn)[8], float (&cm)[8], float (&c2)[8]) {
 #pragma unroll
-	for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group
+	for (int i = 0; i < 8; ++i) {   // up to 64 chunks per group of channels; the first NG groups of eight are requested (all at once: no branch between them)
+		cn[i] = 0.f; cm[i] = 0.f; c2[i] = 0.f;
+		if (i >= NG) continue;
 		const int k = sub + 8 * i;
 		const bool ok = k < nch;
 		const int kk = ok ? k : 0;
 		const float a0 = load(part + 3 * kk), a1 = load(part + 3 * kk + 1), a2 = load(part + 3 * kk + 2);
 		cn[i] = ok ? a0 : 0.f; cm[i] = ok ? a1 : 0.f; c2[i] = ok ? a2 : 0.f;
-		nt += cn[i]; wsum = __builtin_fmaf(cn[i], cm[i], wsum);
 	}
+}
+template <typename LoadF>
+__device__ __forceinline__ void gn_load_triples(const float* part, int nch, int sub, LoadF load, float (&cn)[8], float (&cm)[8], float (&c2)[8]) {
+	gn_load_triples_n<8>(part, nch, sub, load, cn, cm, c2);
+}
+__device__ __forceinline__ void gn_merge_loaded(const float (&cn)[8], const float (&cm)[8], const float (&c2)[8], float& mean, float& rstd) {
+#pragma clang fp contract(off)
+	float nt = 0.f, wsum = 0.f;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) { nt += cn[i]; wsum = __builtin_fmaf(cn[i], cm[i], wsum); }
 	nt = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(nt)));
 	wsum = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(wsum)));
 	mean = wsum / nt;
@@ -159,6 +171,12 @@ __device__ __forceinline__ void gn_merge_triples(const float* part, int nch, int
 	for (int i = 0; i < 8; ++i) { const float d = cm[i] - mean; m2 += __builtin_fmaf(cn[i] * d, d, c2[i]); }
 	m2 = dpp_add<0x141>(dpp_add<0x4E>(dpp_add<0xB1>(m2)));
 	rstd = rsqrtf(m2 / nt + 1e-5f);
+}
+template <typename LoadF>
+__device__ __forceinline__ void gn_merge_triples(const float* part, int nch, int sub, LoadF load, float& mean, float& rstd) {
+	float cn[8], cm[8], c2[8];
+	gn_load_triples(part, nch, sub, load, cn, cm, c2);
+	gn_merge_loaded(cn, cm, c2, mean, rstd);
 }
 // y = x * a + d with a = rstd * gamma * (1 + scale), d = (beta - mean * rstd * gamma) * (1 + scale) + shift
 __device__ __forceinline__ void gn_fold_coef(float mean, float rstd, float gamma, float beta, float scale, float shift, float& a, float& d) {
