@@ -268,16 +268,14 @@ __device__ __forceinline__ void load_residual_role(const GemmParams& p, float (&
 }
 
 // PRE: `res` already holds the residual (requested under the last k-tiles, see the role kernels' tail)
+// `bj`: the NI bias values of this lane's columns, requested by the caller in front of the k-loop (round 6: fetched here they were an L2 round trip between the last MFMA and the first store)
 template <typename T, int ROLE, bool GUARD, int MI, int NI, bool PRE = false>
-__device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[MI][NI], float (&res)[MI][4][NI], int row0, int col0, int lane) {
+__device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[MI][NI], float (&res)[MI][4][NI], const float (&bj)[NI], int row0, int col0, int lane) {
 #pragma clang fp contract(off)
 	typedef GRole<ROLE> R;
 	typedef typename OutOf<T>::type OT;
 	constexpr int N = R::N;
 	const int lr = 4 * (lane >> 4), lc = lane & 15;
-	float bj[NI];
-#pragma unroll
-	for (int j = 0; j < NI; ++j) bj[j] = p.bias[col0 + 16 * j + lc];
 	const float os = sizeof(T) == 1 ? p.out_scale : 1.f;      // fp8 operands: the weights' power-of-two tensor scale (16-bit roles have none)
 	if constexpr (R::RES && !PRE) {      // all residual loads before the first store: C aliases the residual
 #pragma unroll
@@ -290,6 +288,29 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 					res[i][r][j] = (!GUARD || gm < p.M) ? p.residual[(unsigned)(gm * N + col0 + 16 * j + lc)] : 0.f;
 				}
 	}
+	if constexpr (R::MODE == 0 && sizeof(OT) == 2 && !R::RES) {
+		// 16-bit output (the q / k / v projection): a lane holds four ROWS of one column, so the plain form is 64 two-byte stores per lane (1.6 us of epilogue).  Neighbouring lanes
+		// hold neighbouring columns: one DPP swap per row pair gives the even lane both columns of the upper row and the odd lane both of the lower one -- 32 dword stores of the
+		// same converted values (round 6).
+		const bool odd = lc & 1;
+#pragma unroll
+		for (int i = 0; i < MI; ++i)
+#pragma unroll
+			for (int j = 0; j < NI; ++j)
+#pragma unroll
+				for (int rp = 0; rp < 2; ++rp) {
+					float v0 = acc[i][j][2 * rp], v1 = acc[i][j][2 * rp + 1];
+					if constexpr (sizeof(T) == 1) { v0 = v0 * os; v1 = v1 * os; }
+					v0 = v0 + bj[j]; v1 = v1 + bj[j];
+					acc[i][j][2 * rp] = v0; acc[i][j][2 * rp + 1] = v1;
+					const float mine = odd ? v1 : v0, give = odd ? v0 : v1;      // the row this lane stores / the row its neighbour stores
+					const float got = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]: the neighbour's value of MY row
+					const uint2 pk = pack4_16<OT>(odd ? got : mine, odd ? mine : got, 0.f, 0.f);      // (column order: even lane's column first)
+					const int gm = row0 + 16 * i + lr + 2 * rp + (odd ? 1 : 0);
+					if (GUARD && gm >= p.M) continue;
+					*(unsigned*)((OT*)p.C + (unsigned)(gm * N + col0 + 16 * j + (lc & ~1))) = pk.x;
+				}
+	} else {
 #pragma unroll
 	for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -308,6 +329,7 @@ __device__ __forceinline__ void epilogue_role(const GemmParams& p, f32x4 (&acc)[
 				else ((OT*)p.C)[o] = cvt<OT>(v);
 			}
 		}
+	}
 	if constexpr (R::GN) {
 		if (MI == 4 && row0 < p.M) {
 			const int b = div_recip(row0, p.gn_T, p.inv_gn_T), chunk = (row0 - b * p.gn_T) >> 6, nch = p.gn_T >> 6;
@@ -354,6 +376,9 @@ __device__ __forceinline__ void conv3_image_tile(const GemmParams& p, const int 
 	const int wm = wave / NWN, wn = wave % NWN;
 	const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
 	const int Tb = p.rows_per_batch;
+	float bias_pre[NI];      // (the oldest requests of the wave: retired by the first counted wait)
+#pragma unroll
+	for (int j = 0; j < NI; ++j) bias_pre[j] = p.bias[n0 + wn * WN + 16 * j + l15];
 
 	// fragment addresses: tap s reads image row (row in tile) + s; sub-tile i adds 16 rows = 2048 bytes (an immediate), the image slot IMG bytes (an immediate too)
 	unsigned fa[3][KSTEPS], fb[KSTEPS];
@@ -521,7 +546,7 @@ __device__ __forceinline__ void conv3_image_tile(const GemmParams& p, const int 
 	}
 #endif
 	TTK_WSTAMPD(stamps_, blockIdx.x, 3, acc[0][0][0]);
-	if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI, true>(p, acc, res_pre, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI, true>(p, acc, res_pre, row0, col0, lane);
+	if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI, true>(p, acc, res_pre, bias_pre, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI, true>(p, acc, res_pre, bias_pre, row0, col0, lane);
 	TTK_WSTAMP(stamps_, blockIdx.x, 4);
 #if defined(TTK_STAMPS) && TTK_STAMPS == 2
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -676,6 +701,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 
 	const int row0 = m0 + wm * WM, col0 = n0 + wn * WN;
 	float res_pre[MI][4][NI];
+	float bias_pre[NI];      // roles: the bias of this lane's columns, requested in front of every DMA piece (the wave's oldest requests: retired by the first counted wait)
+	if constexpr (R::on) {
+#pragma unroll
+		for (int j = 0; j < NI; ++j) bias_pre[j] = p.bias[col0 + 16 * j + (lane & 15)];
+	}
 	constexpr int RESN = MI * 4 * NI;
 	constexpr bool PRE_RES = R::on && R::RES && NSTAGE >= 3 && (NSTAGE - 2) * PER_TILE + RESN <= 63 && (NSTAGE == 3 || (TTK_GEMM_PIPE && ES == 2 && MI * NI <= 8));
 	// wait until at most `tiles` of this wave's requested tiles are still in flight (vmcnt takes an immediate: uniform branch chain)
@@ -1085,7 +1115,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	TTK_WSTAMPD(stamps_, blockIdx.x, 3, acc[0][0][0]);
 
 	if constexpr (R::on) {
-		if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI, PRE_RES>(p, acc, res_pre, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI, PRE_RES>(p, acc, res_pre, row0, col0, lane);
+		if (m0 + BM <= p.M) epilogue_role<T, ROLE, false, MI, NI, PRE_RES>(p, acc, res_pre, bias_pre, row0, col0, lane); else epilogue_role<T, ROLE, true, MI, NI, PRE_RES>(p, acc, res_pre, bias_pre, row0, col0, lane);
 		TTK_WSTAMP(stamps_, blockIdx.x, 4);
 #if defined(TTK_STAMPS) && TTK_STAMPS == 2
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
