@@ -22,6 +22,9 @@
 
 namespace ttk {
 
+#ifndef TTK_ATTN_XCD_MAP
+#define TTK_ATTN_XCD_MAP 1      // 0: strip index = blockIdx.x, as before round 6 (A/B builds)
+#endif
 constexpr int HD = 64;
 constexpr float NEG_BIG = -1e30f;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -99,20 +102,29 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	__shared__ float band_s[BIAS ? 288 : 4];   // the bias as a function of key - query over [-144, 144), saturation included: band tiles index it without clamps
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int h = blockIdx.y, b = blockIdx.z;
+	// Balanced form: which (query strip, head, batch element) this workgroup serves is remapped so that the G workgroups of ONE (batch, head) run on ONE XCD (round 6).  Workgroups are
+	// dealt to the 8 XCDs round-robin by linear id, x fastest: with G = 8 strips the strip index WAS the XCD, i.e. every XCD fetched every head's K and V (278 KB at T = 1088) for one
+	// strip each -- 84 % of the key loop's reads missed the L2 (TCC hit 16 %, 618 cycles per request, profiles/r06_pmc_kloop.txt).  With a head's strips on one XCD its K / V tiles
+	// come from the Infinity Cache once per XCD and from that XCD's L2 seven times.  Same work per workgroup, same arithmetic: bit-identical output.
+	int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+	if (BAL && TTK_ATTN_XCD_MAP && ((gridDim.y * gridDim.z) & 7) == 0) {
+		const int L = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, G = gridDim.x;
+		const int xcd = L & 7, sidx = L >> 3, bh = (sidx / G) * 8 + xcd;
+		bx = sidx - (sidx / G) * G; h = bh % (int)gridDim.y; b = bh / (int)gridDim.y;
+	}
 	constexpr int QW = 16 * QT, QB = NWV * QW;        // queries per wave / per workgroup
 	const int li = lane & 15, g = lane >> 4;
 	TTK_WSTAMP(p.stamps, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 0);
 	// ragged batch: sequence b holds TL valid rows in its slot of p.T rows.  Every bound below is the sequence's own (TL); p.T is only the stride.
 	const int TL = p.tlen ? p.tlen[b] : p.T;
-	int q0 = blockIdx.x * QB + wave * QW;             // first query row of this wave
+	int q0 = bx * QB + wave * QW;             // first query row of this wave
 	int cnt = NWV;                                    // BAL: 16-query tiles (= working waves) of this workgroup
 	if (BAL) {
 		const int tiles = (TL + 15) / 16, G = gridDim.x, per = tiles / G, extra = tiles - per * G;
-		cnt = per + ((int)blockIdx.x < extra ? 1 : 0);
-		q0 = 16 * ((int)blockIdx.x * per + min((int)blockIdx.x, extra) + wave);
+		cnt = per + (bx < extra ? 1 : 0);
+		q0 = 16 * (bx * per + min(bx, extra) + wave);
 		if (cnt == 0) return;
-	} else if ((int)blockIdx.x * QB >= TL) return;    // a query block of padding rows (uniform for the workgroup: before any barrier)
+	} else if (bx * QB >= TL) return;    // a query block of padding rows (uniform for the workgroup: before any barrier)
 	const T* base = (const T*)p.qkv + (int64_t)b * p.T * p.ld;
 	const int qc = p.q_off + h * p.head_stride, kc = p.k_off + h * p.head_stride, vc = p.v_off + h * p.head_stride;
 
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_attn_fwd(AttnPar
 	}
 
 	int nkt = (TL + 63) / 64;
-	if (CAUSAL) { const int last_q = min((int)blockIdx.x * QB + QB - 1, TL - 1); nkt = min(nkt, last_q / 64 + 1); }
+	if (CAUSAL) { const int last_q = min(bx * QB + QB - 1, TL - 1); nkt = min(nkt, last_q / 64 + 1); }
 
 	// staging registers as named scalars (indexed arrays captured by the lambdas were placed in scratch memory)
 	uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
