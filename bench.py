@@ -247,7 +247,7 @@ def _gemm_floor_us(M, N, K, taps, e, peak, model="hardware"):
 	if t128 >= 256:
 		bm, bn, tiles = 128, 128, t128
 		t256 = -(-M // 256) * -(-N // 128)
-		if e <= 2 and t128 > 256 and 15 * -(-t256 // 256) < 9 * -(-t128 // 256):
+		if e <= 2 and t128 > 256 and 15 * -(-t256 // 256) <= 9 * -(-t128 // 256):
 			bm, bn, tiles = 256, 128, t256
 	elif t12864 >= 128:
 		bm, bn, tiles, waves = 128, 64, t12864, 4

@@ -555,7 +555,8 @@ __device__ __forceinline__ void conv3_image_tile(const GemmParams& p, const int 
 }
 
 // One output tile [m0, m0 + BM) x [n0, n0 + BN): operand staging, the k-loop and the epilogue.  `wave` = this wave's index among the NWM x NWN waves of the tile.
-template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE>
+// LONGK (generic kernel, 64 x 64 wave blocks only): the host promises more k-tiles than ring stages, so the half-tile hand-ordered loop can run without a run-time fallback
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE, bool LONGK = false>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, const int n0, const int wave) {
 	typedef GRole<ROLE> R;
 	static_assert(!R::on || (sizeof(T) <= 2 && R::N % BN == 0), "roles are 16-bit or fp8, N a multiple of the tile width");
@@ -724,12 +725,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 	// so two sets fit beside the 64 accumulators.  Half-step H0 of tile kt multiplies its k-step 0 (set f0) while k-step 1 of the SAME tile is read into f1 (no barrier: the tile
 	// has landed); H1 waits for tile kt + 1, passes the barrier (every wave's reads of tile kt ended with H0), multiplies k-step 1 while k-step 0 of tile kt + 1 is read into f0,
 	// and requests tile kt + NSTAGE into the stage tile kt has left.  Same MFMA order per accumulator (k-step 0, then 1): same bits.
-	constexpr bool PIPE_H = TTK_GEMM_PIPE_H && ES == 2 && NSTAGE == 3 && R::on && !R::RES && MI * NI == 16 && KSTEPS == 2;      // (the residual roles keep the compiler-ordered loop at this tile: their epilogue needs 64 more registers and the allocator spills inside the hand-ordered stream)
+	constexpr bool PIPE_H = TTK_GEMM_PIPE_H && ES == 2 && NSTAGE == 3 && ((R::on && !R::RES) || (!R::on && LONGK)) && MI * NI == 16 && KSTEPS == 2;      // (the residual roles keep the compiler-ordered loop at this tile: their epilogue needs 64 more registers and the allocator spills inside the hand-ordered stream)
 	if constexpr (PIPE_H) {
 		constexpr int NM = MI * NI, NR = MI + NI, D0 = NM - PER_TILE - 1;      // 16 MFMAs, 8 reads (one per gap from the first), the DMA pieces in the last gaps
 		static_assert(NR <= NM && D0 >= 0, "reads and DMA pieces must fit the gaps of a half-step");
-		constexpr int NT = R::NSEG * (GR_K / BKE);
-		static_assert(NT > NSTAGE, "the ring is deeper than the k-loop");
+		const int NT = NTILES;      // (roles: a compile-time constant; generic: > NSTAGE by LONGK)
+		static_assert(!R::on || R::NSEG * (GR_K / BKE) > NSTAGE, "the ring is deeper than the k-loop");
 		struct HFrags { u32x4 a[MI], b[NI]; };
 		unsigned fa[KSTEPS], fb[KSTEPS];
 #pragma unroll
@@ -1135,7 +1136,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int m0, con
 }
 
 // NWM x NWN waves per workgroup; 8 waves (2 per SIMD) let one wave's MFMAs run under another's LDS reads and DMA issue.
-template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE, bool LONGK = false>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 	typedef GRole<ROLE> R;
 
@@ -1174,7 +1175,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void k_gemm(GemmParams p) {
 		m0 = p.m_major ? (tile_id / tiles_n) * BM : (tile_id % tiles_m) * BM;
 		n0 = p.m_major ? (tile_id % tiles_n) * BN : (tile_id / tiles_m) * BN;
 	}
-	gemm_tile<T, BM, BN, NWM, NWN, NSTAGE, ROLE>(p, m0, n0, wave);
+	gemm_tile<T, BM, BN, NWM, NWN, NSTAGE, ROLE, LONGK>(p, m0, n0, wave);
 }
 
 // Mixed grid for the statistics roles when the 128 x 64 tiling leaves a few tiles more than there are CUs (the DDIM step at T = 1088: 17 x 16 = 272 tiles on 256
@@ -1212,12 +1213,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmParams p) {
 	}
 }
 
-template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE>
+template <typename T, int BM, int BN, int NWM, int NWN, int NSTAGE, int ROLE = GR_NONE, bool LONGK = false>
 static void launch_tile(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hipEvent_t eb) {
 	constexpr int LDS = NSTAGE * (BM + BN) * 128;
+	if constexpr (!LONGK && ROLE == GR_NONE && sizeof(T) == 2 && BM == 256 && BN == 128 && NSTAGE == 3) {      // the generic 64 x 64-wave-block tile: the half-tile hand-ordered loop when the k-loop is longer than the ring
+		if (TTK_GEMM_PIPE_H && (p_in.K / 64) * p_in.nseg > NSTAGE) return launch_tile<T, BM, BN, NWM, NWN, NSTAGE, ROLE, true>(p_in, s, ea, eb);
+	}
 	static bool attr_set = false;      // per instantiation, process-wide: assumes ONE device per process (this design: one process per GPU); a second device in the same process would need the attribute set again
 	if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
-		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+		if (LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE, LONGK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 		attr_set = true;
 	}
 	GemmParams p = p_in;
@@ -1226,7 +1230,7 @@ static void launch_tile(const GemmParams& p_in, hipStream_t s, hipEvent_t ea, hi
 	p.inv_rpb = p.rows_per_batch > 0 ? 1.0f / (float)p.rows_per_batch : 0.f;
 	p.inv_gn_T = p.gn_T > 0 ? 1.0f / (float)p.gn_T : 0.f;
 	const int grid = p.tiles_m * ((p.N + BN - 1) / BN);
-	hipExtLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE>), dim3(grid), dim3(64 * NWM * NWN), (unsigned)LDS, s, ea, eb, 0, p);
+	hipExtLaunchKernelGGL((k_gemm<T, BM, BN, NWM, NWN, NSTAGE, ROLE, LONGK>), dim3(grid), dim3(64 * NWM * NWN), (unsigned)LDS, s, ea, eb, 0, p);
 }
 
 // see k_gemm_mixed: tile rows [0, fm) as full 128 x 64 tiles (fm x 16 = 256 of them), the remaining M - 128 fm rows as 64 x 64 tiles
@@ -1336,7 +1340,7 @@ static void launch_gemm_t(const GemmParams& p, hipStream_t s, hipEvent_t ea, hip
 		if (wide >= 0) { if (p.N >= 3072) tile = wide; }
 		else if (wide == -2 && sizeof(T) <= 2 && t128 > 256) {
 			const int r128 = (t128 + 255) / 256, r256 = (t256 + 255) / 256;
-			if (15 * r256 < 9 * r128) tile = 8;      // 1.5 r256 < 0.9 r128
+			if (15 * r256 <= 9 * r128) tile = 8;      // 1.5 r256 <= 0.9 r128 (round 6: "<=" -- the wide tile runs the half-tile hand-ordered loop now; the latent pass's c_fc, 5 rounds of 128 x 128 against 3 of 256 x 128, 78.9 us, is the case on the line)
 		}
 	}
 	const int role = gemm_role_of(p, (int)sizeof(T));
