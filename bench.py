@@ -227,7 +227,7 @@ def rank_file(rank):
 # Launch lists (include/ttk.h entry points -> csrc/ar.hip, csrc/diff.hip): a decode token = 30 x (ln_1+c_attn, attention, c_proj, ln_2+c_fc, mlp.c_proj) + mel_head + sampler
 # = 152 launches over 805 MB of weights + the KV cache; the dense passes (prefill, latent pass) = 30 x (2 LayerNorm + 4 GEMM + attention) + 4; a DDIM step on the cond +
 # cond-free batch = 16 ResBlocks x (2 GroupNorm-apply + 1x1 conv + k=3 conv) + 13 AttentionBlocks x (GroupNorm-apply + qkv + attention + proj_out) + 8 others
-# (layout changes, input / integrating / output convs, out norm, the sampler update) = 124 launches.  Reported NEXT TO `frac`, never instead of it.
+# (layout changes, input / integrating / output convs, out norm, the sampler update) = 124 launches (123 since round 6: the sampler update writes the next step's channels-last copy of x).  Reported NEXT TO `frac`, never instead of it.
 BOUNDARY_US, HBM_STREAM, CU_L2_INTAKE = 1.45, 6.4e12, 68e9
 # Round 6: a GEMM k-loop is no longer priced with CU_L2_INTAKE -- that constant reproduced the measured k-loops because it was READ OFF them.
 # Its floor is now the largest of three hardware rates, none of them taken from csrc/gemm.hip:
@@ -296,9 +296,9 @@ def effective_floor(dtype_name, n_text=TEXT_TOKENS, n_cand=CANDIDATES, n_mel=MEL
 	gn = M * d * (4 + e_blk) / 256 / CU_L2_INTAKE * 1e6
 	res = 2 * gn + _g(M, d, d, 1, e_blk, peak_blk) + _g(M, d, d, 3, e_blk, peak_blk) + 4 * BOUNDARY_US
 	att = gn + _g(M, 3 * d, d, 1, e, peak) + 2.0 * 2 * T * T * d * 2 / peak * 1e6 + _g(M, d, d, 1, e_blk, peak_blk) + 4 * BOUNDARY_US      # (the q / k / v projection keeps 16-bit operands in the fp8 modes)
-	other = 8 * BOUNDARY_US + _g(M, d, 100, 3, e, peak) + _g(M, d, 2 * d, 1, e, peak) + _g(M, 200, d, 3, e, peak) + gn
+	other = 7 * BOUNDARY_US + _g(M, d, 100, 3, e, peak) + _g(M, d, 2 * d, 1, e, peak) + _g(M, 200, d, 3, e, peak) + gn
 	step_us = 16 * res + 13 * att + other
-	step_launches = 16 * 4 + 13 * 4 + 8
+	step_launches = 16 * 4 + 13 * 4 + 7
 	pre_us = 4 * (att - gn) + 8 * BOUNDARY_US                          # timestep_independent: 4 AttentionBlocks on the M latent rows (small), conv, norm, interpolate
 	consts = {"boundary_us": BOUNDARY_US, "hbm_stream_Bps": HBM_STREAM, "cu_stream_Bps (LayerNorm / GroupNorm-apply launches)": CU_L2_INTAKE}
 	consts.update({"gemm_kloop_Bps_per_CU (measured on this implementation)": CU_L2_INTAKE} if model == "launch_chain" else

@@ -242,7 +242,7 @@ def test_bench_effective_floor_follows_its_stated_formula():
 	assert (bench.CLOCK_HZ, bench.CU_INTAKE_BPC, bench.L2_CHIP) == (2.3e9, {4: 59.0, 8: 72.0}, 34.5e12)
 	e = bench.effective_floor("bf16")
 	c = bench.effective_floor("bf16", model="launch_chain")
-	assert e["launches"] == c["launches"] == {"decode_token": 152, "ddim_step": 124}
+	assert e["launches"] == c["launches"] == {"decode_token": 152, "ddim_step": 123}
 	# one decode token at context c: 152 boundaries + (block weights + head + KV cache of 16 candidates + logits) / 6.4 TB/s
 	P1 = 68
 	want = 0.0

@@ -391,11 +391,14 @@ int ttk_diff_begin(ttk_diff* h, const float* E, int b, int T, void* stream) {
 }
 
 // the part of a sampler step that sees x: layout change, network body on the integrated code stream `cs`, the DDIM / ancestral update
-static int step_body(ttk_diff* h, float* x, const ttk_step* st, const float* noise, const float* emb_row, const float* cs, hipEvent_t cs_consumed, hipStream_t s) {
+// staged: the previous step of this loop has already written this step's channels-last copy of x (its update launch did); next: the step that follows in this loop, or null --
+// its copy is then written by THIS step's update launch (round 6: one layout launch per loop instead of one per step; not for ragged batches, whose padding frames must read zero)
+static int step_body(ttk_diff* h, float* x, const ttk_step* st, const float* noise, const float* emb_row, const float* cs, hipEvent_t cs_consumed, hipStream_t s,
+					 bool staged = false, const ttk_step* next = nullptr) {
 	const int b = h->cur_b, T = h->cur_T;
 	const bool cf = st->cfk >= 0.f;
 	const int nb = cf ? 2 * b : b;
-	launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, cf ? 2 : 1, s, h->tlen);
+	if (!staged || h->tlen) launch_cf_to_cl(h->dt, x, b, h->cfg.in_channels, T, h->xcl.p, h->in_pad, cf ? 2 : 1, s, h->tlen);
 	float* out = (float*)h->outb.p;
 	body(h, nb, T, emb_row, 0, cs, out, s, cs_consumed);
 	StepCoefs k = {};
@@ -403,7 +406,9 @@ static int step_body(ttk_diff* h, float* x, const ttk_step* st, const float* noi
 	k.sqrt_1m_ac_prev = st->sqrt_1m_ac_prev; k.cfk = st->cfk; k.coef1 = st->coef1; k.coef2 = st->coef2;
 	k.min_log = st->min_log; k.max_log = st->max_log; k.sampler = st->sampler; k.nonzero = st->nonzero;
 	const int Cin = h->cfg.in_channels;
-	launch_diffusion_step(out, out + (size_t)b * h->cfg.out_channels * T, x, noise, b, Cin, T, k, s);
+	if (next && !h->tlen && (next->cfk >= 0.f) == cf) launch_diffusion_step(      // (same batch layout in the next step: its padding columns are already zero)
+		out, out + (size_t)b * h->cfg.out_channels * T, x, noise, b, Cin, T, k, s, h->xcl.p, h->in_pad, next->cfk >= 0.f ? 2 : 1, elem_kind(h->dt));
+	else launch_diffusion_step(out, out + (size_t)b * h->cfg.out_channels * T, x, noise, b, Cin, T, k, s);
 	return TTK_OK;
 }
 static int step_impl(ttk_diff* h, float* x, const ttk_step* st, const float* noise, const float* emb_row, hipStream_t s) {
@@ -477,7 +482,8 @@ static int sample_loop(ttk_diff* h, float* x, const float* E, int b, int T, cons
 		}
 		TTK_HIP(hipStreamWaitEvent(s, h->ev_int[j & 1], 0));
 		const int i = n_steps - 1 - j;
-		TTK_TRY(step_body(h, x, &steps[i], noise ? noise + (size_t)j * nz : nullptr, emb_all + i * stride, csb[j & 1], h->ev_free[j & 1], s));
+		const bool staged = j > 0 && (steps[i + 1].cfk >= 0.f) == (steps[i].cfk >= 0.f);      // the previous step's update launch wrote this step's copy (see step_body)
+		TTK_TRY(step_body(h, x, &steps[i], noise ? noise + (size_t)j * nz : nullptr, emb_all + i * stride, csb[j & 1], h->ev_free[j & 1], s, staged, i > 0 ? &steps[i - 1] : nullptr));
 	}
 	TTK_HIP(hipGetLastError());
 	return TTK_OK;

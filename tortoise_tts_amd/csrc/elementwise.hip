@@ -179,7 +179,9 @@ void launch_silu_cast(int dt, const float* x, void* y, int64_t n, hipStream_t s)
 //   x0 prediction       diffusion.py:433-438, clamp :401-403
 //   DDIM (eta = 0)      diffusion.py:675-693   eps' = (sqrt_recip_ac x - x0) / sqrt_recipm1_ac ; x = x0 sqrt(ac_prev) + sqrt(1-ac_prev) eps'
 //   ancestral "p"       diffusion.py:301-323, 366-373, 545-553   mean = c1 x0 + c2 x ; log_var from the learned range
-__global__ void k_diffusion_step(const float* out_c, const float* out_u, float* x, const float* noise, int nb, int C, int Tn, StepCoefs k) {
+// xcl (round 6, optional): the NEXT step's channels-last operand copy of the updated x -- what k_cf_to_cl would make of it ([rep * nb * T][ldo] in the kernel type, element kind
+// `ekind`; the zero padding columns C .. ldo stay as the first step's k_cf_to_cl left them) -- so that a loop of steps needs that launch once, not once per step
+__global__ void k_diffusion_step(const float* out_c, const float* out_u, float* x, const float* noise, int nb, int C, int Tn, StepCoefs k, void* xcl, int ldo, int rep, int ekind) {
 	const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const int64_t per = (int64_t)C * Tn;
 	if (idx >= nb * per) return;
@@ -193,20 +195,31 @@ __global__ void k_diffusion_step(const float* out_c, const float* out_u, float* 
 	const float xv = x[idx];
 	float x0 = k.sqrt_recip_ac * xv - k.sqrt_recipm1_ac * eps;
 	x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+	float xn;
 	if (k.sampler == 0) {
 		const float e2 = (k.sqrt_recip_ac * xv - x0) / k.sqrt_recipm1_ac;
-		x[idx] = x0 * k.sqrt_ac_prev + k.sqrt_1m_ac_prev * e2;
+		xn = x0 * k.sqrt_ac_prev + k.sqrt_1m_ac_prev * e2;
 	} else {
 		const float var = out_c[(int64_t)b * 2 * per + per + r];
 		const float frac = (var + 1.0f) / 2.0f;
 		const float log_var = frac * k.max_log + (1.0f - frac) * k.min_log;
 		const float mean = k.coef1 * x0 + k.coef2 * xv;
-		x[idx] = mean + (k.nonzero ? expf(0.5f * log_var) * noise[idx] : 0.f);
+		xn = mean + (k.nonzero ? expf(0.5f * log_var) * noise[idx] : 0.f);
+	}
+	x[idx] = xn;
+	if (xcl) {
+		const int c = (int)(r / Tn), t = (int)(r - (int64_t)c * Tn);
+		for (int q = 0; q < rep; ++q) {
+			const int64_t o = (((int64_t)q * nb + b) * Tn + t) * ldo + c;
+			if (ekind == EK_F32) ((float*)xcl)[o] = xn;
+			else if (ekind == EK_F16) ((f16*)xcl)[o] = cvt<f16>(xn);
+			else ((bf16*)xcl)[o] = cvt<bf16>(xn);
+		}
 	}
 }
-void launch_diffusion_step(const float* out_c, const float* out_u, float* x, const float* noise, int nb, int C, int T, StepCoefs c, hipStream_t s) {
+void launch_diffusion_step(const float* out_c, const float* out_u, float* x, const float* noise, int nb, int C, int T, StepCoefs c, hipStream_t s, void* xcl, int ldo, int rep, int ekind) {
 	const int64_t total = (int64_t)nb * C * T;
-	hipLaunchKernelGGL(k_diffusion_step, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out_c, out_u, x, noise, nb, C, T, c);
+	hipLaunchKernelGGL(k_diffusion_step, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out_c, out_u, x, noise, nb, C, T, c, xcl, ldo, rep, ekind);
 }
 
 }  // namespace ttk

@@ -267,7 +267,7 @@ struct StepCoefs {
 	float coef1, coef2, min_log, max_log; int sampler; int nonzero;            // sampler 0 ddim, 1 p
 };
 void launch_diffusion_step(const float* out_c, const float* out_u, float* x, const float* noise, int nb, int C, int T,
-						   StepCoefs c, hipStream_t s);
+						   StepCoefs c, hipStream_t s, void* xcl = nullptr, int ldo = 0, int rep = 0, int ekind = 0);      // xcl: also the next step's channels-last operand copy of x (elementwise.hip)
 
 // ---------------------------------------------------------------- packing (pack.hip)
 enum PackLayout { PK_NK = 0, PK_KN = 1, PK_CONV3 = 2, PK_CONVK = 3, PK_CONVT = 4 };   // CONVK: src[n][k][ntap]; CONVT: src[k][n][ntap]
