@@ -14,7 +14,11 @@
 // (cdna_hip_programming.md section 5 "Pipelining across barriers").  The swizzle lives on the per-lane SOURCE address (LDS
 // destination of a glds is lane-linear); rows outside M or outside a conv tap's batch element use an out-of-range buffer offset
 // (the buffer hardware returns zeros).
-// Roofline: MFMA-bound for the diffusion shapes (M = b*T ~ 2k rows, N,K in 1k..3k); bytes/flop is tiny.
+// Three forms of the k-loop since round 6: the hand-ordered stream for wave blocks up to 64 x 32 (16-bit operands: `pipe_*` below), the same stream at half-tile granularity for the
+// 64 x 64 wave blocks of the 256 x 128 tile, and the compiler-ordered ping-pong (f32, fp8, residual roles at 256 x 128, rings that are not 3 deep).  The k = 3 residual convolution of
+// the DDIM loop runs on a shared activation image instead of the ring (conv3_image_tile).  Every k = 3 'same' convolution adds its products tap-inner (see gemm_tile).
+// Roofline: by flops these shapes are MFMA-bound (M = b*T ~ 2k rows, N, K in 1k..3k); at one 128 x 64 tile per CU what bounds the k-loop is the L2 -> LDS intake of a CU
+// (59 B/clk with four waves) and the chip's L2 bandwidth, 24 KiB per trip either way.
 #include <stdlib.h>
 
 #include <type_traits>
